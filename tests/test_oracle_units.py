@@ -1,0 +1,128 @@
+"""Known-answer and cross-implementation checks of the oracle (CPU only).
+
+oracle/stft.py is "parity unpinned" (librosa absent): these tests hold it to the
+mathematical known answers listed in SURVEY.md section 4 and to two independent
+implementations of the same documented semantics (torch.stft, scipy.signal)."""
+import itertools
+
+import numpy as np
+import pytest
+import scipy.signal
+import torch
+
+from oracle import stft as S
+from oracle import upit as O
+
+
+def _sig(n, seed=0):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(n) * 0.1).astype(np.float32)
+
+
+def test_hann_is_scipy_periodic_hann_and_sums_to_1p5():
+    w = S.hann_periodic(512)
+    np.testing.assert_allclose(w, scipy.signal.get_window("hann", 512, fftbins=True), atol=1e-7)
+    wss = np.zeros(512 + 128 * 20)
+    for t in range(21):
+        wss[t * 128:t * 128 + 512] += w.astype(np.float64) ** 2
+    np.testing.assert_allclose(wss[512:-512], 1.5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [51072, 24000, 4097, 700])
+def test_stft_shape_and_torch_agreement(n):
+    y = _sig(n, n)
+    X = S.stft(y)
+    assert X.shape == (257, 1 + n // 128) and X.dtype == np.complex64
+    Xt = torch.stft(torch.from_numpy(y), 512, hop_length=128, window=torch.hann_window(512, periodic=True),
+                    center=True, pad_mode="reflect", return_complex=True).numpy()
+    np.testing.assert_allclose(X, Xt, atol=2e-5 * np.abs(Xt).max())
+
+
+def test_stft_scipy_agreement():
+    y = _sig(8192, 3)
+    ypad = np.pad(y, 256, mode="reflect")
+    _, _, Z = scipy.signal.stft(ypad, window=scipy.signal.get_window("hann", 512, fftbins=True), nperseg=512,
+                                noverlap=384, boundary=None, padded=False)
+    Z = Z * scipy.signal.get_window("hann", 512, fftbins=True).sum()     # undo scipy's spectrum scaling
+    np.testing.assert_allclose(S.stft(y), Z, atol=2e-5 * np.abs(Z).max())
+
+
+@pytest.mark.parametrize("n", [51072, 6400, 1000])
+def test_istft_inverts_stft_and_lengths(n):
+    y = _sig(n, 7)
+    X = S.stft(y)
+    yr = S.istft(X)
+    T = X.shape[1]
+    assert yr.shape == (128 * (T - 1),) and yr.dtype == np.float32
+    np.testing.assert_allclose(yr, y[:128 * (T - 1)], atol=2e-6)
+    yt = torch.istft(torch.from_numpy(X), 512, hop_length=128, window=torch.hann_window(512, periodic=True),
+                     center=True, length=128 * (T - 1)).numpy()
+    np.testing.assert_allclose(yr, yt, atol=2e-6)
+
+
+def test_int16_truncates_and_wraps():
+    s = np.array([0.0, 0.5, -0.5, 0.99999, 3.05e-5, -3.05e-5, 1.5, -1.5], dtype=np.float32)
+    got = S.to_int16_wav(s)
+    # truncation toward zero, wrap (no saturation) beyond +-1 (steps/reconstruct_sources.py:41-42)
+    assert got.tolist() == [0, 16383, -16383, 32766, 0, 0, 49150 - 65536, -49150 + 65536]
+    inr = s[:6]
+    assert np.array_equal(S.to_int16_wav(inr), (inr * 32767).astype("int16"))
+
+
+def _random_model(H, L, S_, seed=0):
+    torch.manual_seed(seed)
+    return O.OracleSepDNN(feat_dim=33, num_spk=S_, hidden_dim=H, num_layers=L)
+
+
+@pytest.mark.parametrize("lens", [[9, 7, 7, 3], [5, 5, 5], [1, 6]])
+def test_padded_masked_blstm_equals_packed_lstm(lens):
+    model = _random_model(12, 3, 2)
+    B, T = len(lens), max(lens)
+    order = O.collate_order(lens)
+    lens_sorted = [lens[i] for i in order]
+    xs = [torch.randn(t, 33) for t in lens_sorted]
+    packed = torch.nn.utils.rnn.pack_sequence(xs)
+    h0, c0 = model.init_hidden(B)
+    yp, (hn, cn) = model.blstm(packed, (h0, c0))
+    yp, _ = torch.nn.utils.rnn.pad_packed_sequence(yp)            # (T,B,2H) zeros past len
+    x = torch.zeros(T, B, 33)
+    for b, v in enumerate(xs):
+        x[:v.shape[0], b] = v
+    y, hn2, cn2 = O.blstm_padded(x, lens_sorted, O.lstm_weights(model), h0, c0)
+    np.testing.assert_allclose(y.numpy(), yp.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(hn2.numpy(), hn.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(cn2.numpy(), cn.detach().numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize("S_", [1, 2, 3])
+def test_pit_properties(S_):
+    torch.manual_seed(S_)
+    B, T, F = 3, 5, 7
+    mask = torch.rand(B, T, F * S_)
+    mix = torch.rand(B, T, F)
+    srcs = [torch.rand(B, T, F) for _ in range(S_)]
+    lens = torch.tensor([5, 4, 2])
+    loss, norm, losses, idx = O.pit_mse(mask, mix, srcs, lens, S_, F)
+    # permuting the source order never changes the loss
+    for perm in itertools.permutations(range(S_)):
+        l2, *_ = O.pit_mse(mask, mix, [srcs[i] for i in perm], lens, S_, F)
+        np.testing.assert_allclose(float(l2), float(loss), rtol=1e-6)
+    # min over S! perms == min over assignments of the SxS pairwise SSE matrix
+    masked = (mask.view(B, T, S_, F) * mix.unsqueeze(2))
+    pair = torch.stack([torch.stack([((masked[:, :, s] - srcs[r]) ** 2).sum((1, 2)) for r in range(S_)], 1)
+                        for s in range(S_)], 1)                               # (B,S,S)
+    perms = list(itertools.permutations(range(S_)))
+    from_pair = torch.stack([sum(pair[:, s, p[s]] for s in range(S_)) for p in perms])
+    np.testing.assert_allclose(from_pair.numpy(), losses.numpy(), rtol=1e-5)
+    if S_ == 1:
+        np.testing.assert_allclose(float(loss * norm), float(((mask * mix - srcs[0]) ** 2).sum()), rtol=1e-6)
+
+
+def test_si_sdr_known_values():
+    rng = np.random.default_rng(0)
+    ref = rng.standard_normal(8000)
+    assert O.si_sdr(3.0 * ref, ref) > 100          # scale invariant
+    noise = rng.standard_normal(8000)
+    noise -= noise.dot(ref) / ref.dot(ref) * ref
+    est = ref + noise * np.sqrt(ref.dot(ref) / noise.dot(noise)) * 0.1
+    np.testing.assert_allclose(O.si_sdr(est, ref), 20.0, atol=0.05)
