@@ -1,0 +1,161 @@
+/* sepkern.h -- C ABI of libsepkern.so: the MI355X (gfx950) kernels under the uPIT hot path.
+ *
+ * The reference (mmaciej2/speech-separation) has no FFI: its hot path is library calls made
+ * from Python (torch / librosa).  Each entry point below replaces the library call(s) cited
+ * next to it and is what the host-side mirror of archs/uPIT.py, steps/extract_feats.py and
+ * steps/reconstruct_sources.py binds through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SK_E* code otherwise; nothing throws
+ *     across the boundary; sk_last_error() returns a thread-local message for the last failure
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
+ *     buffer (the library allocates nothing); workspace sizes are queried
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*)
+ *   - tensors are row-major contiguous fp32; sequence tensors are time-major (T, B, C)
+ *   - LSTM weight layout is torch's per-parameter layout (gate rows i,f,g,o), so a
+ *     reference state_dict round-trips unchanged
+ */
+#ifndef SEPKERN_H
+#define SEPKERN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SK_VERSION 100
+
+#define SK_OK 0
+#define SK_EINVAL (-1)   /* bad argument / unsupported shape */
+#define SK_ELAUNCH (-2)  /* HIP launch or runtime error      */
+#define SK_ETIMEOUT (-3) /* a persistent kernel's bounded spin gave up (see sk_lstm_status) */
+
+typedef void* sk_stream_t; /* hipStream_t */
+
+int sk_version(void);
+const char* sk_last_error(void);
+/* number of CUs / LDS bytes per workgroup of the current device */
+int sk_device_info(int* num_cu, int* lds_bytes);
+
+/* ---------------------------------------------------------------- STFT front end
+ * Replaces librosa.core.load's PCM scaling + librosa.core.stft(n_fft=512, hop=128) [+ np.abs]
+ * (reference steps/extract_feats.py:85-89 train, :104-105 test).
+ * Utterance u: samples wav[wav_offs[u] .. +nsamp[u]) (float32, or int16 PCM scaled by 1/32768
+ * when pcm16 != 0); T_u = 1 + nsamp[u]/hop frames, reflect-padded by n_fft/2, periodic Hann.
+ * Output element (t, f) of utterance u goes to out[out_offs[u] + t*stride_t[u] + f*stride_f[u]]
+ * (units: elements; float32 magnitude when want_complex == 0, interleaved complex64 otherwise).
+ * (stride_t = F, stride_f = 1) is the (T,F) training layout; (1, T_u) is the reference's
+ * on-disk (F, T) layout.  max_frames >= max_u T_u sizes the grid.  n_fft must be 512. */
+int sk_stft(const void* wav, int pcm16, const int64_t* wav_offs, const int32_t* nsamp, int nutt,
+            int n_fft, int hop, int want_complex, void* out, const int64_t* out_offs,
+            const int64_t* stride_t, const int64_t* stride_f, int max_frames, sk_stream_t stream);
+
+/* ---------------------------------------------------------------- mask-apply + iSTFT back end
+ * Replaces np.multiply(mix_spec, mask) + librosa.core.istft(hop_length=128) + (*32767).astype(int16)
+ * (reference steps/reconstruct_sources.py:39-42).  For utterance u and source s:
+ *   spec (f,t) = mix[mix_offs[u] + f*mix_sf[u] + t*mix_st[u]] (complex64)
+ *   mask (f,t) = mask[mask_offs[u*S+s] + f*mask_sf[u] + t*mask_st[u]] (float32; NULL mask = all ones)
+ * Output 128*(T_u-1) samples at wav_out / pcm_out + out_offs[u*S+s] (either may be NULL).
+ * int16 conversion truncates toward zero and WRAPS (no saturation), as the reference does. */
+int sk_mask_istft(const void* mix_c64, const int64_t* mix_offs, const int64_t* mix_st, const int64_t* mix_sf,
+                  const float* mask, const int64_t* mask_offs, const int64_t* mask_st, const int64_t* mask_sf,
+                  const int32_t* nframes, int nutt, int S, int n_fft, int hop,
+                  float* wav_out, int16_t* pcm_out, const int64_t* out_offs, int max_frames,
+                  sk_stream_t stream);
+
+/* ---------------------------------------------------------------- fp32 MFMA GEMM
+ * C[M,N] (ldc) = act( opA(A) * opB(B) + bias[n] + (accumulate ? C : 0) ).
+ * transA == 0: A is M x K row-major (lda); transA != 0: A is stored K x M row-major (lda).
+ * transB == 0: B is K x N row-major (ldb); transB != 0: B is stored N x K row-major (ldb).
+ * act: 0 none, 1 sigmoid.  bias may be NULL.  batch > 1 runs `batch` independent problems with
+ * pointer strides sA/sB/sC/sbias (elements).  Replaces the matrix products inside nn.LSTM's input
+ * projection, nn.Linear and their backward passes (reference archs/uPIT.py:132,141). */
+int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
+                int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, sk_stream_t stream);
+
+/* ---------------------------------------------------------------- BLSTM recurrence
+ * One bidirectional LSTM layer's time recurrence (the part of nn.LSTM, reference
+ * archs/uPIT.py:115,132, that cannot be batched over time), with packed-sequence semantics
+ * on padded input: for row b the state is frozen and y is 0 at t >= lens[b]; the reverse
+ * direction starts from (h0,c0) at t = lens[b]-1.
+ *   gx    (T,B,2,4H)  input projections x*W_ih^T + b_ih + b_hh for both directions
+ *   whh   (2,4H,H)    recurrent weights (torch layout, gate rows i,f,g,o)
+ *   h0,c0 (2,B,H)     initial state of this layer;  hn,cn (2,B,H) final state (may be NULL)
+ *   y     (T,B,2H)    layer output [fwd | bwd]
+ *   gates (T,B,2,4H)  post-activation i,f,g,o and cs (T,B,2,H) cell states, saved for the
+ *                     backward pass (both NULL for inference)
+ *   ws    workspace of sk_lstm_workspace_bytes(); zeroed by the call itself
+ * mode: 0 auto, 1 persistent (one launch, flag-synchronised time loop), 2 one launch per step. */
+size_t sk_lstm_workspace_bytes(int T, int B, int H);
+int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
+                float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
+                int T, int B, int H, int mode, sk_stream_t stream);
+/* Backward of the recurrence.  dy (T,B,2H) is the gradient of the layer output; produces
+ * dgx (T,B,2,4H) = gradient of the gate pre-activations (zero at padded positions), from which
+ * the caller forms dW_ih, dW_hh, db and dx with sk_gemm_f32 / sk_colsum, and dh0/dc0 (2,B,H; may
+ * be NULL).  y is the forward output (h_t), used for nothing but is kept for symmetry. */
+int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs,
+                const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0, void* ws,
+                int T, int B, int H, int mode, sk_stream_t stream);
+/* After a persistent launch has completed: 0, or SK_ETIMEOUT if a bounded spin gave up
+ * (reads one word of the workspace back to the host; synchronises the stream). */
+int sk_lstm_status(const void* ws, sk_stream_t stream);
+/* dW_hh += sum_t dgx_t^T h_{t-1}: fills hprev (T,B,2,H) with the recurrent input of every step
+ * (h0 at a row's first step, the previous output otherwise, 0 at padded positions). */
+int sk_lstm_hprev(const float* y, const float* h0, const int32_t* lens, float* hprev,
+                  int T, int B, int H, sk_stream_t stream);
+
+/* ---------------------------------------------------------------- BatchNorm1d over (rows, C)
+ * Replaces nn.BatchNorm1d(2H) on (B, 2H, T) (reference archs/uPIT.py:119,138): statistics over
+ * ALL rows = B*T_max positions, zero-padded frames included.
+ * stats: mean[c], var[c] (biased) over R rows (two-pass); ws >= sk_bn_workspace_bytes(R,C). */
+size_t sk_bn_workspace_bytes(int R, int C);
+int sk_bn_stats(const float* x, int R, int C, float* mean, float* var, void* ws, sk_stream_t stream);
+/* running = (1-momentum)*running + momentum*batch (var unbiased, n/(n-1)), as torch does */
+int sk_bn_update_running(const float* mean, const float* var, float* running_mean, float* running_var,
+                         int R, int C, float momentum, sk_stream_t stream);
+/* out = (x - mean) / sqrt(var + eps) * gamma + beta */
+int sk_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                float* out, int R, int C, float eps, sk_stream_t stream);
+/* training-mode backward: dgamma, dbeta, dx from dout, x and the batch statistics */
+int sk_bn_bwd(const float* dout, const float* x, const float* mean, const float* var, const float* gamma,
+              float* dx, float* dgamma, float* dbeta, void* ws, int R, int C, float eps, sk_stream_t stream);
+
+/* out[c] (+)= sum_r x[r*ld + c]   (bias gradients); ws >= sk_bn_workspace_bytes(R,C) */
+int sk_colsum(const float* x, int R, int C, int ld, float* out, int accumulate, void* ws, sk_stream_t stream);
+/* dz = dmask * m * (1 - m)   (sigmoid backward, reference archs/uPIT.py:144) */
+int sk_sigmoid_bwd(const float* dmask, const float* m, float* dz, int64_t n, sk_stream_t stream);
+
+/* ---------------------------------------------------------------- PIT-MSE loss
+ * Replaces the loss body of compute_loss (reference archs/uPIT.py:181-197,206).
+ *   mask (T,B,S*F), mix (T,B,F), src_host[s] -> (T,B,F) device pointers (host array of S), lens (B)
+ *   pair_sse (B,S,S): pair[b][s][r] = sum_{t,f} (mask[t,b,s,f]*mix[t,b,f] - src_r[t,b,f])^2
+ *   perm_loss (S!,B) in itertools.permutations order; best_perm (B) = argmin (first minimum)
+ *   out[0] = loss/norm, out[1] = norm = sum(lens)*F, out[2] = sum_b min loss / S
+ * norm_override > 0 replaces norm (data-parallel training divides by the GLOBAL norm). */
+size_t sk_pit_workspace_bytes(int T, int B, int S);
+int sk_pit_mse_fwd(const float* mask, const float* mix, const float* const* src_host, const int32_t* lens,
+                   int T, int B, int F, int S, float norm_override, float* pair_sse, float* perm_loss,
+                   int32_t* best_perm, float* out, void* ws, sk_stream_t stream);
+/* dmask = gscale[0] * 2 * (mask*mix - src_{best_perm[b][s]}) * mix / (S * norm), norm = out[1] */
+int sk_pit_mse_bwd(const float* mask, const float* mix, const float* const* src_host,
+                   const int32_t* best_perm, const float* out, const float* gscale,
+                   int T, int B, int F, int S, float* dmask, sk_stream_t stream);
+
+/* ---------------------------------------------------------------- clip_grad_norm_ + Adam
+ * Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step()
+ * (reference steps/train_qsub.py:121-122) on ONE flat fp32 buffer holding every parameter.
+ *   scal[0] = total grad L2 norm, scal[1] = clip coefficient min(1, max_norm/(norm+1e-6))
+ * step is the 1-based Adam step count. ws >= sk_optim_workspace_bytes(n). */
+size_t sk_optim_workspace_bytes(int64_t n);
+int sk_grad_norm(const float* g, int64_t n, float max_norm, float* scal, void* ws, sk_stream_t stream);
+int sk_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* scal,
+                 float lr, float beta1, float beta2, float eps, int step, sk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

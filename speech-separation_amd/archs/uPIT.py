@@ -1,0 +1,368 @@
+#!/usr/bin/env python3
+"""uPIT arch plug-in, MI355X-native: drop-in for the reference's archs/uPIT.py.
+
+Same module-level protocol (looked up by name from steps/train_qsub.py:66,80-95,117-135 and
+steps/eval_qsub.py:43-72 of the reference):
+
+    TrainSet(datadir, location="")   .collator      reads <datadir>/feats_train.scp
+    TestSet(datadir)                 .collator      reads <datadir>/feats_test.scp
+    SepDNN(gpuid, **kwargs)          nn.Module; kwargs are strings from the conf file
+    compute_loss(model, epoch, batch_sample, plotdir="")     -> (loss/norm, norm) 0-dim tensors
+    compute_cv_loss(model, epoch, batch_sample, plotdir="")  -> same
+    compute_masks(model, batch_sample, out_dir)              -> writes <out_dir>/<id>.npz
+
+All numerics run in libsepkern.so (hand-written gfx950 kernels, see include/sepkern.h) through
+sepkern.engine; there is NO CPU path -- SepDNN(-1) or a missing library raises.
+
+Beyond the reference (all optional, defaults reproduce it):
+  * conf keys hidden_dim (600) and num_layers (2): the reference hard-codes 2x600
+    (archs/uPIT.py:115-119); BASELINE's 2x300 / 3x896 configurations need them.
+  * model.hidden_generator: a torch.Generator for the randn h0/c0 the reference draws per batch
+    (archs/uPIT.py:121-127); tests inject (h0, c0) by assigning model.next_hidden.
+  * under torch.distributed (one process per GPU) gradients are all-reduced over RCCL inside
+    backward and the loss is normalised by the GLOBAL frame count.
+"""
+import collections.abc
+import itertools
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import PackedSequence, pack_sequence, pad_packed_sequence
+from torch.utils.data import Dataset
+from torch.utils.data.dataloader import default_collate
+
+try:
+    import sepkern  # noqa: F401
+except ImportError:  # the frozen copy exp/<...>/arch.py is imported from another directory
+    for cand in (os.environ.get("SEPKERN_HOME"), "speech-separation_amd",
+                 os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")):
+        if cand and os.path.isdir(os.path.join(cand, "sepkern")):
+            sys.path.insert(0, os.path.abspath(cand))
+            break
+    import sepkern  # noqa: F401
+from sepkern import ops
+from sepkern.engine import Engine
+from sepkern._lib import SepkernError
+
+
+# Define collating function (that constructs packed sequences from a batch)
+class Collator():
+  """Same contract as the reference Collator (archs/uPIT.py:23-48): dict samples are sorted by
+  the length of `sort_key` (descending, via argsort()[::-1]) and every ndarray entry becomes a
+  float32 PackedSequence; everything else goes through default_collate."""
+
+  def __init__(self, sort_key):
+    self.key = sort_key
+    if not self.key:
+      print("Warning: you have not provided a sort key.")
+      print("  If you are using RNNs with variable-length input, you must")
+      print("  provide the key for element in each sample that is the input")
+      print("  of variable length.")
+
+  def __call__(self, batch):
+    if not self.key:
+      return default_collate(batch)
+    if isinstance(batch[0], collections.abc.Mapping):
+      sort_inds = np.argsort(np.array([len(d[self.key]) for d in batch]))[::-1]
+      return {key: self.__call__([batch[i][key] for i in sort_inds]) for key in batch[0]}
+    if isinstance(batch[0], np.ndarray):
+      if re.search('[SaUO]', batch[0].dtype.str) is not None:
+        raise TypeError("batch must contain tensors, numbers, dicts or lists; found {}".format(batch[0].dtype))
+      return pack_sequence([(torch.from_numpy(b)).float() for b in batch])
+    return default_collate(batch)
+
+
+def _read_scp(path):
+  return [line.rstrip('\n').split(' ')[1] for line in open(path)]
+
+
+# Define dataset
+class TrainSet(Dataset):
+  """feats_train.scp -> {'mix': (T,F), 'source1': (T,F), ...} (reference archs/uPIT.py:51-79)."""
+
+  def __init__(self, datadir, location=""):
+    filelist = datadir + "/feats_train.scp"
+    self.list = _read_scp(filelist)
+    if location:
+      # the reference shells out to tools/copy_scp_data_to_dir.sh (rsync); same effect, in-process
+      staged = []
+      for path in self.list:
+        dst = location + '/' + path
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        if not os.path.exists(dst):
+          shutil.copy2(path, dst)
+        staged.append(dst)
+      self.list = staged
+    self.collator = Collator('mix')
+
+  def __len__(self):
+    return len(self.list)
+
+  def __getitem__(self, idx):
+    feat = np.load(self.list[idx])
+    mix_mag_spec = feat['mix'].transpose()
+    sample = {'mix': mix_mag_spec}
+    if len(feat.files) == 1:
+      sample["source1"] = mix_mag_spec
+    else:
+      for src in range(len(feat.files) - 1):
+        sample["source" + str(src + 1)] = feat['s' + str(src + 1)].transpose()
+    return sample
+
+
+class TestSet(Dataset):
+  """feats_test.scp -> {'mix': |complex STFT| (T,F), 'name': '<id>.npz'} (reference archs/uPIT.py:81-94)."""
+
+  def __init__(self, datadir):
+    self.list = _read_scp(datadir + "/feats_test.scp")
+    self.collator = Collator('mix')
+
+  def __len__(self):
+    return len(self.list)
+
+  def __getitem__(self, idx):
+    mix_mag_spec = np.abs(np.load(self.list[idx])['mix']).transpose()
+    return {'mix': mix_mag_spec, 'name': os.path.basename(self.list[idx])}
+
+
+class _Params(nn.Module):
+  """A bag of named parameters/buffers (keeps the reference's state_dict keys, e.g. blstm.weight_ih_l0)."""
+
+
+class _NetFn(torch.autograd.Function):
+  """mask = net(x); backward runs the libsepkern backward kernels and leaves the gradients in the
+  flat gradient buffer that every param.grad is a view of."""
+
+  @staticmethod
+  def forward(ctx, anchor, model, x, lens, h0, c0):
+    ctx.model = model
+    ctx.saved_fwd = torch.is_grad_enabled() or anchor.requires_grad
+    return model._engine.forward(x, lens, h0, c0, model.training, save=True)
+
+  @staticmethod
+  def backward(ctx, dmask):
+    model = ctx.model
+    model._engine.backward(dmask)
+    model._allreduce_grads()
+    return None, None, None, None, None, None
+
+
+class _PitFn(torch.autograd.Function):
+  """out = [loss/norm, norm, sum_b min_p L/S] (reference archs/uPIT.py:181-197,206)."""
+
+  @staticmethod
+  def forward(ctx, mask, mix, lens, norm_override, *srcs):
+    res = ops.pit_mse_fwd(mask, mix, list(srcs), lens, norm_override)
+    ctx.save_for_backward(mask, mix, res["best_perm"], res["out"], *srcs)
+    ctx.mark_non_differentiable(res["best_perm"])
+    return res["out"], res["best_perm"]
+
+  @staticmethod
+  def backward(ctx, gout, _gperm):
+    mask, mix, best, out = ctx.saved_tensors[:4]
+    srcs = list(ctx.saved_tensors[4:])
+    dmask = ops.pit_mse_bwd(mask, mix, srcs, best, out, gout[0:1].contiguous())
+    return (dmask, None, None, None) + (None,) * len(srcs)
+
+
+# define nnet
+class SepDNN(nn.Module):
+  def __init__(self, gpuid, **kwargs):
+    super(SepDNN, self).__init__()
+    self.gpuid = gpuid
+    if int(gpuid) < 0:
+      raise SepkernError("SepDNN(gpuid=%s): this build has no CPU path; it runs on an MI355X only" % gpuid)
+    self.feat_dim = int(kwargs.get('feat_dim', 257))
+    self.num_spk = int(kwargs.get('num_spk', 2))
+    self.hidden_dim = int(kwargs.get('hidden_dim', 600))
+    self.num_layers = int(kwargs.get('num_layers', 2))
+    for key in kwargs.keys():
+      print('modelparam:', key, kwargs[key])
+    H, L = self.hidden_dim, self.num_layers
+
+    # Initial values exactly as the reference draws them (archs/uPIT.py:115-119: nn.LSTM, nn.Linear,
+    # nn.BatchNorm1d constructed in this order consume the RNG identically); the modules are only
+    # used as initialisers, the kernels never call them.
+    init_lstm = nn.LSTM(self.feat_dim, H, num_layers=L, bidirectional=True)
+    init_lin = nn.Linear(H * 2, self.feat_dim * self.num_spk)
+    init_bn = nn.BatchNorm1d(H * 2)
+    self.blstm = _Params()
+    for name, p in init_lstm.named_parameters():
+      self.blstm.register_parameter(name, nn.Parameter(p.detach().clone()))
+    self.lin = _Params()
+    self.lin.register_parameter('weight', nn.Parameter(init_lin.weight.detach().clone()))
+    self.lin.register_parameter('bias', nn.Parameter(init_lin.bias.detach().clone()))
+    self.bn = _Params()
+    self.bn.register_parameter('weight', nn.Parameter(init_bn.weight.detach().clone()))
+    self.bn.register_parameter('bias', nn.Parameter(init_bn.bias.detach().clone()))
+    self.bn.register_buffer('running_mean', init_bn.running_mean.clone())
+    self.bn.register_buffer('running_var', init_bn.running_var.clone())
+    self.bn.register_buffer('num_batches_tracked', init_bn.num_batches_tracked.clone())
+
+    self.hidden = None
+    self.next_hidden = None          # tests: (h0, c0) used by the next init_hidden call
+    self.hidden_generator = None
+    self._engine = None
+    self._anchor = None
+
+  # ---- parameter storage: every nn.Parameter is a view into the engine's flat buffer
+  def _named_views(self, eng, flat_view):
+    for l in range(self.num_layers):
+      for d, sfx in enumerate(("", "_reverse")):
+        for base in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+          yield getattr(self.blstm, "%s_l%d%s" % (base, l, sfx)), flat_view("%s_l%d" % (base, l))[d]
+    yield self.lin.weight, flat_view("lin.weight")
+    yield self.lin.bias, flat_view("lin.bias")
+    yield self.bn.weight, flat_view("bn.weight")
+    yield self.bn.bias, flat_view("bn.bias")
+
+  def _bind(self):
+    """(Re)attach parameters to the flat buffers; cheap when already bound."""
+    dev = self.lin.weight.device
+    if dev.type != 'cuda':
+      raise SepkernError("SepDNN must be moved to the GPU (model.cuda()) before use; there is no CPU path")
+    eng = self._engine
+    if eng is not None and eng.device == dev and self.lin.weight.data_ptr() == eng.p("lin.weight").data_ptr():
+      eng.running_mean, eng.running_var = self.bn.running_mean, self.bn.running_var
+      return eng
+    with torch.cuda.device(dev):
+      eng = Engine(self.feat_dim, self.num_spk, self.hidden_dim, self.num_layers, dev)
+    with torch.no_grad():
+      for p, v in self._named_views(eng, eng.p):
+        v.copy_(p.data)
+        p.data = v
+      for p, gv in self._named_views(eng, eng.g):
+        if p.grad is not None:
+          gv.copy_(p.grad)
+        p.grad = gv
+    eng.running_mean, eng.running_var = self.bn.running_mean, self.bn.running_var
+    self._engine = eng
+    self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+    return eng
+
+  def zero_grad(self, set_to_none=False):
+    # gradients stay views of the flat buffer; the next backward overwrites them
+    if self._engine is not None:
+      self._engine.zero_grad()
+    else:
+      super(SepDNN, self).zero_grad(set_to_none=False)
+
+  def flat_parameters(self):
+    """(params, grads): the two flat fp32 buffers (for sepkern.optim.ClipAdam and the DP all-reduce)."""
+    eng = self._bind()
+    return eng.flat, eng.grad
+
+  def _allreduce_grads(self):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+      dist.all_reduce(self._engine.grad)            # one RCCL collective over the whole gradient
+
+  def init_hidden(self, batch_size):
+    """h0, c0 ~ N(0,1), shape (2L, B, H), fresh for every batch (reference archs/uPIT.py:121-127)."""
+    if self.next_hidden is not None:
+      h, self.next_hidden = self.next_hidden, None
+      return h
+    dev = self.lin.weight.device
+    shape = (2 * self.num_layers, batch_size, self.hidden_dim)
+    return (torch.randn(shape, device=dev, generator=self.hidden_generator),
+            torch.randn(shape, device=dev, generator=self.hidden_generator))
+
+  def forward_padded(self, x, lens):
+    """x (T,B,F) time-major zero-padded CUDA tensor, lens int32 CUDA (B) -> mask (T,B,F*S)."""
+    eng = self._bind()
+    if self.hidden is None:
+      self.hidden = self.init_hidden(x.shape[1])
+    h0, c0 = self.hidden
+    h0 = h0.to(x.device, torch.float32).contiguous()
+    c0 = c0.to(x.device, torch.float32).contiguous()
+    if self.training:
+      self.bn.num_batches_tracked += 1
+    if torch.is_grad_enabled():
+      return _NetFn.apply(self._anchor, self, x, lens, h0, c0)
+    return eng.forward(x, lens, h0, c0, self.training, save=False)
+
+  def forward(self, x):
+    # x: packed sequence of dim feat_dim  ->  tensor of shape (batch, seq_length, feat_dim*num_spk)
+    xp, lens = _to_padded(x, self.lin.weight.device)
+    return self.forward_padded(xp, lens).permute(1, 0, 2)
+
+
+def _to_padded(packed, device):
+  """PackedSequence (as the Collator builds it) -> zero-padded time-major CUDA tensor + int32 lengths."""
+  if not isinstance(packed, PackedSequence):
+    raise TypeError("expected a PackedSequence from the arch's collator")
+  x, lens = pad_packed_sequence(packed.to(device))
+  return x.contiguous(), lens.to(device=device, dtype=torch.int32)
+
+
+def compute_cv_loss(model, epoch, batch_sample, plotdir=""):
+  if plotdir:
+    loss, norm = compute_loss(model, epoch, batch_sample, plotdir)
+  else:
+    loss, norm = compute_loss(model, epoch, batch_sample)
+  return loss, norm
+
+
+# define training pass
+def compute_loss(model, epoch, batch_sample, plotdir=""):
+  dev = model.lin.weight.device
+  mix, lens = _to_padded(batch_sample['mix'], dev)
+  batch = mix.shape[1]
+  sources = [_to_padded(batch_sample['source' + str(i + 1)], dev)[0] for i in range(model.num_spk)]
+
+  model.zero_grad()
+  model.hidden = model.init_hidden(batch)
+
+  norm_override = 0.0
+  import torch.distributed as dist
+  if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    gn = (lens.sum().float() * model.feat_dim).reshape(1)
+    dist.all_reduce(gn)
+    norm_override = float(gn.item())
+
+  mask_out = model.forward_padded(mix, lens)
+  # mask_out: tensor of shape (seq_length, batch, feat_dim*num_spk)
+  out, best = _PitFn.apply(mask_out, mix, lens, norm_override, *sources)
+  loss, norm = out[0], out[1].detach()
+
+  if plotdir:
+    sys.path.append('tools')
+    import plot
+    os.system("mkdir -p " + plotdir)
+    F = model.feat_dim
+    m0 = mask_out[:, 0].detach()
+    masked = (m0.view(-1, model.num_spk, F) * mix[:, 0].unsqueeze(1)).reshape(-1, model.num_spk * F)
+    plot.plot_spec(mix[:, 0].cpu().numpy(), plotdir + '/Mixture.png')
+    plot.plot_spec(masked.cpu().numpy(), plotdir + '/Masked_Mixture.png')
+    permutation = list(itertools.permutations(range(model.num_spk)))[int(best[0])]
+    plot.plot_spec(torch.cat([sources[i][:, 0] for i in permutation], dim=1).cpu().numpy(),
+                   plotdir + '/Chosen_Permutation.png')
+
+  return loss, norm
+
+
+# define test pass
+def compute_masks(model, batch_sample, out_dir):
+  dev = model.lin.weight.device
+  mix, lens = _to_padded(batch_sample['mix'], dev)
+  name = batch_sample['name']
+  batch = mix.shape[1]
+
+  model.zero_grad()
+  model.hidden = model.init_hidden(batch)
+
+  with torch.no_grad():
+    mask_out = model.forward_padded(mix, lens).permute(1, 0, 2)
+  mask_np = mask_out.cpu().numpy()
+  lens = lens.cpu().numpy()
+  for i in range(len(name)):
+    mask = mask_np[i].transpose()[:, 0:lens[i]]
+    file_dict = dict()
+    for src in range(model.num_spk):
+      file_dict['s' + str(src + 1)] = mask[src * model.feat_dim:(src + 1) * model.feat_dim]
+    np.savez_compressed(out_dir + '/' + name[i], **file_dict)

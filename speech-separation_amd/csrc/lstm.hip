@@ -1,0 +1,586 @@
+// lstm.hip -- the time recurrence of one bidirectional LSTM layer on gfx950, forward and backward.
+//
+// Reference: nn.LSTM(257, H, L, bidirectional=True) on a PackedSequence (archs/uPIT.py:115,132).
+// The input projections x*W_ih^T for all T*B rows are a plain GEMM (gemm.hip); what remains is
+// the sequential part  gates_t = gx_t + h_{t-1} W_hh^T  ->  cell update,  T steps per direction.
+//
+// Design (MI355X-first):
+//  * One workgroup per CU owns 16 hidden units x 16 batch rows of one direction.  Its slice of
+//    W_hh (64 gate rows x H, up to 256 KB) lives in the VGPRs of its 4 waves for the WHOLE
+//    sequence: 4*KS registers per lane feed v_mfma_f32_16x16x4_f32 as the A operand, so the
+//    recurrent weights are read from HBM once per layer, not once per step.
+//  * The MFMA is issued transposed (rows = gate columns, cols = batch) with gate rows
+//    interleaved (4*unit + gate), so each lane ends up holding i,f,g,o of ONE (unit,batch) cell in
+//    its 4 accumulator registers: the cell update is lane-local and c_t never leaves registers.
+//  * h_t (16 x H per batch group) is exchanged between the workgroups of a (direction, batch
+//    group) once per step through a small L2-resident buffer: write-through (sc1) stores, one
+//    sc1 flag per workgroup, sc1 polls and sc1 loads on the consumer side -- the placement-
+//    independent hand-off protocol for gfx950's non-coherent per-XCD L2s.  The exchange buffer is
+//    laid out [k/4][16 rows][4] so producers write and consumers read whole 1 KB lines.
+//  * Forward stages h_{t-1} in LDS (shared by the 4 waves); backward splits K = 4H across the 4
+//    waves, streams dG straight into the MFMA B operand and reduces the 4 partial tiles in LDS.
+//  * Every spin is bounded by a wall-clock timeout that raises a status word (sk_lstm_status).
+//  * mode 2 runs the same kernel one step per launch (state through the workspace) and is the
+//    fallback when the grid cannot be co-resident (more workgroups than CUs).
+#include "sk_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
+
+#define SK_RLX __ATOMIC_RELAXED
+#define SK_AGENT __HIP_MEMORY_SCOPE_AGENT
+
+struct WsLayout {
+  size_t ctrl, flags, xbuf, state, total;
+  int KS, NBG;
+};
+
+inline int pick_ks(int H) {
+  const int need = (H + 15) / 16;
+  const int opts[4] = {19, 38, 56, 64};
+  for (int i = 0; i < 4; ++i)
+    if (opts[i] >= need) return opts[i];
+  return 0;
+}
+
+inline WsLayout ws_layout(int B, int H) {
+  WsLayout w;
+  w.KS = pick_ks(H);
+  w.NBG = (B + 15) / 16;
+  const size_t Hp = 16 * (size_t)w.KS;
+  w.ctrl = 0;
+  w.flags = 256;
+  const size_t nflags = 2 * (size_t)w.NBG * w.KS;
+  w.xbuf = w.flags + sk_align(nflags * 4, 256);
+  const size_t xbytes = 2 * 2 * (size_t)w.NBG * Hp * 64 * 4;  // backward exchange is the larger one
+  w.state = w.xbuf + sk_align(xbytes, 256);
+  const size_t sbytes = 2 * 2 * (size_t)w.NBG * 16 * Hp * 4;  // two per-cell state arrays
+  w.total = w.state + sk_align(sbytes, 256);
+  return w;
+}
+
+struct FwdArgs {
+  const float* gx;
+  const float* whh;
+  const float* h0;
+  const float* c0;
+  const int* lens;
+  float* y;
+  float* gates;
+  float* cs;
+  float* hn;
+  float* cn;
+  float* xbuf;
+  float* state;
+  unsigned* flags;
+  unsigned* ctrl;
+  int T, B, H, NBG, s_begin, s_end;
+};
+
+struct BwdArgs {
+  const float* dy;
+  const float* whh;
+  const float* gates;
+  const float* cs;
+  const float* c0;
+  const int* lens;
+  float* dgx;
+  float* dh0;
+  float* dc0;
+  float* xbuf;
+  float* state;
+  unsigned* flags;
+  unsigned* ctrl;
+  int T, B, H, NBG, s_begin, s_end, final_mm;
+};
+
+// Wave 0 waits until every flag of its (direction, batch group) has reached `target`.
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigned target, unsigned* ctrl, int lane) {
+  const long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+    for (int i = lane; i < n; i += 64) ok = ok && (__hip_atomic_load(flags + i, SK_RLX, SK_AGENT) >= target);
+    if (__all(ok)) return true;
+    if (__hip_atomic_load(ctrl, SK_RLX, SK_AGENT) != 0u) return false;  // another workgroup gave up
+    if (wall_clock64() - t0 > SPIN_TICKS) {
+      if (lane == 0) __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+__device__ __forceinline__ f32x4 ld16_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16 /* sc1 */));
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
+  constexpr int HP = 16 * KS, LDH = HP + 4;
+  __shared__ __attribute__((aligned(16))) float hs[16 * LDH + 4];
+  int* s_abort = reinterpret_cast<int*>(&hs[16 * LDH]);
+
+  const int ug = blockIdx.x, bg = blockIdx.y, dir = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;
+
+  // ---- W_hh slice -> registers.  MFMA A operand: lane l supplies A[i = l&15][k = l>>4];
+  //      row i = 4*unit_local + gate, k of (chunk s, r) = 16 s + 4 (l>>4) + r.
+  float wreg[4 * KS];
+  {
+    const int i = lane & 15, kq = lane >> 4;
+    const int unit_i = ug * 16 + 4 * w + (i >> 2), g_i = i & 3;
+    const bool rowok = unit_i < H;
+    const float* wrow = a.whh + ((size_t)dir * 4 * H + (size_t)g_i * H + unit_i) * H;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 16 * s + 4 * kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rowok && k < H) v = *reinterpret_cast<const float4*>(wrow + k);
+      wreg[4 * s + 0] = v.x;
+      wreg[4 * s + 1] = v.y;
+      wreg[4 * s + 2] = v.z;
+      wreg[4 * s + 3] = v.w;
+    }
+  }
+
+  // ---- this lane's cell: unit (lane>>4 within the wave), batch row (lane&15)
+  const int u_l = lane >> 4, bl = lane & 15;
+  const int unit = ug * 16 + 4 * w + u_l, b = bg * 16 + bl;
+  const bool cellok = unit < H && b < B;
+  const int len_b = (b < B) ? a.lens[b] : 0;
+  const size_t xblk = (size_t)16 * HP;  // floats per (parity, dir, batch group) exchange block
+  float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
+  float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
+  const int xoff = ((ug * 4 + w) * 16 + bl) * 4 + u_l;
+  float* const st_c = a.state + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + (ug * 16 + 4 * w + u_l);
+  unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+
+  float c_reg = 0.f, h_reg = 0.f;
+  if (cellok) {
+    if (a.s_begin == 0) {
+      c_reg = a.c0[((size_t)dir * B + b) * H + unit];
+      h_reg = a.h0[((size_t)dir * B + b) * H + unit];
+    } else {
+      c_reg = *st_c;
+      h_reg = __hip_atomic_load(((a.s_begin - 1) & 1 ? xb1 : xb0) + xoff, SK_RLX, SK_AGENT);
+    }
+  }
+  if (tid == 0) *s_abort = 0;
+  __syncthreads();
+
+  for (int s = a.s_begin; s < a.s_end; ++s) {
+    const int t = dir ? T - 1 - s : s;
+    // 1. this step's input-projection terms (independent of the recurrence: issue early)
+    float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cellok) {
+      const float* gp = a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
+    }
+    // 2. wait for h_{s-1} of every unit group of this (direction, batch group)
+    if (s > a.s_begin && w == 0) {
+      if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) *s_abort = 1;
+    }
+    __syncthreads();
+    if (*s_abort) break;
+    // 3. stage h_{s-1} (16 rows x HP) in LDS as [row][k]
+    if (s == 0) {
+      for (int i = tid; i < 16 * (HP / 4); i += 256) {
+        const int bb = i / (HP / 4), k4 = (i - bb * (HP / 4)) * 4;
+        const int brow = bg * 16 + bb;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (brow < B && k4 < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)dir * B + brow) * H + k4);
+        *reinterpret_cast<float4*>(&hs[bb * LDH + k4]) = v;
+      }
+    } else {
+      const float* src = ((s - 1) & 1) ? xb1 : xb0;
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(xblk * 4), 0x00020000);
+      for (int i = tid; i < 4 * HP; i += 256) {  // float4 index: (k/4, row)
+        const int c = i >> 4, bb = i & 15;
+        const f32x4 v = ld16_sc1(rs, (unsigned)i * 16u);
+        *reinterpret_cast<f32x4*>(&hs[bb * LDH + 4 * c]) = v;
+      }
+    }
+    __syncthreads();
+    // 4. gates^T (64 gate rows x 16 batch) += W_slice (64 x HP) * h^T (HP x 16); this wave: 16 rows
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    {
+      const float* hrow = &hs[(lane & 15) * LDH + 4 * (lane >> 4)];
+#pragma unroll
+      for (int q = 0; q < KS; ++q) {
+        const float4 hb = *reinterpret_cast<const float4*>(hrow + 16 * q);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], hb.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], hb.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], hb.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], hb.w, acc1, 0, 0, 0);
+      }
+    }
+    // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
+    const float gi = sk_sigmoid(acc0[0] + acc1[0] + gxv[0]);
+    const float gf = sk_sigmoid(acc0[1] + acc1[1] + gxv[1]);
+    const float gg = tanhf(acc0[2] + acc1[2] + gxv[2]);
+    const float go = sk_sigmoid(acc0[3] + acc1[3] + gxv[3]);
+    const float c_new = gf * c_reg + gi * gg;
+    const float h_new = go * tanhf(c_new);
+    const bool valid = cellok && t < len_b;
+    if (valid) {
+      c_reg = c_new;
+      h_reg = h_new;
+    }
+    if (cellok) {
+      a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = valid ? h_new : 0.f;
+      if (a.gates && valid) {
+        float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+        gp[0] = gi;
+        gp[(size_t)H] = gf;
+        gp[(size_t)2 * H] = gg;
+        gp[(size_t)3 * H] = go;
+        a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit] = c_new;
+      }
+    }
+    // 6. publish h_s (write-through), then one flag per workgroup
+    __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+  }
+
+  if (!*s_abort && cellok) {
+    if (a.s_end == T) {
+      if (a.hn) a.hn[((size_t)dir * B + b) * H + unit] = h_reg;
+      if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = c_reg;
+    } else {
+      *st_c = c_reg;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ backward
+// dh_{prev}[b][u] = sum_{k'} dG[b][k'] W_hh[row(k')][u],  k' = 4*unit_k + gate (gate-interleaved).
+// Transposed MFMA: D[m = out unit][n = batch] = sum_k' A[m][k'] B[k'][n]; wave w takes the k' chunks
+// [w*KS, (w+1)*KS) (a quarter of the units), partial tiles are summed through LDS.
+template <int KS>
+__device__ __forceinline__ float bwd_matmul(const float (&wreg)[4 * KS], const float* xsrc, size_t xblk_bytes,
+                                            float (*red)[16][17], int w, int lane) {
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (int)xblk_bytes, 0x00020000);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const unsigned lane_off = (unsigned)(((lane >> 4) * 16 + (lane & 15)) * 16);
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const unsigned cc = (unsigned)(w * KS + q);
+    const f32x4 db = ld16_sc1(rs, cc * 1024u + lane_off);  // dG[b = lane&15][k' = 16 cc + 4 (lane>>4) + 0..3]
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], db[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], db[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], db[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], db[3], acc1, 0, 0, 0);
+  }
+  // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[w][4 * (lane >> 4) + r][lane & 15] = acc0[r] + acc1[r];
+  __syncthreads();
+  const int m = 4 * w + (lane >> 4), n = lane & 15;  // this lane's own cell
+  const float v = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+  __syncthreads();
+  return v;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
+  constexpr int HP = 16 * KS;
+  __shared__ float red[4][16][17];
+  __shared__ int s_abort;
+
+  const int ug = blockIdx.x, bg = blockIdx.y, dir = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;
+
+  // ---- W_hh^T slice -> registers: A[m = out unit i][k'] = W_hh[gate r * H + unit_k][ug*16 + i]
+  float wreg[4 * KS];
+  {
+    const int i = lane & 15, kq = lane >> 4;
+    const int uout = ug * 16 + i;
+    const float* wbase = a.whh + (size_t)dir * 4 * H * H + uout;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int unit_k = 4 * (w * KS + s) + kq;
+      const bool ok = uout < H && unit_k < H;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wreg[4 * s + r] = ok ? wbase[((size_t)r * H + unit_k) * H] : 0.f;
+    }
+  }
+
+  const int u_l = lane >> 4, bl = lane & 15;
+  const int unit = ug * 16 + 4 * w + u_l, b = bg * 16 + bl;
+  const bool cellok = unit < H && b < B;
+  const int len_b = (b < B) ? a.lens[b] : 0;
+  const size_t xblk = (size_t)HP * 64;  // floats per (parity, dir, batch group) exchange block
+  float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
+  float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
+  const size_t xoff = ((size_t)unit * 16 + bl) * 4;
+  const size_t soff = ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit;
+  float* const st_dh = a.state + soff;
+  float* const st_dc = a.state + (size_t)2 * NBG * 16 * HP + soff;
+  unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+
+  // carry = gradient wrt h that passes straight through a frozen (padded) step
+  float carry = 0.f, dc_rec = 0.f, dh_rec = 0.f;
+  if (a.s_begin > 0) {
+    carry = *st_dh;
+    dc_rec = *st_dc;
+  }
+  if (tid == 0) s_abort = 0;
+  __syncthreads();
+
+  for (int s = a.s_begin; s < a.s_end; ++s) {
+    const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
+    const bool valid = cellok && t < len_b;
+    // 1. saved activations of this cell (independent of the recurrence: issue early)
+    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cprev = 0.f, dyv = 0.f;
+    if (valid) {
+      const float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+      gi = gp[0];
+      gf = gp[(size_t)H];
+      gg = gp[(size_t)2 * H];
+      go = gp[(size_t)3 * H];
+      ct = a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit];
+      const int tp = dir ? t + 1 : t - 1;
+      const bool has_prev = dir ? (t + 1 < len_b) : (t > 0);
+      cprev = has_prev ? a.cs[(((size_t)tp * B + b) * 2 + dir) * H + unit] : a.c0[((size_t)dir * B + b) * H + unit];
+      dyv = a.dy[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit];
+    }
+    // 2. recurrent gradient from the step processed before this one
+    if (s > 0) {
+      if (s > a.s_begin && w == 0) {
+        if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
+      }
+      __syncthreads();
+      if (s_abort) break;
+      dh_rec = bwd_matmul<KS>(wreg, ((s - 1) & 1) ? xb1 : xb0, xblk * 4, red, w, lane) + carry;
+    } else {
+      dh_rec = 0.f;
+    }
+    // 3. cell backward
+    f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+      const float dh = dyv + dh_rec;
+      const float tc = tanhf(ct);
+      const float dout = dh * tc;
+      const float dc = dc_rec + dh * go * (1.0f - tc * tc);
+      dpre[0] = dc * gg * gi * (1.0f - gi);
+      dpre[1] = dc * cprev * gf * (1.0f - gf);
+      dpre[2] = dc * gi * (1.0f - gg * gg);
+      dpre[3] = dout * go * (1.0f - go);
+      dc_rec = dc * gf;
+      carry = 0.f;
+    } else {
+      carry = dh_rec;  // frozen step: h_t = h_{t-1}
+    }
+    if (cellok) {
+      float* dp = a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+      dp[0] = dpre[0];
+      dp[(size_t)H] = dpre[1];
+      dp[(size_t)2 * H] = dpre[2];
+      dp[(size_t)3 * H] = dpre[3];
+    }
+    // 4. publish dG_s in gate-interleaved order: 16 B per cell, 1 KB contiguous per wave
+    {
+      float* xdst = (s & 1) ? xb1 : xb0;
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+  }
+
+  if (s_abort) return;
+  if (a.final_mm) {
+    // gradient wrt the initial state: one more product with the last published dG (s_end == T)
+    if (T > a.s_begin && w == 0) {
+      if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane) && lane == 0) s_abort = 1;
+    }
+    __syncthreads();
+    if (s_abort) return;
+    dh_rec = bwd_matmul<KS>(wreg, ((T - 1) & 1) ? xb1 : xb0, xblk * 4, red, w, lane) + carry;
+    if (cellok) {
+      if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
+      if (a.dc0) a.dc0[((size_t)dir * B + b) * H + unit] = dc_rec;
+    }
+  } else {
+    *st_dh = carry;
+    *st_dc = dc_rec;
+  }
+}
+
+// hprev[t][b][dir][:] = recurrent input of step (t, dir) for row b (see sk_lstm_hprev)
+__global__ __launch_bounds__(256) void hprev_kernel(const float* __restrict__ y, const float* __restrict__ h0,
+                                                    const int* __restrict__ lens, float* __restrict__ hprev, int T,
+                                                    int B, int H) {
+  const int64_t row = blockIdx.x;  // (t*B + b)*2 + dir
+  const int dir = (int)(row & 1);
+  const int64_t tb = row >> 1;
+  const int b = (int)(tb % B), t = (int)(tb / B);
+  const int len = lens[b];
+  for (int k = threadIdx.x; k < H; k += 256) {
+    float v = 0.f;
+    if (t < len) {
+      if (dir == 0)
+        v = t > 0 ? y[((int64_t)(t - 1) * B + b) * 2 * H + k] : h0[(int64_t)b * H + k];
+      else
+        v = (t + 1 < len) ? y[((int64_t)(t + 1) * B + b) * 2 * H + H + k] : h0[((int64_t)B + b) * H + k];
+    }
+    hprev[row * H + k] = v;
+  }
+}
+
+template <int KS>
+int launch_fwd(const FwdArgs& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_fwd_kernel<KS>, grid, dim3(256), 0, st, a);
+  return 0;
+}
+template <int KS>
+int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL(lstm_bwd_kernel<KS>, grid, dim3(256), 0, st, a);
+  return 0;
+}
+
+int dispatch_fwd(int KS, const FwdArgs& a, dim3 grid, hipStream_t st) {
+  switch (KS) {
+    case 19: return launch_fwd<19>(a, grid, st);
+    case 38: return launch_fwd<38>(a, grid, st);
+    case 56: return launch_fwd<56>(a, grid, st);
+    default: return launch_fwd<64>(a, grid, st);
+  }
+}
+int dispatch_bwd(int KS, const BwdArgs& a, dim3 grid, hipStream_t st) {
+  switch (KS) {
+    case 19: return launch_bwd<19>(a, grid, st);
+    case 38: return launch_bwd<38>(a, grid, st);
+    case 56: return launch_bwd<56>(a, grid, st);
+    default: return launch_bwd<64>(a, grid, st);
+  }
+}
+
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+  }
+  return n;
+}
+
+int check_common(const char* fn, int T, int B, int H, const float* whh, int mode) {
+  SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
+  SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
+  SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
+  SK_CHECK_ARG(mode >= 0 && mode <= 2, "%s: unknown mode %d", fn, mode);
+  return SK_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sk_lstm_workspace_bytes(int T, int B, int H) {
+  (void)T;
+  if (B <= 0 || H <= 0 || pick_ks(H) == 0) return 0;
+  return ws_layout(B, H).total;
+}
+
+extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
+                           float* y, float* gates, float* cs, float* hn, float* cn, void* ws, int T, int B, int H,
+                           int mode, sk_stream_t stream) {
+  SK_CHECK_ARG(gx && whh && h0 && c0 && lens && y && ws, "sk_lstm_fwd: null pointer");
+  SK_CHECK_ARG((gates == nullptr) == (cs == nullptr), "sk_lstm_fwd: gates and cs must be given together");
+  SK_CHECK_ARG(((uintptr_t)h0 % 16) == 0, "sk_lstm_fwd: h0 must be 16-byte aligned");
+  int rc = check_common("sk_lstm_fwd", T, B, H, whh, mode);
+  if (rc) return rc;
+  const WsLayout L = ws_layout(B, H);
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)ws;
+  FwdArgs a;
+  a.gx = gx; a.whh = whh; a.h0 = h0; a.c0 = c0; a.lens = lens;
+  a.y = y; a.gates = gates; a.cs = cs; a.hn = hn; a.cn = cn;
+  a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
+  a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
+  a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
+  dim3 grid((unsigned)L.KS, (unsigned)L.NBG, 2);
+  const int nwg = L.KS * L.NBG * 2;
+  const bool fits = nwg <= num_cus();
+  SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode needs %d co-resident workgroups, device has %d CUs", nwg, num_cus());
+  SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));  // status word + flags
+  if (mode == 1 || (mode == 0 && fits)) {
+    a.s_begin = 0; a.s_end = T;
+    dispatch_fwd(L.KS, a, grid, st);
+  } else {
+    for (int s = 0; s < T; ++s) {
+      a.s_begin = s; a.s_end = s + 1;
+      dispatch_fwd(L.KS, a, grid, st);
+    }
+  }
+  SK_CHECK_LAUNCH("sk_lstm_fwd");
+  return SK_OK;
+}
+
+extern "C" int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs, const float* c0,
+                           const int32_t* lens, float* dgx, float* dh0, float* dc0, void* ws, int T, int B, int H,
+                           int mode, sk_stream_t stream) {
+  SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
+  int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
+  if (rc) return rc;
+  const WsLayout L = ws_layout(B, H);
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)ws;
+  BwdArgs a;
+  a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens;
+  a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0;
+  a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
+  a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
+  a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
+  const int want_d0 = (dh0 || dc0) ? 1 : 0;
+  dim3 grid((unsigned)L.KS, (unsigned)L.NBG, 2);
+  const int nwg = L.KS * L.NBG * 2;
+  const bool fits = nwg <= num_cus();
+  SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_bwd: persistent mode needs %d co-resident workgroups, device has %d CUs", nwg, num_cus());
+  SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));
+  if (mode == 1 || (mode == 0 && fits)) {
+    a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;
+    dispatch_bwd(L.KS, a, grid, st);
+  } else {
+    a.final_mm = 0;  // a step launch never waits on other workgroups
+    for (int s = 0; s < T; ++s) {
+      a.s_begin = s; a.s_end = s + 1;
+      dispatch_bwd(L.KS, a, grid, st);
+    }
+    if (want_d0) {
+      a.s_begin = T; a.s_end = T; a.final_mm = 1;
+      dispatch_bwd(L.KS, a, grid, st);
+    }
+  }
+  SK_CHECK_LAUNCH("sk_lstm_bwd");
+  return SK_OK;
+}
+
+extern "C" int sk_lstm_status(const void* ws, sk_stream_t stream) {
+  SK_CHECK_ARG(ws, "sk_lstm_status: null workspace");
+  unsigned v = 0;
+  SK_CHECK_HIP(hipMemcpyAsync(&v, ws, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  SK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (v != 0) return sk_fail(SK_ETIMEOUT, "sk_lstm: a workgroup's bounded wait timed out (grid not co-resident?)");
+  return SK_OK;
+}
+
+extern "C" int sk_lstm_hprev(const float* y, const float* h0, const int32_t* lens, float* hprev, int T, int B, int H,
+                             sk_stream_t stream) {
+  SK_CHECK_ARG(y && h0 && lens && hprev && T > 0 && B > 0 && H > 0, "sk_lstm_hprev: bad arguments");
+  hipLaunchKernelGGL(hprev_kernel, dim3((unsigned)((int64_t)T * B * 2)), dim3(256), 0, (hipStream_t)stream, y, h0, lens,
+                     hprev, T, B, H);
+  SK_CHECK_LAUNCH("sk_lstm_hprev");
+  return SK_OK;
+}

@@ -1,0 +1,194 @@
+// pit.hip -- utterance-level permutation-invariant MSE (uPIT) loss, forward and backward.
+//
+// Reference: compute_loss, archs/uPIT.py:181-197,206.  The reference evaluates S! full
+// element-wise passes; here ONE streaming pass forms the S x S pairwise per-utterance SSE matrix
+//   pair[b][s][r] = sum_{t,f} (mask[t,b,s,f] * mix[t,b,f] - src_r[t,b,f])^2
+// by wavefront reduction (HBM-bound: (2S+1)*F*4 bytes per frame), and the S! permutation sums,
+// the per-utterance arg-min and the scalar loss are formed from it by a tiny finalize kernel.
+// Reductions use fixed-order partial sums (no atomics), so results are run-to-run reproducible.
+#include "sk_common.h"
+
+namespace {
+
+constexpr int MAXS = 4;
+constexpr int TCH = 8;  // frames per block in the pairwise pass
+
+struct SrcPtrs {
+  const float* p[MAXS];
+};
+
+template <int S>
+__global__ __launch_bounds__(256) void pit_pair_kernel(const float* __restrict__ mask, const float* __restrict__ mix,
+                                                       SrcPtrs src, int T, int B, int F,
+                                                       float* __restrict__ partial /* (B, nch, S*S) */) {
+  __shared__ float red[4];
+  const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
+  float acc[S][S];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int r = 0; r < S; ++r) acc[s][r] = 0.f;
+  const int tend = min(T, (ch + 1) * TCH);
+  for (int t = ch * TCH; t < tend; ++t) {
+    const int64_t row = (int64_t)t * B + b;
+    for (int f = threadIdx.x; f < F; f += 256) {
+      const float mx = mix[row * F + f];
+      float sv[S];
+#pragma unroll
+      for (int r = 0; r < S; ++r) sv[r] = src.p[r][row * F + f];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float mm = mask[row * (int64_t)(S * F) + s * F + f] * mx;
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+          const float d = mm - sv[r];
+          acc[s][r] += d * d;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+      const float v = sk_block_sum256(acc[s][r], red);
+      if (threadIdx.x == 0) partial[((int64_t)b * nch + ch) * (S * S) + s * S + r] = v;
+    }
+}
+
+// Lexicographic permutation number `idx` of {0..S-1} (itertools.permutations order).
+__device__ __forceinline__ void nth_perm(int idx, int S, int* perm) {
+  int avail[MAXS];
+  for (int i = 0; i < S; ++i) avail[i] = i;
+  int fact = 1;
+  for (int i = 2; i < S; ++i) fact *= i;  // (S-1)!
+  for (int i = 0; i < S; ++i) {
+    const int q = idx / fact;
+    idx -= q * fact;
+    perm[i] = avail[q];
+    for (int j = q; j < S - 1 - i; ++j) avail[j] = avail[j + 1];
+    if (S - 1 - i > 0) fact /= (S - 1 - i);
+  }
+}
+
+__global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restrict__ partial, int nch,
+                                                           const int32_t* __restrict__ lens, int B, int F, int S,
+                                                           float norm_override, float* __restrict__ pair_sse,
+                                                           float* __restrict__ perm_loss, int32_t* __restrict__ best_perm,
+                                                           float* __restrict__ out) {
+  __shared__ float s_min[256];
+  __shared__ float s_len[256];
+  __shared__ float red[4];
+  int nperm = 1;
+  for (int i = 2; i <= S; ++i) nperm *= i;
+  float my_min = 0.f, my_len = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    float pr[MAXS * MAXS];
+    for (int q = 0; q < S * S; ++q) {
+      float a = 0.f;
+      for (int c = 0; c < nch; ++c) a += partial[((int64_t)b * nch + c) * (S * S) + q];
+      pr[q] = a;
+      pair_sse[(int64_t)b * S * S + q] = a;
+    }
+    float best = 0.f;
+    int bi = 0;
+    for (int p = 0; p < nperm; ++p) {
+      int perm[MAXS];
+      nth_perm(p, S, perm);
+      float l = 0.f;
+      for (int s = 0; s < S; ++s) l += pr[s * S + perm[s]];
+      perm_loss[(int64_t)p * B + b] = l;
+      if (p == 0 || l < best) {
+        best = l;
+        bi = p;
+      }
+    }
+    best_perm[b] = bi;
+    my_min += best;
+    my_len += (float)lens[b];
+  }
+  (void)s_min;
+  (void)s_len;
+  const float tot = sk_block_sum256(my_min, red);
+  const float len = sk_block_sum256(my_len, red);
+  if (threadIdx.x == 0) {
+    const float norm = norm_override > 0.f ? norm_override : len * (float)F;
+    const float lsum = tot / (float)S;
+    out[0] = lsum / norm;
+    out[1] = norm;
+    out[2] = lsum;
+  }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void pit_bwd_kernel(const float* __restrict__ mask, const float* __restrict__ mix,
+                                                      SrcPtrs src, const int32_t* __restrict__ best_perm,
+                                                      const float* __restrict__ out, const float* __restrict__ gscale,
+                                                      int T, int B, int F, float* __restrict__ dmask) {
+  const int64_t row = blockIdx.x;  // t*B + b
+  const int b = (int)(row % B);
+  int perm[MAXS];
+  nth_perm(best_perm[b], S, perm);
+  const float k = gscale[0] * 2.0f / ((float)S * out[1]);
+  for (int f = threadIdx.x; f < F; f += 256) {
+    const float mx = mix[row * F + f];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int64_t o = row * (int64_t)(S * F) + s * F + f;
+      const float sv = src.p[perm[s]][row * F + f];
+      dmask[o] = k * (mask[o] * mx - sv) * mx;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t sk_pit_workspace_bytes(int T, int B, int S) {
+  return sk_align((size_t)B * sk_cdiv(T, TCH) * S * S * sizeof(float), 256);
+}
+
+extern "C" int sk_pit_mse_fwd(const float* mask, const float* mix, const float* const* src_host, const int32_t* lens,
+                              int T, int B, int F, int S, float norm_override, float* pair_sse, float* perm_loss,
+                              int32_t* best_perm, float* out, void* ws, sk_stream_t stream) {
+  SK_CHECK_ARG(mask && mix && src_host && lens && pair_sse && perm_loss && best_perm && out && ws,
+               "sk_pit_mse_fwd: null pointer");
+  SK_CHECK_ARG(S >= 1 && S <= MAXS, "sk_pit_mse_fwd: num_spk %d outside 1..%d", S, MAXS);
+  SK_CHECK_ARG(T > 0 && B > 0 && B <= 65535 && F > 0, "sk_pit_mse_fwd: bad sizes");
+  SrcPtrs sp;
+  for (int s = 0; s < MAXS; ++s) sp.p[s] = s < S ? src_host[s] : nullptr;
+  const int nch = (int)sk_cdiv(T, TCH);
+  dim3 grid((unsigned)nch, (unsigned)B);
+  float* partial = (float*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  switch (S) {
+    case 1: hipLaunchKernelGGL(pit_pair_kernel<1>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
+    case 2: hipLaunchKernelGGL(pit_pair_kernel<2>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
+    case 3: hipLaunchKernelGGL(pit_pair_kernel<3>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
+    default: hipLaunchKernelGGL(pit_pair_kernel<4>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
+  }
+  SK_CHECK_LAUNCH("pit_pair_kernel");
+  hipLaunchKernelGGL(pit_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nch, lens, B, F, S, norm_override,
+                     pair_sse, perm_loss, best_perm, out);
+  SK_CHECK_LAUNCH("pit_finalize_kernel");
+  return SK_OK;
+}
+
+extern "C" int sk_pit_mse_bwd(const float* mask, const float* mix, const float* const* src_host,
+                              const int32_t* best_perm, const float* out, const float* gscale, int T, int B, int F,
+                              int S, float* dmask, sk_stream_t stream) {
+  SK_CHECK_ARG(mask && mix && src_host && best_perm && out && gscale && dmask, "sk_pit_mse_bwd: null pointer");
+  SK_CHECK_ARG(S >= 1 && S <= MAXS, "sk_pit_mse_bwd: num_spk %d outside 1..%d", S, MAXS);
+  SK_CHECK_ARG(T > 0 && B > 0 && F > 0, "sk_pit_mse_bwd: bad sizes");
+  SrcPtrs sp;
+  for (int s = 0; s < MAXS; ++s) sp.p[s] = s < S ? src_host[s] : nullptr;
+  dim3 grid((unsigned)((int64_t)T * B));
+  hipStream_t st = (hipStream_t)stream;
+  switch (S) {
+    case 1: hipLaunchKernelGGL(pit_bwd_kernel<1>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;
+    case 2: hipLaunchKernelGGL(pit_bwd_kernel<2>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;
+    case 3: hipLaunchKernelGGL(pit_bwd_kernel<3>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;
+    default: hipLaunchKernelGGL(pit_bwd_kernel<4>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;
+  }
+  SK_CHECK_LAUNCH("pit_bwd_kernel");
+  return SK_OK;
+}

@@ -1,0 +1,80 @@
+"""ctypes binding of libsepkern.so (include/sepkern.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsepkern.so")
+
+SK_VERSION = 100
+
+_p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes): one entry per symbol declared in include/sepkern.h
+PROTOTYPES = {
+    "sk_version": (_i, []),
+    "sk_last_error": (C.c_char_p, []),
+    "sk_device_info": (_i, [C.POINTER(_i), C.POINTER(_i)]),
+    "sk_stft": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "sk_mask_istft": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
+    "sk_gemm_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p]),
+    "sk_lstm_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sk_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "sk_lstm_status": (_i, [_p, _p]),
+    "sk_lstm_hprev": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "sk_bn_workspace_bytes": (_sz, [_i, _i]),
+    "sk_bn_stats": (_i, [_p, _i, _i, _p, _p, _p, _p]),
+    "sk_bn_update_running": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
+    "sk_bn_apply": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "sk_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "sk_colsum": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
+    "sk_sigmoid_bwd": (_i, [_p, _p, _p, _i64, _p]),
+    "sk_pit_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sk_pit_mse_fwd": (_i, [_p, _p, C.POINTER(_p), _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
+    "sk_pit_mse_bwd": (_i, [_p, _p, C.POINTER(_p), _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "sk_optim_workspace_bytes": (_sz, [_i64]),
+    "sk_grad_norm": (_i, [_p, _i64, _f, _p, _p, _p]),
+    "sk_clip_adam": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),
+}
+
+_lib = None
+
+
+class SepkernError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libsepkern.so; raises SepkernError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SepkernError(
+            "libsepkern.so not found at %s -- build it with `python __graft_entry__.py` "
+            "(or make -C speech-separation_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.sk_version()
+    if v != SK_VERSION:
+        raise SepkernError("libsepkern.so version %d does not match binding %d; rebuild" % (v, SK_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sk_last_error().decode("utf-8", "replace")
+        raise SepkernError("%s failed (code %d): %s" % (what or "sepkern call", rc, msg))
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero code."""
+    rc = getattr(load(), name)(*args)
+    check(rc, name)

@@ -1,0 +1,204 @@
+"""The uPIT network (BLSTM -> BatchNorm1d -> Linear -> sigmoid) as a sequence of libsepkern calls.
+
+Mirrors SepDNN.forward of the reference (archs/uPIT.py:129-147) and the backward torch's autograd
+would run for it, on padded time-major (T, B, C) tensors with per-row lengths instead of
+PackedSequences.  All parameters live in ONE flat fp32 buffer (and all gradients in another):
+  * the LSTM kernels want (2, 4H, *) blocks (both directions of a layer) contiguous,
+  * data-parallel training all-reduces one buffer (RCCL, one collective per step),
+  * clip_grad_norm_ + Adam run as one fused pass over it (sepkern.optim).
+nn.Parameters with the reference's names are views into it, so state_dict() is unchanged.
+"""
+import os
+
+import torch
+
+from . import ops
+from ._lib import SepkernError
+
+_PER_DIR = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+
+
+def _align(n, a=4):
+    return (n + a - 1) // a * a
+
+
+class ParamLayout:
+    """Offsets (in floats) of every parameter block inside the flat buffer.
+
+    Per layer: weight_ih (2,4H,I) | weight_hh (2,4H,H) | bias_ih (2,4H) | bias_hh (2,4H); then
+    lin.weight (S*F, 2H), lin.bias, bn.weight, bn.bias.  Every block starts 16-byte aligned.
+    """
+
+    def __init__(self, feat_dim, num_spk, hidden, layers):
+        self.F, self.S, self.H, self.L = feat_dim, num_spk, hidden, layers
+        self.blocks = {}
+        off = 0
+        H = hidden
+        for l in range(layers):
+            I = feat_dim if l == 0 else 2 * H
+            for name, shape in (("weight_ih", (2, 4 * H, I)), ("weight_hh", (2, 4 * H, H)),
+                                ("bias_ih", (2, 4 * H)), ("bias_hh", (2, 4 * H))):
+                n = 1
+                for s in shape:
+                    n *= s
+                self.blocks["%s_l%d" % (name, l)] = (off, shape)
+                off = _align(off + n)
+        for name, shape in (("lin.weight", (num_spk * feat_dim, 2 * H)), ("lin.bias", (num_spk * feat_dim,)),
+                            ("bn.weight", (2 * H,)), ("bn.bias", (2 * H,))):
+            n = 1
+            for s in shape:
+                n *= s
+            self.blocks[name] = (off, shape)
+            off = _align(off + n)
+        self.total = off
+
+    def view(self, flat, name):
+        off, shape = self.blocks[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return flat[off:off + n].view(shape)
+
+
+class Engine:
+    """Forward / backward of the network on one device."""
+
+    def __init__(self, feat_dim, num_spk, hidden, layers, device):
+        if hidden % 4 != 0 or hidden > 1024:
+            raise SepkernError("hidden_dim must be a multiple of 4 and <= 1024 (got %d)" % hidden)
+        self.F, self.S, self.H, self.L = feat_dim, num_spk, hidden, layers
+        self.layout = ParamLayout(feat_dim, num_spk, hidden, layers)
+        self.device = device
+        self.flat = torch.zeros(self.layout.total, device=device)
+        self.grad = torch.zeros(self.layout.total, device=device)
+        self.running_mean = torch.zeros(2 * hidden, device=device)
+        self.running_var = torch.ones(2 * hidden, device=device)
+        self.eps, self.momentum = 1e-5, 0.1
+        self.lstm_mode = int(os.environ.get("SEPKERN_LSTM_MODE", "0"))
+        self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
+        self._calls = 0
+        self.ctx = None
+
+    def p(self, name):
+        return self.layout.view(self.flat, name)
+
+    def g(self, name):
+        return self.layout.view(self.grad, name)
+
+    def zero_grad(self):
+        """model.zero_grad(): the next backward overwrites every gradient element, so nothing is memset."""
+        self.grads_fresh = True
+
+    def _check_status(self, ws):
+        # a timed-out persistent launch leaves garbage: surface it (synchronises, so not every call)
+        self._calls += 1
+        if self._calls <= 4 or self._calls % 64 == 0 or os.environ.get("SEPKERN_CHECK") == "1":
+            ops.lstm_status(ws)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, lens, h0, c0, training, save):
+        """x (T,B,F) fp32, lens int32 (B) on device, h0/c0 (2L,B,H) -> mask (T,B,S*F)."""
+        T, B, F = x.shape
+        if F != self.F:
+            raise SepkernError("feature dim %d != model feat_dim %d" % (F, self.F))
+        H, L, S = self.H, self.L, self.S
+        R = T * B
+        x = x.contiguous()
+        dev = x.device
+        saved = []
+        inp, I = x, F
+        ws = None
+        for l in range(L):
+            wih = self.p("weight_ih_l%d" % l)
+            whh = self.p("weight_hh_l%d" % l)
+            # b_ih + b_hh for both directions: the two bias blocks are adjacent rows of a (2, 8H) matrix
+            off_ih, _ = self.layout.blocks["bias_ih_l%d" % l]
+            bsum = torch.empty(8 * H, device=dev)
+            ops.colsum(self.flat[off_ih:], 2, 8 * H, 8 * H, bsum)
+            gx = torch.empty(T, B, 2, 4 * H, device=dev)
+            ops.gemm(inp, wih, gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum)
+            y = torch.empty(T, B, 2 * H, device=dev)
+            cs = torch.empty(T, B, 2, H, device=dev) if save else None
+            ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
+                              None, None, T, B, H, self.lstm_mode)
+            saved.append((inp, gx, cs, y))
+            inp, I = y, 2 * H
+        self._check_status(ws)
+        y2d = inp.view(R, 2 * H)
+        if training:
+            mean = torch.empty(2 * H, device=dev)
+            var = torch.empty(2 * H, device=dev)
+            ops.bn_stats(y2d, mean, var)
+            ops.bn_update_running(mean, var, self.running_mean, self.running_var, R, self.momentum)
+        else:
+            mean, var = self.running_mean, self.running_var
+        xbn = torch.empty(R, 2 * H, device=dev)
+        ops.bn_apply(y2d, mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
+        mask = torch.empty(T, B, S * F, device=dev)
+        ops.gemm(xbn, self.p("lin.weight"), mask, R, S * F, 2 * H, 2 * H, 2 * H, S * F, transB=True,
+                 bias=self.p("lin.bias"), act=1)
+        if save:
+            self.ctx = dict(saved=saved, mean=mean, var=var, xbn=xbn, mask=mask, lens=lens, h0=h0, c0=c0,
+                            T=T, B=B, training=training)
+        return mask
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dmask):
+        """Gradient of every parameter from dmask (T,B,S*F); consumes the context of the last forward."""
+        ctx = self.ctx
+        if ctx is None:
+            raise SepkernError("backward called without a saved forward")
+        if not ctx["training"]:
+            raise SepkernError("backward through eval-mode BatchNorm is not built")
+        self.ctx = None
+        T, B, H, L, S, F = ctx["T"], ctx["B"], self.H, self.L, self.S, self.F
+        R = T * B
+        dev = dmask.device
+        acc = not self.grads_fresh
+        lens, h0, c0 = ctx["lens"], ctx["h0"], ctx["c0"]
+        dmask = dmask.contiguous()
+
+        def put(name, val):           # small vectors produced by non-accumulating kernels
+            if acc:
+                self.g(name).add_(val)
+            else:
+                self.g(name).copy_(val)
+
+        dz = torch.empty_like(dmask)
+        ops.sigmoid_bwd(dmask, ctx["mask"], dz)
+        ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), S * F, 2 * H, R, S * F, 2 * H, 2 * H, transA=True, accumulate=acc)
+        ops.colsum(dz, R, S * F, S * F, self.g("lin.bias"), accumulate=acc)
+        dxbn = torch.empty(R, 2 * H, device=dev)
+        ops.gemm(dz, self.p("lin.weight"), dxbn, R, 2 * H, S * F, S * F, 2 * H, 2 * H)
+        del dz
+        y_top = ctx["saved"][-1][3].view(R, 2 * H)
+        dy = torch.empty(R, 2 * H, device=dev)
+        dgamma = torch.empty(2 * H, device=dev)
+        dbeta = torch.empty(2 * H, device=dev)
+        ops.bn_bwd(dxbn, y_top, ctx["mean"], ctx["var"], self.p("bn.weight"), dy, dgamma, dbeta, self.eps)
+        put("bn.weight", dgamma)
+        put("bn.bias", dbeta)
+        del dxbn
+        hprev = torch.empty(T, B, 2, H, device=dev)
+        ws = None
+        for l in range(L - 1, -1, -1):
+            inp, gates, cs, y = ctx["saved"][l]
+            I = F if l == 0 else 2 * H
+            whh = self.p("weight_hh_l%d" % l)
+            dgx = gates                                  # overwritten in place, cell by cell
+            ws = ops.lstm_bwd(dy, whh, gates, cs, c0[2 * l:2 * l + 2], lens, dgx, None, None, T, B, H, self.lstm_mode)
+            ops.lstm_hprev(y, h0[2 * l:2 * l + 2], lens, hprev, T, B, H)
+            # dW_hh[d] = dgx[:, d]^T hprev[:, d]   (two directions as a batch of 2)
+            ops.gemm(dgx, hprev, self.g("weight_hh_l%d" % l), 4 * H, H, R, 8 * H, 2 * H, H, transA=True,
+                     accumulate=acc, batch=2, sA=4 * H, sB=H, sC=4 * H * H)
+            # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
+            ops.gemm(dgx, inp, self.g("weight_ih_l%d" % l), 8 * H, I, R, 8 * H, I, I, transA=True, accumulate=acc)
+            db = torch.empty(8 * H, device=dev)
+            ops.colsum(dgx, R, 8 * H, 8 * H, db)
+            put("bias_ih_l%d" % l, db.view(2, 4 * H))
+            put("bias_hh_l%d" % l, db.view(2, 4 * H))
+            if l > 0:
+                dy = torch.empty(R, I, device=dev)
+                ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy, R, I, 8 * H, 8 * H, I, I)
+        self._check_status(ws)
+        self.grads_fresh = False

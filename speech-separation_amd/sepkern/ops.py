@@ -1,0 +1,265 @@
+"""Tensor-level wrappers over the C ABI (include/sepkern.h).
+
+PyTorch supplies device memory and the current HIP stream; all arithmetic is in libsepkern.so.
+Every wrapper takes fp32 CUDA tensors and passes raw device pointers.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_WS = {}
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=torch.float32):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise _lib.SepkernError("sepkern ops need CUDA(HIP) tensors; got a CPU tensor (there is no CPU path)")
+    if t.dtype != dtype:
+        raise _lib.SepkernError("expected dtype %s, got %s" % (dtype, t.dtype))
+
+
+def workspace(nbytes, tag="default"):
+    """A cached per-(device, tag) scratch buffer of at least nbytes (owned by torch's allocator)."""
+    key = (torch.cuda.current_device(), tag)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+        _WS[key] = ws
+    return ws
+
+
+def device_info():
+    ncu, lds = C.c_int(0), C.c_int(0)
+    _lib.call("sk_device_info", C.byref(ncu), C.byref(lds))
+    return ncu.value, lds.value
+
+
+# ----------------------------------------------------------------------------- GEMM
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, accumulate=False, act=0,
+         batch=1, sA=0, sB=0, sC=0, sbias=0):
+    """Cout[M,N] = act(opA(A) opB(B) + bias (+ Cout)).  A/B/Cout are tensors whose data_ptr() is the
+    first element of the operand (views are fine: leading dimensions are explicit)."""
+    for t in (A, B, Cout, bias):
+        _chk(t)
+    _lib.call("sk_gemm_f32", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA),
+              int(transB), int(accumulate), int(act), batch, sA, sB, sC, sbias, _stream())
+
+
+# ----------------------------------------------------------------------------- STFT / iSTFT
+def _i64(vals, device):
+    return torch.tensor(vals, dtype=torch.int64, device=device)
+
+
+def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, stride_t=None, stride_f=None):
+    """STFT (n_fft 512, hop 128, reflect-centred, periodic Hann) of a list of 1-D waveforms.
+
+    wavs: list of 1-D CUDA tensors, float32 in [-1,1) or int16 PCM (scaled by 1/32768 in-kernel).
+    layout "TF": returns list of (T_u, 257) tensors; "FT": list of (257, T_u) (the reference's npz layout).
+    With `out` given, writes element (t,f) of utterance u at out_offs[u] + t*stride_t[u] + f*stride_f[u].
+    """
+    dev = wavs[0].device
+    pcm16 = wavs[0].dtype == torch.int16
+    for w in wavs:
+        _chk(w, torch.int16 if pcm16 else torch.float32)
+        if w.dim() != 1 or w.numel() <= 256:
+            raise _lib.SepkernError("stft needs 1-D waveforms longer than n_fft/2 samples")
+    ns = [int(w.numel()) for w in wavs]
+    Ts = [1 + n // 128 for n in ns]
+    cat = torch.cat(wavs) if len(wavs) > 1 else wavs[0].contiguous()
+    woffs, acc = [], 0
+    for n in ns:
+        woffs.append(acc)
+        acc += n
+    F = 257
+    ret = None
+    if out is None:
+        odt = torch.complex64 if want_complex else torch.float32
+        total = sum(Ts) * F
+        out = torch.empty(total, dtype=odt, device=dev)
+        out_offs, stride_t, stride_f, acc = [], [], [], 0
+        for T in Ts:
+            out_offs.append(acc)
+            stride_t.append(F if layout == "TF" else 1)
+            stride_f.append(1 if layout == "TF" else T)
+            acc += T * F
+        ret = [out[o:o + T * F].view((T, F) if layout == "TF" else (F, T)) for o, T in zip(out_offs, Ts)]
+    _lib.call("sk_stft", _ptr(cat), int(pcm16), _ptr(_i64(woffs, dev)), _ptr(torch.tensor(ns, dtype=torch.int32, device=dev)),
+              len(wavs), 512, 128, int(want_complex), _ptr(out), _ptr(_i64(out_offs, dev)), _ptr(_i64(stride_t, dev)),
+              _ptr(_i64(stride_f, dev)), max(Ts), _stream())
+    return ret if ret is not None else out
+
+
+def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True):
+    """Mask-apply + iSTFT.  mix_specs: list of (257, T_u) complex64 CUDA tensors (the reference's
+    feats_test layout); masks: None or list (per utterance) of lists (per source) of (257, T_u) float32.
+    Returns (list of lists of float32 waveforms or None, list of lists of int16 waveforms or None)."""
+    dev = mix_specs[0].device
+    nutt = len(mix_specs)
+    S = len(masks[0]) if masks is not None else 1
+    Ts = [int(m.shape[1]) for m in mix_specs]
+    F = 257
+    for m in mix_specs:
+        _chk(m, torch.complex64)
+        if m.shape[0] != F:
+            raise _lib.SepkernError("mask_istft expects (257, T) spectra")
+    mixcat = torch.cat([m.contiguous().view(-1) for m in mix_specs])
+    moffs, acc = [], 0
+    for T in Ts:
+        moffs.append(acc)
+        acc += T * F
+    mst, msf = [1] * nutt, list(Ts)
+    if masks is not None:
+        flat = []
+        koffs, acc = [], 0
+        for u in range(nutt):
+            for s in range(S):
+                _chk(masks[u][s])
+                flat.append(masks[u][s].contiguous().view(-1))
+                koffs.append(acc)
+                acc += Ts[u] * F
+        maskcat = torch.cat(flat)
+        kst, ksf = [1] * nutt, list(Ts)
+    ooffs, acc = [], 0
+    for u in range(nutt):
+        for s in range(S):
+            ooffs.append(acc)
+            acc += 128 * (Ts[u] - 1)
+    wav = torch.empty(acc, dtype=torch.float32, device=dev) if want_float else None
+    pcm = torch.empty(acc, dtype=torch.int16, device=dev) if want_pcm else None
+    _lib.call("sk_mask_istft", _ptr(mixcat), _ptr(_i64(moffs, dev)), _ptr(_i64(mst, dev)), _ptr(_i64(msf, dev)),
+              _ptr(maskcat) if masks is not None else None,
+              _ptr(_i64(koffs, dev)) if masks is not None else None,
+              _ptr(_i64(kst, dev)) if masks is not None else None,
+              _ptr(_i64(ksf, dev)) if masks is not None else None,
+              _ptr(torch.tensor(Ts, dtype=torch.int32, device=dev)), nutt, S, 512, 128, _ptr(wav), _ptr(pcm),
+              _ptr(_i64(ooffs, dev)), max(Ts), _stream())
+
+    def split(buf):
+        if buf is None:
+            return None
+        return [[buf[ooffs[u * S + s]:ooffs[u * S + s] + 128 * (Ts[u] - 1)] for s in range(S)] for u in range(nutt)]
+    return split(wav), split(pcm)
+
+
+# ----------------------------------------------------------------------------- PIT-MSE
+def pit_mse_fwd(mask, mix, srcs, lens, norm_override=0.0):
+    """mask (T,B,S*F), mix (T,B,F), srcs list of S (T,B,F), lens int32 (B) ->
+    dict(out (3,), pair (B,S,S), perm_loss (S!,B), best_perm (B))."""
+    T, B, F = mix.shape
+    S = len(srcs)
+    for t in [mask, mix] + list(srcs):
+        _chk(t)
+        if not t.is_contiguous():
+            raise _lib.SepkernError("pit_mse needs contiguous tensors")
+    _chk(lens, torch.int32)
+    nperm = 1
+    for i in range(2, S + 1):
+        nperm *= i
+    dev = mix.device
+    pair = torch.empty(B, S, S, device=dev)
+    perm_loss = torch.empty(nperm, B, device=dev)
+    best = torch.empty(B, dtype=torch.int32, device=dev)
+    out = torch.empty(3, device=dev)
+    ws = workspace(_lib.load().sk_pit_workspace_bytes(T, B, S), "pit")
+    sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
+    _lib.call("sk_pit_mse_fwd", _ptr(mask), _ptr(mix), sp, _ptr(lens), T, B, F, S, float(norm_override), _ptr(pair),
+              _ptr(perm_loss), _ptr(best), _ptr(out), _ptr(ws), _stream())
+    return dict(out=out, pair=pair, perm_loss=perm_loss, best_perm=best)
+
+
+def pit_mse_bwd(mask, mix, srcs, best_perm, out, gscale):
+    T, B, F = mix.shape
+    S = len(srcs)
+    dmask = torch.empty_like(mask)
+    sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
+    _chk(gscale)
+    _lib.call("sk_pit_mse_bwd", _ptr(mask), _ptr(mix), sp, _ptr(best_perm), _ptr(out), _ptr(gscale), T, B, F, S,
+              _ptr(dmask), _stream())
+    return dmask
+
+
+# ----------------------------------------------------------------------------- BN / column ops
+def bn_ws(R, Ccols):
+    return workspace(_lib.load().sk_bn_workspace_bytes(R, Ccols), "bn")
+
+
+def bn_stats(x2d, mean, var):
+    R, Cc = x2d.shape
+    _lib.call("sk_bn_stats", _ptr(x2d), R, Cc, _ptr(mean), _ptr(var), _ptr(bn_ws(R, Cc)), _stream())
+
+
+def bn_update_running(mean, var, rmean, rvar, R, momentum):
+    _lib.call("sk_bn_update_running", _ptr(mean), _ptr(var), _ptr(rmean), _ptr(rvar), R, mean.numel(), float(momentum),
+              _stream())
+
+
+def bn_apply(x2d, mean, var, gamma, beta, out, eps):
+    R, Cc = x2d.shape
+    _lib.call("sk_bn_apply", _ptr(x2d), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), _ptr(out), R, Cc, float(eps),
+              _stream())
+
+
+def bn_bwd(dout, x2d, mean, var, gamma, dx, dgamma, dbeta, eps):
+    R, Cc = x2d.shape
+    _lib.call("sk_bn_bwd", _ptr(dout), _ptr(x2d), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(dx), _ptr(dgamma),
+              _ptr(dbeta), _ptr(bn_ws(R, Cc)), R, Cc, float(eps), _stream())
+
+
+def colsum(x, R, Ccols, ld, out, accumulate=False):
+    _lib.call("sk_colsum", _ptr(x), R, Ccols, ld, _ptr(out), int(accumulate), _ptr(bn_ws(R, Ccols)), _stream())
+
+
+def sigmoid_bwd(dmask, m, dz):
+    _lib.call("sk_sigmoid_bwd", _ptr(dmask), _ptr(m), _ptr(dz), dmask.numel(), _stream())
+
+
+# ----------------------------------------------------------------------------- LSTM recurrence
+def lstm_ws(T, B, H):
+    n = _lib.load().sk_lstm_workspace_bytes(T, B, H)
+    if n == 0:
+        raise _lib.SepkernError("unsupported LSTM shape B=%d H=%d" % (B, H))
+    return workspace(n, "lstm")
+
+
+def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0):
+    ws = lstm_ws(T, B, H)
+    _lib.call("sk_lstm_fwd", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(y), _ptr(gates), _ptr(cs),
+              _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, _stream())
+    return ws
+
+
+def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0):
+    ws = lstm_ws(T, B, H)
+    _lib.call("sk_lstm_bwd", _ptr(dy), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0), _ptr(lens), _ptr(dgx), _ptr(dh0),
+              _ptr(dc0), _ptr(ws), T, B, H, mode, _stream())
+    return ws
+
+
+def lstm_status(ws):
+    _lib.call("sk_lstm_status", _ptr(ws), _stream())
+
+
+def lstm_hprev(y, h0, lens, hprev, T, B, H):
+    _lib.call("sk_lstm_hprev", _ptr(y), _ptr(h0), _ptr(lens), _ptr(hprev), T, B, H, _stream())
+
+
+# ----------------------------------------------------------------------------- optimizer
+def grad_norm(g, max_norm, scal):
+    ws = workspace(_lib.load().sk_optim_workspace_bytes(g.numel()), "optim")
+    _lib.call("sk_grad_norm", _ptr(g), g.numel(), float(max_norm), _ptr(scal), _ptr(ws), _stream())
+
+
+def clip_adam(p, g, m, v, scal, lr, beta1, beta2, eps, step):
+    _lib.call("sk_clip_adam", _ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), _ptr(scal), float(lr), float(beta1),
+              float(beta2), float(eps), int(step), _stream())

@@ -1,0 +1,47 @@
+"""Fused gradient clipping + Adam over the model's flat parameter buffer.
+
+Replaces `torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25); optimizer.step()`
+(reference steps/train_qsub.py:121-122, Adam(lr) defaults from :95) with three launches over one
+contiguous buffer: sum of squares -> norm / clip coefficient (kept on the device) -> Adam update.
+Optimizer state is not part of the reference's checkpoints (only model.state_dict() is saved,
+steps/train_qsub.py:105,150,155); state_dict()/load_state_dict() here are an addition.
+"""
+import torch
+
+from . import ops
+
+
+class ClipAdam:
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, max_norm=0.25):
+        self.model = model
+        self.lr, self.betas, self.eps, self.max_norm = float(lr), betas, float(eps), float(max_norm)
+        self.step_count = 0
+        self._bound = None
+        self.m = self.v = self.scal = None
+
+    def _state(self):
+        p, g = self.model.flat_parameters()
+        if self._bound is None or self._bound.data_ptr() != p.data_ptr():
+            self.m = torch.zeros_like(p)
+            self.v = torch.zeros_like(p)
+            self.scal = torch.zeros(2, device=p.device)
+            self._bound = p
+        return p, g
+
+    def step(self):
+        """Returns the device tensor [total_norm, clip_coef] (no host sync)."""
+        p, g = self._state()
+        self.step_count += 1
+        ops.grad_norm(g, self.max_norm, self.scal)
+        ops.clip_adam(p, g, self.m, self.v, self.scal, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+        return self.scal
+
+    def state_dict(self):
+        self._state()
+        return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone()}
+
+    def load_state_dict(self, sd):
+        self._state()
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])

@@ -1,0 +1,286 @@
+"""Parity of every libsepkern kernel against the CPU oracle, through the C ABI (ctypes).
+
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+Tolerances: fp32 kernels vs an fp64/fp32 CPU evaluation of the same formula; the only
+differences are summation order (MFMA k-ordered fmaf chains, wave reductions) and libm.
+"""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import stft as OS
+from oracle import upit as OU
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X (torch.cuda.is_available() is False)")
+    from sepkern import ops as _ops
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,tA,tB", [
+    (300, 200, 257, False, True),      # layer-0 input projection shape class (K=257: unaligned rows)
+    (256, 256, 64, False, False), (256, 256, 64, True, False), (256, 256, 64, False, True), (256, 256, 64, True, True),
+    (130, 514, 96, False, True), (1000, 72, 1, False, False), (129, 131, 300, True, False), (64, 1792, 514, False, False),
+])
+def test_gemm_matches_fp64(ops, M, N, K, tA, tB):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double().t() if tA else A.double()) @ (B.double().t() if tB else B.double()) + bias.double()
+    C = torch.full((M, N), float("nan")).cuda()
+    ops.gemm(dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N, transA=tA, transB=tB, bias=dev(bias))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
+
+
+def test_gemm_accumulate_sigmoid_batch_and_ld(ops):
+    g = torch.Generator().manual_seed(5)
+    # batch of 2 TN products out of strided storage: A (K, 2*M) and B (K, 2*N), like dW_hh
+    K, M, N = 70, 40, 24
+    A = torch.randn(K, 2 * M, generator=g)
+    B = torch.randn(K, 2 * N, generator=g)
+    C0 = torch.randn(2, M, N, generator=g)
+    C = dev(C0.clone())
+    ops.gemm(dev(A), dev(B), C, M, N, K, 2 * M, 2 * N, N, transA=True, accumulate=True, batch=2, sA=M, sB=N, sC=M * N)
+    ref = torch.stack([A[:, d * M:(d + 1) * M].double().t() @ B[:, d * N:(d + 1) * N].double() for d in range(2)]) + C0.double()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=1e-5)
+    # sigmoid epilogue
+    X, W, b = torch.randn(50, 30, generator=g), torch.randn(20, 30, generator=g), torch.randn(20, generator=g)
+    out = torch.empty(50, 20).cuda()
+    ops.gemm(dev(X), dev(W), out, 50, 20, 30, 30, 30, 20, transB=True, bias=dev(b), act=1)
+    np.testing.assert_allclose(out.cpu().numpy(), torch.sigmoid(X.double() @ W.double().t() + b.double()).numpy(), atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------ STFT / iSTFT
+def _sig(n, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal(n) * 0.2).astype(np.float32)
+
+
+@pytest.mark.parametrize("layout", ["TF", "FT"])
+def test_stft_matches_oracle(ops, layout):
+    ns = [51072, 24000, 4097, 700, 257]
+    ys = [_sig(n, n) for n in ns]
+    outs = ops.stft_batch([torch.from_numpy(y).cuda() for y in ys], want_complex=True, layout=layout)
+    mags = ops.stft_batch([torch.from_numpy(y).cuda() for y in ys], want_complex=False, layout=layout)
+    for y, X, Mg in zip(ys, outs, mags):
+        ref = OS.stft(y)                          # (257, T) complex64
+        got = X.cpu().numpy() if layout == "FT" else X.cpu().numpy().T
+        gm = Mg.cpu().numpy() if layout == "FT" else Mg.cpu().numpy().T
+        assert got.shape == ref.shape == (257, 1 + len(y) // 128)
+        tol = 1e-5 * np.abs(ref).max()            # stated tolerance: 1e-5 of the largest bin (fp32 FFT)
+        np.testing.assert_allclose(got, ref, atol=tol)
+        np.testing.assert_allclose(gm, np.abs(ref), atol=tol)
+
+
+def test_stft_pcm16_input_and_time_major_batch_layout(ops):
+    rng = np.random.default_rng(3)
+    pcm = [rng.integers(-20000, 20000, n).astype(np.int16) for n in (5000, 3000)]
+    Ts = [1 + len(p) // 128 for p in pcm]
+    B, F, T = 2, 257, max(Ts)
+    out = torch.zeros(T, B, F).cuda()
+    ops.stft_batch([torch.from_numpy(p).cuda() for p in pcm], out=out, out_offs=[b * F for b in range(B)],
+                   stride_t=[B * F] * B, stride_f=[1] * B)
+    got = out.cpu().numpy()
+    for b, p in enumerate(pcm):
+        ref = OS.stft_mag(OS.pcm16_to_float(p)).T          # (T_b, F)
+        np.testing.assert_allclose(got[:Ts[b], b], ref, atol=1e-5 * ref.max())
+        assert np.all(got[Ts[b]:, b] == 0)                  # padding untouched
+
+
+def test_mask_istft_matches_oracle_and_round_trips(ops):
+    rng = np.random.default_rng(11)
+    ns = [51072, 6400, 1000]
+    ys = [_sig(n, 100 + n) for n in ns]
+    specs = [OS.stft(y) for y in ys]
+    masks = [[rng.uniform(0, 1, s.shape).astype(np.float32) for _ in range(2)] for s in specs]
+    wav, pcm = ops.mask_istft([torch.from_numpy(s).cuda() for s in specs],
+                              [[torch.from_numpy(m).cuda() for m in ms] for ms in masks])
+    for u, s in enumerate(specs):
+        for k in range(2):
+            ref_f, ref_i = OS.reconstruct(s, masks[u][k])
+            got_f, got_i = wav[u][k].cpu().numpy(), pcm[u][k].cpu().numpy()
+            assert got_f.shape == ref_f.shape == (128 * (s.shape[1] - 1),)
+            np.testing.assert_allclose(got_f, ref_f, atol=3e-6)          # fp32 iFFT + overlap-add
+            d = np.abs(got_i.astype(np.int32) - ref_i.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3               # truncation boundary cases only
+    # no mask: istft(stft(x)) == x on the retained samples
+    wav, _ = ops.mask_istft([torch.from_numpy(s).cuda() for s in specs], None, want_pcm=False)
+    for u, y in enumerate(ys):
+        got = wav[u][0].cpu().numpy()
+        np.testing.assert_allclose(got, y[:len(got)], atol=3e-6)
+
+
+def test_istft_int16_wraps_like_reference(ops):
+    y = _sig(4096, 9) * 12.0                                   # |y| well above 1.0
+    s = OS.stft(y)
+    _, pcm = ops.mask_istft([torch.from_numpy(s).cuda()], None, want_float=False)
+    ref = OS.to_int16_wav(OS.istft(s))
+    d = np.abs(pcm[0][0].cpu().numpy().astype(np.int32) - ref.astype(np.int32))
+    d = np.minimum(d, 65536 - d)
+    assert d.max() <= 2 and (np.abs(y) > 1.0).any()
+
+
+# ------------------------------------------------------------------------------------ PIT-MSE
+@pytest.mark.parametrize("S", [1, 2, 3])
+def test_pit_mse_fwd_bwd_matches_oracle(ops, S):
+    torch.manual_seed(S)
+    T, B, F = 19, 5, 257
+    lens = torch.tensor([19, 17, 12, 12, 3])
+    valid = (torch.arange(T)[:, None] < lens[None, :]).float().unsqueeze(2)        # (T,B,1)
+    mask = torch.rand(T, B, S * F)
+    mix = torch.rand(T, B, F) * valid
+    srcs = [torch.rand(T, B, F) * valid for _ in range(S)]
+    mo = mask.permute(1, 0, 2).clone().requires_grad_(True)
+    loss, norm, losses, idx = OU.pit_mse(mo, mix.permute(1, 0, 2), [s.permute(1, 0, 2) for s in srcs], lens, S, F)
+    loss.backward()
+    res = ops.pit_mse_fwd(dev(mask), dev(mix), [dev(s) for s in srcs], dev(lens.int()))
+    out = res["out"].cpu().numpy()
+    np.testing.assert_allclose(out[0], float(loss), rtol=2e-6)
+    np.testing.assert_allclose(out[1], float(norm), rtol=0)
+    np.testing.assert_allclose(res["perm_loss"].cpu().numpy(), losses.detach().numpy(), rtol=2e-6)
+    assert res["best_perm"].cpu().tolist() == idx.tolist()
+    dm = ops.pit_mse_bwd(dev(mask), dev(mix), [dev(s) for s in srcs], res["best_perm"], res["out"],
+                         torch.ones(1).cuda())
+    np.testing.assert_allclose(dm.cpu().permute(1, 0, 2).numpy(), mo.grad.numpy(), rtol=1e-5, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------ BN / colsum / sigmoid
+def test_bn_stats_apply_backward(ops):
+    torch.manual_seed(0)
+    R, Cc = 1000, 200
+    x = torch.randn(R, Cc) * 0.5 + 0.3
+    x[700:] = 0.0                                             # zero-padded frames are part of the statistics
+    bn = torch.nn.BatchNorm1d(Cc)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    xr = x.clone().requires_grad_(True)
+    y = bn(xr)
+    dy = torch.randn(R, Cc)
+    y.backward(dy)
+    mean, var = torch.empty(Cc).cuda(), torch.empty(Cc).cuda()
+    ops.bn_stats(dev(x), mean, var)
+    np.testing.assert_allclose(mean.cpu().numpy(), x.double().mean(0).numpy(), atol=1e-6)
+    np.testing.assert_allclose(var.cpu().numpy(), x.double().var(0, unbiased=False).numpy(), rtol=2e-5)
+    rm, rv = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda()
+    ops.bn_update_running(mean, var, rm, rv, R, 0.1)
+    np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=2e-5)
+    out = torch.empty(R, Cc).cuda()
+    ops.bn_apply(dev(x), mean, var, dev(bn.weight.detach()), dev(bn.bias.detach()), out, 1e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), y.detach().numpy(), atol=5e-6)
+    dx, dg, db = torch.empty(R, Cc).cuda(), torch.empty(Cc).cuda(), torch.empty(Cc).cuda()
+    ops.bn_bwd(dev(dy), dev(x), mean, var, dev(bn.weight.detach()), dx, dg, db, 1e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), bn.weight.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), bn.bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-6)
+
+
+def test_colsum_and_sigmoid_bwd(ops):
+    torch.manual_seed(1)
+    x = torch.randn(777, 130)
+    out = torch.ones(100).cuda()
+    ops.colsum(dev(x)[:, 10:], 777, 100, 130, out, accumulate=True)
+    np.testing.assert_allclose(out.cpu().numpy(), x[:, 10:110].double().sum(0).numpy() + 1.0, atol=2e-4)
+    m, dm = torch.rand(5000), torch.randn(5000)
+    dz = torch.empty(5000).cuda()
+    ops.sigmoid_bwd(dev(dm), dev(m), dz)
+    np.testing.assert_allclose(dz.cpu().numpy(), (dm * m * (1 - m)).numpy(), rtol=1e-6, atol=1e-8)
+
+
+def test_clip_adam_matches_torch(ops):
+    torch.manual_seed(2)
+    n = 100_003
+    p0 = torch.randn(n)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pt], lr=1e-3)
+    p = dev(p0.clone())
+    m, v, scal = torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(2).cuda()
+    for step in range(1, 4):
+        g = torch.randn(n) * (0.01 if step == 2 else 1e-4)           # step 2 clips, the others do not
+        pt.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pt], 0.25)
+        opt.step()
+        ops.grad_norm(dev(g), 0.25, scal)
+        ops.clip_adam(p, dev(g), m, v, scal, 1e-3, 0.9, 0.999, 1e-8, step)
+        np.testing.assert_allclose(scal[0].item(), float(tn), rtol=1e-5)
+        np.testing.assert_allclose(p.cpu().numpy(), pt.detach().numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------ BLSTM recurrence
+def _layer_case(T, B, H, I, lens, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = 1.0 / np.sqrt(H)
+    w = [[tuple((torch.rand(s, generator=g) * 2 - 1) * k for s in ((4 * H, I), (4 * H, H), (4 * H,), (4 * H,)))
+          for _ in range(2)]]
+    x = torch.randn(T, B, I, generator=g)
+    for b, n in enumerate(lens):
+        x[n:, b] = 0
+    h0 = torch.randn(2, B, H, generator=g)
+    c0 = torch.randn(2, B, H, generator=g)
+    return w, x, h0, c0
+
+
+@pytest.mark.parametrize("mode", [2, 1])
+@pytest.mark.parametrize("T,B,H,I,lens", [
+    (5, 3, 8, 6, [5, 3, 1]),
+    (7, 20, 300, 33, [7] * 5 + [6] * 5 + [4] * 5 + [1] * 5),
+    (6, 32, 600, 40, [6] * 16 + [5] * 8 + [2] * 8),
+    (4, 32, 896, 24, [4] * 20 + [3] * 12),
+])
+def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
+    w, x, h0, c0 = _layer_case(T, B, H, I, lens, seed=T * 100 + H)
+    # ---- oracle with autograd
+    wr = [[tuple(t.clone().requires_grad_(True) for t in w[0][d]) for d in range(2)]]
+    h0r, c0r = h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    y_ref, hn_ref, cn_ref = OU.blstm_padded(x, lens, wr, h0r, c0r)
+    dy = torch.randn(T, B, 2 * H, generator=torch.Generator().manual_seed(1))
+    (y_ref * dy).sum().backward()
+    # ---- kernels
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+    wih = torch.stack([w[0][d][0] for d in range(2)]).cuda()          # (2,4H,I)
+    whh = torch.stack([w[0][d][1] for d in range(2)]).cuda()          # (2,4H,H)
+    bsum = torch.stack([w[0][d][2] + w[0][d][3] for d in range(2)]).reshape(-1).cuda()
+    R = T * B
+    gx = torch.empty(T, B, 2, 4 * H).cuda()
+    ops.gemm(dev(x), wih, gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum)
+    y = torch.full((T, B, 2 * H), float("nan")).cuda()
+    cs = torch.empty(T, B, 2, H).cuda()
+    hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
+    ws = ops.lstm_fwd(gx, whh, dev(h0), dev(c0), lens_d, y, gx, cs, hn, cn, T, B, H, mode)
+    ops.lstm_status(ws)
+    tol = dict(rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(hn.cpu().numpy(), hn_ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(cn.cpu().numpy(), cn_ref.detach().numpy(), **tol)
+    dh0, dc0 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
+    ws = ops.lstm_bwd(dev(dy), whh, gx, cs, dev(c0), lens_d, gx, dh0, dc0, T, B, H, mode)
+    ops.lstm_status(ws)
+    gtol = dict(rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(dh0.cpu().numpy(), h0r.grad.numpy(), **gtol)
+    np.testing.assert_allclose(dc0.cpu().numpy(), c0r.grad.numpy(), **gtol)
+    dgx = gx.cpu().double().view(R, 2, 4 * H)
+    assert torch.isfinite(dgx).all()
+    hprev = torch.empty(T, B, 2, H).cuda()
+    ops.lstm_hprev(y, dev(h0), lens_d, hprev, T, B, H)
+    hp = hprev.cpu().double().view(R, 2, H)
+    for d in range(2):
+        w_ih_g, w_hh_g, b_ih_g, b_hh_g = (t.grad for t in wr[0][d])
+        np.testing.assert_allclose((dgx[:, d].t() @ x.double().view(R, I)).numpy(), w_ih_g.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose((dgx[:, d].t() @ hp[:, d]).numpy(), w_hh_g.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(dgx[:, d].sum(0).numpy(), b_ih_g.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(b_hh_g.numpy(), b_ih_g.numpy())

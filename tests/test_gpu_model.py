@@ -1,0 +1,225 @@
+"""The drop-in arch module (speech-separation_amd/archs/uPIT.py) on the MI355X against
+(1) golden vectors produced by the reference's own archs/uPIT.py and (2) the CPU oracle.
+
+Tolerances (fp32 end to end; differences are summation order and libm only):
+  masks 1e-4 relative (BASELINE.json), loss 1e-5 relative, same arg-min permutation,
+  SI-SDR of reconstructed waveforms within +-0.1 dB.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, fixture_samples
+from oracle import stft as OS
+from oracle import upit as OU
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(ROOT, "speech-separation_amd", "archs"))
+
+
+@pytest.fixture(scope="module")
+def arch():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    import uPIT
+    return uPIT
+
+
+def _hidden(fx, prefix=""):
+    return (torch.from_numpy(fx[prefix + "h0"]).cuda(), torch.from_numpy(fx[prefix + "c0"]).cuda())
+
+
+def _check_init(model, fx, prefix="wsum_"):
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            got = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+            np.testing.assert_allclose(got, fx[prefix + k], rtol=1e-6, atol=1e-6, err_msg="init drift in " + k)
+
+
+@pytest.mark.parametrize("tag", ["s2", "s3"])
+def test_compute_loss_matches_reference_golden(arch, tag):
+    fx = np.load(os.path.join(GOLDEN, "ref_upit_loss_%s.npz" % tag))
+    S, lens = int(fx["num_spk"]), fx["lens"].tolist()
+    torch.manual_seed(int(fx["seed"]))
+    model = arch.SepDNN(0, num_spk=str(S))
+    model.cuda()
+    model.train()
+    assert list(model.state_dict().keys())[:4] == ["blstm.weight_ih_l0", "blstm.weight_hh_l0", "blstm.bias_ih_l0",
+                                                   "blstm.bias_hh_l0"]
+    assert list(model.state_dict().keys())[-7:] == ["lin.weight", "lin.bias", "bn.weight", "bn.bias",
+                                                    "bn.running_mean", "bn.running_var", "bn.num_batches_tracked"]
+    samples = fixture_samples(fx, "", len(lens), ["mix"] + ["source%d" % (s + 1) for s in range(S)])
+    batch = arch.Collator("mix")(samples)
+    model.next_hidden = _hidden(fx)
+    loss, norm = arch.compute_loss(model, 0, batch)
+    loss.backward()
+    _check_init(model, fx)                              # weights equal the reference's, running stats moved once
+    assert float(norm) == float(fx["norm"])
+    np.testing.assert_allclose(float(loss), float(fx["loss"]), rtol=1e-5)
+    for k, p in model.named_parameters():
+        g = p.grad
+        np.testing.assert_allclose(float(g.double().norm()), float(fx["gnorm_" + k]), rtol=2e-4, err_msg=k)
+        flat = g.flatten()
+        sl = flat[:: max(1, flat.numel() // 64)][:64].cpu().numpy()
+        np.testing.assert_allclose(sl, fx["gslice_" + k], rtol=2e-3, atol=2e-7, err_msg=k)
+    # masks: same (h0,c0), train-mode BN (batch statistics), no grad
+    model.next_hidden = _hidden(fx)
+    model.hidden = model.init_hidden(len(lens))
+    with torch.no_grad():
+        mask = model(batch["mix"])
+    ref = fx["mask_out"]
+    assert tuple(mask.shape) == ref.shape
+    got = mask.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    np.testing.assert_allclose(((got - ref) ** 2).mean() / (ref ** 2).mean(), 0, atol=1e-8)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_three_train_steps_match_reference_golden(arch, fused):
+    from sepkern.optim import ClipAdam
+    fx = np.load(os.path.join(GOLDEN, "ref_upit_train3.npz"))
+    torch.manual_seed(int(fx["seed"]))
+    model = arch.SepDNN(0)
+    model.cuda()
+    model.train()
+    opt = ClipAdam(model, lr=0.001, max_norm=0.25) if fused else torch.optim.Adam(model.parameters(), lr=0.001)
+    for step in range(3):
+        lens = fx["step%d_lens" % step].tolist()
+        samples = fixture_samples(fx, "step%d_" % step, len(lens), ["mix", "source1", "source2"])
+        batch = arch.Collator("mix")(samples)
+        model.next_hidden = _hidden(fx, "step%d_" % step)
+        loss, norm = arch.compute_loss(model, 0, batch)      # steps/train_qsub.py:117-122
+        loss.backward()
+        if fused:
+            gnorm = float(opt.step()[0])
+        else:
+            gnorm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25))
+            opt.step()
+        np.testing.assert_allclose(float(loss), float(fx["step%d_loss" % step]), rtol=5e-5)
+        assert float(norm) == float(fx["step%d_norm" % step])
+        np.testing.assert_allclose(gnorm, float(fx["step%d_gnorm" % step]), rtol=2e-4)
+    for k, v in model.state_dict().items():
+        if v.dtype.is_floating_point:
+            got = np.array([float(v.double().sum()), float(v.double().abs().sum())])
+            np.testing.assert_allclose(got, fx["wsum_final_" + k], rtol=2e-5, atol=2e-4, err_msg=k)
+    assert int(model.bn.num_batches_tracked) == 3
+
+
+def test_compute_masks_matches_reference_golden(arch, tmp_path):
+    fx = np.load(os.path.join(GOLDEN, "ref_upit_masks.npz"))
+    torch.manual_seed(int(fx["seed"]))
+    model = arch.SepDNN(0)
+    sd = model.state_dict()
+    sd["bn.running_mean"] = torch.from_numpy(fx["running_mean"])
+    sd["bn.running_var"] = torch.from_numpy(fx["running_var"])
+    model.cuda()
+    model.load_state_dict(sd)                               # exercises the state_dict round trip
+    model.eval()
+    lens = fx["lens"].tolist()
+    samples = fixture_samples(fx, "", len(lens), ["mix"])
+    for i, d in enumerate(samples):
+        d["name"] = "utt%02d.npz" % i
+    batch = arch.Collator("mix")(samples)
+    model.next_hidden = _hidden(fx)
+    with torch.no_grad():
+        arch.compute_masks(model, batch, str(tmp_path))
+    for i, n in enumerate(lens):
+        z = np.load(os.path.join(str(tmp_path), "utt%02d.npz" % i))
+        assert z.files == ["s1", "s2"]
+        for k in z.files:
+            ref = fx["mask_utt%02d.npz_%s" % (i, k)]
+            assert z[k].shape == ref.shape == (257, n) and z[k].dtype == np.float32
+            assert np.abs(z[k] - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def _oracle_like(model, H, L, S):
+    """An OracleSepDNN carrying the same weights as the GPU model."""
+    o = OU.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
+    o.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    return o
+
+
+@pytest.mark.parametrize("H,L,S,B,T", [(300, 2, 2, 8, 40), (896, 3, 2, 32, 24), (600, 2, 3, 5, 30)])
+def test_configs_match_oracle(arch, H, L, S, B, T):
+    """BASELINE configs 1 (2x300), 2 (3x896, B=32) and 4 (3 speakers) against the CPU oracle, ragged lengths."""
+    torch.manual_seed(H + L)
+    rng = np.random.default_rng(H)
+    model = arch.SepDNN(0, num_spk=str(S), hidden_dim=str(H), num_layers=str(L))
+    model.cuda()
+    model.train()
+    orc = _oracle_like(model, H, L, S)
+    orc.train()
+    lens = sorted([int(v) for v in rng.integers(max(2, T // 2), T + 1, B)])
+    lens[-1] = T
+    samples = []
+    for n in lens:
+        d = {"mix": np.abs(rng.standard_normal((n, 257))).astype(np.float32)}
+        for s in range(S):
+            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((n, 257))).astype(np.float32) * 0.6
+        samples.append(d)
+    batch = arch.Collator("mix")(samples)
+    h0, c0 = torch.randn(2 * L, B, H), torch.randn(2 * L, B, H)
+    lo, no, aux = OU.compute_loss(orc, OU.collate(samples), (h0, c0))
+    lo.backward()
+    model.next_hidden = (h0.cuda(), c0.cuda())
+    loss, norm = arch.compute_loss(model, 0, batch)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(lo), rtol=1e-5)
+    assert float(norm) == float(no)
+    og = dict(orc.named_parameters())
+    for k, p in model.named_parameters():
+        ref = og[k].grad
+        err = float((p.grad.cpu().double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
+        assert err < 2e-4, (k, err)
+    model.next_hidden = (h0.cuda(), c0.cuda())
+    model.hidden = model.init_hidden(B)
+    with torch.no_grad():
+        mask = model(batch["mix"]).cpu().numpy()
+    ref = aux["mask_out"].detach().numpy()
+    assert np.abs(mask - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_end_to_end_si_sdr_parity(arch):
+    """wav -> STFT -> masks -> mask-apply + iSTFT -> int16 wav, GPU path vs oracle path, SI-SDR +-0.1 dB."""
+    from sepkern import ops, synth
+    from sepkern.sisdr import si_sdr_best_perm
+    torch.manual_seed(3)
+    H, L, S = 300, 2, 2
+    model = arch.SepDNN(0, hidden_dim=str(H), num_layers=str(L))
+    model.cuda()
+    model.eval()
+    orc = _oracle_like(model, H, L, S)
+    orc.eval()
+    pcms = synth.pcm_batch(3, lengths=[24000, 20000, 16000])
+    # GPU path
+    specs = ops.stft_batch([torch.from_numpy(p[0]).cuda() for p in pcms], want_complex=True, layout="FT")
+    samples = [{"mix": np.abs(s.cpu().numpy()).T, "name": "u%d.npz" % i} for i, s in enumerate(specs)]
+    batch = arch.Collator("mix")(samples)
+    order = OU.collate_order([len(d["mix"]) for d in samples])
+    B = len(samples)
+    h0, c0 = torch.randn(2 * L, B, H), torch.randn(2 * L, B, H)
+    model.next_hidden = (h0.cuda(), c0.cuda())
+    model.hidden = model.init_hidden(B)
+    with torch.no_grad():
+        mask = model(batch["mix"])                                   # (B, T, S*F) in collated order
+    # oracle path
+    ospecs = [OS.stft(OS.pcm16_to_float(p[0])) for p in pcms]
+    osamples = [{"mix": np.abs(s).T, "name": "u%d.npz" % i} for i, s in enumerate(ospecs)]
+    with torch.no_grad():
+        omasks = OU.compute_masks(orc, OU.collate(osamples), (h0, c0))
+    for pos, u in enumerate(order):
+        T = specs[u].shape[1]
+        gm = [mask[pos, :T, s * 257:(s + 1) * 257].t().contiguous() for s in range(S)]
+        wav, pcm = ops.mask_istft([specs[u]], [gm])
+        refs = [OS.pcm16_to_float(p)[:128 * (T - 1)] for p in pcms[u][1:]]
+        est_g = [pcm[0][s].cpu().numpy().astype(np.float64) for s in range(S)]
+        est_o = [OS.reconstruct(ospecs[u], omasks["u%d.npz" % u]["s%d" % (s + 1)])[1].astype(np.float64) for s in range(S)]
+        sg, so = si_sdr_best_perm(est_g, refs), si_sdr_best_perm(est_o, refs)
+        assert abs(sg - so) <= 0.1, (sg, so)
+        for s in range(S):
+            d = np.abs(est_g[s] - est_o[s])
+            assert d.max() <= 2.0                                    # int16 LSBs
