@@ -94,9 +94,11 @@ def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, s
             stride_f.append(1 if layout == "TF" else T)
             acc += T * F
         ret = [out[o:o + T * F].view((T, F) if layout == "TF" else (F, T)) for o, T in zip(out_offs, Ts)]
-    _lib.call("sk_stft", _ptr(cat), int(pcm16), _ptr(_i64(woffs, dev)), _ptr(torch.tensor(ns, dtype=torch.int32, device=dev)),
-              len(wavs), 512, 128, int(want_complex), _ptr(out), _ptr(_i64(out_offs, dev)), _ptr(_i64(stride_t, dev)),
-              _ptr(_i64(stride_f, dev)), max(Ts), _stream())
+    # descriptor arrays must outlive the (asynchronous) launch call: keep references until it returns
+    d_woffs, d_ns = _i64(woffs, dev), torch.tensor(ns, dtype=torch.int32, device=dev)
+    d_ooffs, d_st, d_sf = _i64(out_offs, dev), _i64(stride_t, dev), _i64(stride_f, dev)
+    _lib.call("sk_stft", _ptr(cat), int(pcm16), _ptr(d_woffs), _ptr(d_ns), len(wavs), 512, 128, int(want_complex),
+              _ptr(out), _ptr(d_ooffs), _ptr(d_st), _ptr(d_sf), max(Ts), _stream())
     return ret if ret is not None else out
 
 
@@ -137,13 +139,14 @@ def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True):
             acc += 128 * (Ts[u] - 1)
     wav = torch.empty(acc, dtype=torch.float32, device=dev) if want_float else None
     pcm = torch.empty(acc, dtype=torch.int16, device=dev) if want_pcm else None
-    _lib.call("sk_mask_istft", _ptr(mixcat), _ptr(_i64(moffs, dev)), _ptr(_i64(mst, dev)), _ptr(_i64(msf, dev)),
-              _ptr(maskcat) if masks is not None else None,
-              _ptr(_i64(koffs, dev)) if masks is not None else None,
-              _ptr(_i64(kst, dev)) if masks is not None else None,
-              _ptr(_i64(ksf, dev)) if masks is not None else None,
-              _ptr(torch.tensor(Ts, dtype=torch.int32, device=dev)), nutt, S, 512, 128, _ptr(wav), _ptr(pcm),
-              _ptr(_i64(ooffs, dev)), max(Ts), _stream())
+    d_moffs, d_mst, d_msf = _i64(moffs, dev), _i64(mst, dev), _i64(msf, dev)
+    d_koffs = d_kst = d_ksf = None
+    if masks is not None:
+        d_koffs, d_kst, d_ksf = _i64(koffs, dev), _i64(kst, dev), _i64(ksf, dev)
+    d_T, d_ooffs = torch.tensor(Ts, dtype=torch.int32, device=dev), _i64(ooffs, dev)
+    _lib.call("sk_mask_istft", _ptr(mixcat), _ptr(d_moffs), _ptr(d_mst), _ptr(d_msf),
+              _ptr(maskcat) if masks is not None else None, _ptr(d_koffs), _ptr(d_kst), _ptr(d_ksf),
+              _ptr(d_T), nutt, S, 512, 128, _ptr(wav), _ptr(pcm), _ptr(d_ooffs), max(Ts), _stream())
 
     def split(buf):
         if buf is None:

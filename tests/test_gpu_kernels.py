@@ -144,8 +144,9 @@ def test_pit_mse_fwd_bwd_matches_oracle(ops, S):
     mask = torch.rand(T, B, S * F)
     mix = torch.rand(T, B, F) * valid
     srcs = [torch.rand(T, B, F) * valid for _ in range(S)]
-    mo = mask.permute(1, 0, 2).clone().requires_grad_(True)
-    loss, norm, losses, idx = OU.pit_mse(mo, mix.permute(1, 0, 2), [s.permute(1, 0, 2) for s in srcs], lens, S, F)
+    mo = mask.permute(1, 0, 2).contiguous().requires_grad_(True)
+    loss, norm, losses, idx = OU.pit_mse(mo, mix.permute(1, 0, 2).contiguous(),
+                                          [s.permute(1, 0, 2).contiguous() for s in srcs], lens, S, F)
     loss.backward()
     res = ops.pit_mse_fwd(dev(mask), dev(mix), [dev(s) for s in srcs], dev(lens.int()))
     out = res["out"].cpu().numpy()
