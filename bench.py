@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of uPIT BLSTM TRAINING on WSJ0-2mix-shaped synthetic data.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the training hot path over one batch already resident in HBM:
+random h0/c0 -> BLSTM (input-projection GEMMs + persistent recurrence) -> BatchNorm -> Linear+sigmoid ->
+PIT-MSE loss -> full backward -> [N>1: RCCL all-reduce of the flat gradient] -> clip_grad_norm_(0.25) + Adam.
+Workload (BASELINE.json configs[1]): uPIT 3x896 BLSTM, 2 speakers, 512-pt STFT features (257 bins),
+batch 32 x 400 frames PER GPU (weak scaling), fp32.  frames = sum of valid STFT frames per step.
+The features are produced before the timed region by the STFT kernel from synthetic 8 kHz PCM.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline      the dominant kernel (fp32 MFMA GEMM): algorithmic FLOP / HIP-event time, live in the timed region
+  cpu_baseline  the CPU oracle's train step (torch-CPU port of the reference loop) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "speech-separation_amd")
+for p in (ROOT, PKG, os.path.join(PKG, "archs")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* at 64 FLOP/clk/SIMD, 256 CUs, 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.time()
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--hidden", type=int, default=896)
+    ap.add_argument("--layers", type=int, default=3)
+    ap.add_argument("--num-spk", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--aux", action="store_true", help="also time the STFT / iSTFT kernels (extra JSON fields)")
+    return ap.parse_args()
+
+
+def make_batch(torch, ops, synth, B, T, S, rank):
+    """Synthetic PCM -> STFT magnitudes on the GPU, time-major (T,B,257), all utterances T frames."""
+    n = 128 * (T - 1) + 64
+    pcms = synth.pcm_batch(B, n_samples=n, num_spk=S, first_utt=rank * B)
+    F = 257
+    feats = []
+    for k in range(S + 1):
+        out = torch.zeros(T, B, F, device="cuda")
+        ops.stft_batch([torch.from_numpy(p[k]).cuda() for p in pcms], out=out, out_offs=[b * F for b in range(B)],
+                       stride_t=[B * F] * B, stride_f=[1] * B)
+        feats.append(out)
+    lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    return feats[0], feats[1:], lens, pcms
+
+
+def cpu_baseline(H, L, S):
+    """The oracle's train step (same torch-CPU ops as the reference loop, steps/train_qsub.py:116-122)
+    on a bounded sample of the workload: same model, batch 8 x 100 frames."""
+    import numpy as np
+    import torch
+    from oracle import upit as OU
+    B, T = 8, 100
+    torch.manual_seed(0)
+    # the GPU box gives a 1-GPU job a 16-CPU share of a much larger host: os.cpu_count() would oversubscribe
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(16, avail))
+    torch.set_num_threads(threads)
+    model = OU.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    rng = np.random.default_rng(0)
+    samples = []
+    for _ in range(B):
+        d = {"mix": np.abs(rng.standard_normal((T, 257))).astype(np.float32)}
+        for s in range(S):
+            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((T, 257))).astype(np.float32)
+        samples.append(d)
+    batch = OU.collate(samples)
+    OU.train_step(model, opt, batch, model.init_hidden(B))           # warm-up
+    t0 = time.time()
+    n = 0
+    while n < 3 or (time.time() - t0 < 10.0 and n < 20):
+        OU.train_step(model, opt, batch, model.init_hidden(B))
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n * B * T / dt, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "oracle train step (torch-CPU nn.LSTM/BN/Linear + PIT-MSE + clip + Adam), same %dx%d model, "
+                      "batch %d x %d frames, %d steps after 1 warm-up" % (L, H, B, T, n)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from sepkern import ops, synth, _lib
+    from sepkern.optim import ClipAdam
+    _lib.load()
+    import uPIT
+
+    H, L, S, B, T = args.hidden, args.layers, args.num_spk, args.batch, args.frames
+    torch.manual_seed(0)                                  # identical initial weights on every rank
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # SepDNN prints its conf keys like the reference does
+        model = uPIT.SepDNN(local, num_spk=str(S), hidden_dim=str(H), num_layers=str(L))
+    model.cuda()
+    model.train()
+    model.hidden_generator = torch.Generator(device="cuda")
+    model.hidden_generator.manual_seed(1234 + rank)       # per-rank h0/c0 stream
+    opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
+    log("model ready (%dx%d, %d speakers); building the synthetic batch" % (L, H, S))
+    mix, srcs, lens, pcms = make_batch(torch, ops, synth, B, T, S, rank)
+    log("batch resident in HBM: %d x %d frames" % (B, T))
+    frames_per_step = int(lens.sum().item()) * world
+    loss_acc = torch.zeros(2, device="cuda")
+
+    def step():
+        loss, norm = uPIT.compute_loss_padded(model, mix, srcs, lens)
+        loss_acc[0] += loss.detach() * norm               # epoch loss bookkeeping stays on the device
+        loss_acc[1] += norm
+        loss.backward()
+        opt.step()
+
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % (i + 1))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_events:
+        ops.PROF = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    log("timed region done: %.3f ms/step" % (1000.0 * dt / args.steps))
+    prof = ops.prof_summary()
+    ops.PROF = None
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(loss_acc[0] / loss_acc[1])
+    if not (final_loss == final_loss) or final_loss <= 0:
+        sys.exit("bench: loss is not finite/positive (%r)" % final_loss)
+
+    res = {
+        "metric": "frames/sec uPIT BLSTM training on WSJ0-2mix-shaped synth",
+        "value": round(frames_per_step * args.steps / dt, 1),
+        "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * dt / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "uPIT %dx%d BLSTM, %d-spk, 512-pt STFT (257 bins), batch %d x %d frames per GPU, "
+                               "fwd + PIT-MSE + bwd + clip 0.25 + Adam, random-init weights"
+                               % (L, H, S, B, T),
+                   "global_batch": B * world, "frames_per_step": frames_per_step,
+                   "parallelism": "dp%d" % world if world > 1 else "single",
+                   "mean_loss": round(final_loss, 6)},
+    }
+    if prof:
+        n, ms, fl = prof["gemm_f32_kernel"]
+        ach = fl / (ms * 1e-3) / 1e12
+        res["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(ach, 2),
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                           "traffic": None, "launches_per_step": n // args.steps,
+                           "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms / args.steps, 3)}
+        res["kernels"] = {k: {"launches_per_step": v[0] // args.steps, "ms_per_step": round(v[1] / args.steps, 3),
+                              "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in prof.items()}
+        # whole-step figure against the same roofline: 6 x MACs per frame
+        P = sum(2 * 4 * H * ((257 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257 * S
+        res["step_tflops"] = round(6.0 * P * frames_per_step / world / (dt / args.steps) / 1e12, 2)
+        res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+    if args.aux and rank == 0:
+        res["aux"] = aux_kernels(torch, ops, pcms, mix, T, B, S)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("timing the CPU baseline (bounded sample)")
+        res["cpu_baseline"] = cpu_baseline(H, L, S)
+        log("CPU baseline done: %s frames/s on %d threads" % (res["cpu_baseline"]["value"], res["cpu_baseline"]["cores"]))
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def aux_kernels(torch, ops, pcms, mix, T, B, S):
+    """HBM-bound front/back ends: STFT (train layout) and mask-apply + iSTFT, GB/s of algorithmic bytes."""
+    wavs = [torch.from_numpy(p[k]).cuda() for p in pcms for k in range(S + 1)]
+    specs = ops.stft_batch([torch.from_numpy(p[0]).cuda() for p in pcms], want_complex=True, layout="FT")
+    masks = [[torch.rand(257, T, device="cuda") for _ in range(S)] for _ in pcms]
+    out = {}
+
+    def timeit(fn, n=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    ms = timeit(lambda: ops.stft_batch(wavs, want_complex=False, layout="TF"))
+    nfr = T * B * (S + 1)
+    by = nfr * (128 * 2 + 257 * 4)
+    out["stft_mag"] = {"ms_incl_host": round(ms, 4), "frames_per_s": round(nfr / ms * 1e3), "GBs_algorithmic": round(by / ms / 1e6, 1)}
+    ms = timeit(lambda: ops.mask_istft(specs, masks, want_float=False))
+    by = T * B * S * (257 * 8 + 257 * 4 + 128 * 2)
+    out["mask_istft"] = {"ms_incl_host": round(ms, 4), "frames_per_s": round(T * B * S / ms * 1e3), "GBs_algorithmic": round(by / ms / 1e6, 1)}
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -141,7 +141,6 @@ class _NetFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, anchor, model, x, lens, h0, c0):
     ctx.model = model
-    ctx.saved_fwd = torch.is_grad_enabled() or anchor.requires_grad
     return model._engine.forward(x, lens, h0, c0, model.training, save=True)
 
   @staticmethod
@@ -308,13 +307,10 @@ def compute_cv_loss(model, epoch, batch_sample, plotdir=""):
   return loss, norm
 
 
-# define training pass
-def compute_loss(model, epoch, batch_sample, plotdir=""):
-  dev = model.lin.weight.device
-  mix, lens = _to_padded(batch_sample['mix'], dev)
+def compute_loss_padded(model, mix, sources, lens, plotdir=""):
+  """compute_loss on inputs that are already resident on the GPU: mix (T,B,F) and sources
+  [(T,B,F)]*S zero-padded time-major float32, lens int32 (B).  Same return as compute_loss."""
   batch = mix.shape[1]
-  sources = [_to_padded(batch_sample['source' + str(i + 1)], dev)[0] for i in range(model.num_spk)]
-
   model.zero_grad()
   model.hidden = model.init_hidden(batch)
 
@@ -344,6 +340,14 @@ def compute_loss(model, epoch, batch_sample, plotdir=""):
                    plotdir + '/Chosen_Permutation.png')
 
   return loss, norm
+
+
+# define training pass
+def compute_loss(model, epoch, batch_sample, plotdir=""):
+  dev = model.lin.weight.device
+  mix, lens = _to_padded(batch_sample['mix'], dev)
+  sources = [_to_padded(batch_sample['source' + str(i + 1)], dev)[0] for i in range(model.num_spk)]
+  return compute_loss_padded(model, mix, sources, lens, plotdir)
 
 
 # define test pass

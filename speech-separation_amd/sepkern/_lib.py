@@ -5,6 +5,11 @@ The product path has NO fallback: if the HIP library is missing or a call fails,
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (libamdhip64): it must be loaded BEFORE libsepkern.so so that
+# the dynamic linker binds our library to that same runtime instance (one runtime per process;
+# device pointers and streams are shared with torch).
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsepkern.so")
 

@@ -11,6 +11,36 @@ from . import _lib
 
 _WS = {}
 
+# Optional per-kernel-class timing with HIP events recorded on the launch stream (bench.py):
+# PROF = {} enables it; each timed call appends (class, start_event, end_event, flops).
+PROF = None
+
+
+class _timed:
+    def __init__(self, cls, flops=0.0):
+        self.cls, self.flops = cls, flops
+
+    def __enter__(self):
+        if PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROF is not None:
+            self.e1.record()
+            PROF.setdefault(self.cls, []).append((self.e0, self.e1, self.flops))
+        return False
+
+
+def prof_summary():
+    """{class: (launches, total_ms, total_flops)} -- call after torch.cuda.synchronize()."""
+    out = {}
+    for cls, recs in (PROF or {}).items():
+        out[cls] = (len(recs), sum(a.elapsed_time(b) for a, b, _ in recs), sum(f for _, _, f in recs))
+    return out
+
 
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -52,6 +82,11 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     first element of the operand (views are fine: leading dimensions are explicit)."""
     for t in (A, B, Cout, bias):
         _chk(t)
+    with _timed("gemm_f32_kernel", 2.0 * M * N * K * batch):
+        _gemm_call(A, B, Cout, M, N, K, lda, ldb, ldc, transA, transB, bias, accumulate, act, batch, sA, sB, sC, sbias)
+
+
+def _gemm_call(A, B, Cout, M, N, K, lda, ldb, ldc, transA, transB, bias, accumulate, act, batch, sA, sB, sC, sbias):
     _lib.call("sk_gemm_f32", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA),
               int(transB), int(accumulate), int(act), batch, sA, sB, sC, sbias, _stream())
 
@@ -237,15 +272,17 @@ def lstm_ws(T, B, H):
 
 def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0):
     ws = lstm_ws(T, B, H)
-    _lib.call("sk_lstm_fwd", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(y), _ptr(gates), _ptr(cs),
-              _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, _stream())
+    with _timed("lstm_fwd_kernel", 2.0 * T * B * 2 * 4 * H * H):
+        _lib.call("sk_lstm_fwd", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(y), _ptr(gates), _ptr(cs),
+                  _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, _stream())
     return ws
 
 
 def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0):
     ws = lstm_ws(T, B, H)
-    _lib.call("sk_lstm_bwd", _ptr(dy), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0), _ptr(lens), _ptr(dgx), _ptr(dh0),
-              _ptr(dc0), _ptr(ws), T, B, H, mode, _stream())
+    with _timed("lstm_bwd_kernel", 2.0 * T * B * 2 * 4 * H * H):
+        _lib.call("sk_lstm_bwd", _ptr(dy), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0), _ptr(lens), _ptr(dgx), _ptr(dh0),
+                  _ptr(dc0), _ptr(ws), T, B, H, mode, _stream())
     return ws
 
 
