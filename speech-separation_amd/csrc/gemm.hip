@@ -27,36 +27,42 @@ struct GemmArgs {
   int64_t sA, sB, sC, sbias;
 };
 
-// Load 4 consecutive elements p[0..3] of which the first `valid` (0..4) are in range.
-__device__ __forceinline__ float4 ld4(const float* p, int valid, bool vec) {
-  if (valid >= 4 && vec) return *reinterpret_cast<const float4*>(p);
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid > 0) v.x = p[0];
-  if (valid > 1) v.y = p[1];
-  if (valid > 2) v.z = p[2];
-  if (valid > 3) v.w = p[3];
-  return v;
-}
-
-// Fetch this thread's two float4 pieces of an operand tile.
-//  TR == false: operand stored [rows = tile dim (M or N)][K]  (needs transposing into k-major LDS)
-//  TR == true : operand stored [K][tile dim]                   (already k-major)
+// Fetch this thread's two float4 pieces of an operand tile.  Two branch-free forms, selected by a
+// block-uniform condition (per-element "load or zero" branches make hipcc wait vmcnt(0) per load):
+//  fast : tile fully inside the matrix and 16-byte aligned -> unconditional float4 loads
+//  slow : every element loaded from a CLAMPED in-range address and zeroed by a select
+//  KMAJOR == false: operand stored [tile dim (M or N)][K]  (transposed into k-major LDS by stash)
+//  KMAJOR == true : operand stored [K][tile dim]            (already k-major)
 template <bool KMAJOR>
 __device__ __forceinline__ void fetch(const float* __restrict__ P, int ld, int dim0, int dimLimit, int k0, int K,
-                                      bool vec, int tid, float4 (&r)[2]) {
+                                      bool fast, int tid, float4 (&r)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int idx = tid + 256 * i;
+    int row, col, rowLimit, colLimit;  // element (row, col..col+3) of the stored matrix
     if (KMAJOR) {
-      const int kr = idx >> 5, c4 = (idx & 31) * 4;
-      const int k = k0 + kr, c = dim0 + c4;
-      const int valid = (k < K) ? max(0, min(4, dimLimit - c)) : 0;
-      r[i] = ld4(P + (int64_t)k * ld + c, valid, vec);
+      row = k0 + (idx >> 5);
+      col = dim0 + (idx & 31) * 4;
+      rowLimit = K;
+      colLimit = dimLimit;
     } else {
-      const int row = idx >> 2, k4 = (idx & 3) * 4;
-      const int rr = dim0 + row, k = k0 + k4;
-      const int valid = (rr < dimLimit) ? max(0, min(4, K - k)) : 0;
-      r[i] = ld4(P + (int64_t)rr * ld + k, valid, vec);
+      row = dim0 + (idx >> 2);
+      col = k0 + (idx & 3) * 4;
+      rowLimit = dimLimit;
+      colLimit = K;
+    }
+    if (fast) {
+      r[i] = *reinterpret_cast<const float4*>(P + (int64_t)row * ld + col);
+    } else {
+      const bool rok = row < rowLimit;
+      const float* q = P + (int64_t)min(row, rowLimit - 1) * ld;
+      const int cmax = colLimit - 1;
+      const float v0 = q[min(col + 0, cmax)], v1 = q[min(col + 1, cmax)];
+      const float v2 = q[min(col + 2, cmax)], v3 = q[min(col + 3, cmax)];
+      r[i].x = (rok && col + 0 < colLimit) ? v0 : 0.f;
+      r[i].y = (rok && col + 1 < colLimit) ? v1 : 0.f;
+      r[i].z = (rok && col + 2 < colLimit) ? v2 : 0.f;
+      r[i].w = (rok && col + 3 < colLimit) ? v3 : 0.f;
     }
   }
 }
@@ -86,8 +92,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tile = blockIdx.x;
+  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a
+  // contiguous run of tiles (n fastest): neighbours in a run share their A panel, runs share B.
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
+    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+  }
   const int m0 = (tile / g.tilesN) * BM, n0 = (tile % g.tilesN) * BN;
+  const bool fullA = g.vecA && (m0 + BM <= g.M), fullB = g.vecB && (n0 + BN <= g.N);
   const int z = blockIdx.z;
   const float* A = g.A + z * g.sA;
   const float* B = g.B + z * g.sB;
@@ -105,8 +118,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int nk = (g.K + BK - 1) / BK;
   float4 ra[2], rb[2];
   // A is k-major in memory when TA (stored K x M); B is k-major when !TB (stored K x N)
-  fetch<TA>(A, g.lda, m0, g.M, 0, g.K, g.vecA, tid, ra);
-  fetch<!TB>(B, g.ldb, n0, g.N, 0, g.K, g.vecB, tid, rb);
+  fetch<TA>(A, g.lda, m0, g.M, 0, g.K, fullA && BK <= g.K, tid, ra);
+  fetch<!TB>(B, g.ldb, n0, g.N, 0, g.K, fullB && BK <= g.K, tid, rb);
   stash<TA>(As[0], tid, ra);
   stash<!TB>(Bs[0], tid, rb);
   __syncthreads();
@@ -116,8 +129,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      fetch<TA>(A, g.lda, m0, g.M, (kt + 1) * BK, g.K, g.vecA, tid, ra);
-      fetch<!TB>(B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, g.vecB, tid, rb);
+      const bool kfull = (kt + 2) * BK <= g.K;  // block-uniform
+      fetch<TA>(A, g.lda, m0, g.M, (kt + 1) * BK, g.K, fullA && kfull, tid, ra);
+      fetch<!TB>(B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, fullB && kfull, tid, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
