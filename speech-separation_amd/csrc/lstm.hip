@@ -5,22 +5,26 @@
 // the sequential part  gates_t = gx_t + h_{t-1} W_hh^T  ->  cell update,  T steps per direction.
 //
 // Design (MI355X-first):
-//  * One workgroup per CU owns 16 hidden units x 16 batch rows of one direction.  Its slice of
-//    W_hh (64 gate rows x H, up to 256 KB) lives in the VGPRs of its 4 waves for the WHOLE
-//    sequence: 4*KS registers per lane feed v_mfma_f32_16x16x4_f32 as the A operand, so the
-//    recurrent weights are read from HBM once per layer, not once per step.
+//  * One 512-thread workgroup per CU (8 waves, 2 per SIMD) owns 16 hidden units x 16 batch rows
+//    of one direction.  Its slice of W_hh (64 gate rows x H, 224 KB at H=896) lives in the VGPRs
+//    of its waves for the WHOLE sequence (4*KS/2 registers per lane) and feeds
+//    v_mfma_f32_16x16x4_f32 as the A operand: recurrent weights are read once per layer, not per
+//    step.  Two waves per SIMD let the hardware overlap one wave's LDS reads with the other's MFMAs.
 //  * The MFMA is issued transposed (rows = gate columns, cols = batch) with gate rows
-//    interleaved (4*unit + gate), so each lane ends up holding i,f,g,o of ONE (unit,batch) cell in
-//    its 4 accumulator registers: the cell update is lane-local and c_t never leaves registers.
-//  * h_t (16 x H per batch group) is exchanged between the workgroups of a (direction, batch
-//    group) once per step through a small L2-resident buffer: write-through (sc1) stores, one
-//    sc1 flag per workgroup, sc1 polls and sc1 loads on the consumer side -- the placement-
-//    independent hand-off protocol for gfx950's non-coherent per-XCD L2s.  The exchange buffer is
-//    laid out [k/4][16 rows][4] so producers write and consumers read whole 1 KB lines.
-//  * Forward stages h_{t-1} in LDS (shared by the 4 waves); backward splits K = 4H across the 4
-//    waves, streams dG straight into the MFMA B operand and reduces the 4 partial tiles in LDS.
+//    interleaved (4*unit + gate), so a lane ends up holding i,f,g,o of ONE (unit,batch) cell in its
+//    4 accumulator registers: the cell update is lane-local and c_t never leaves registers.
+//  * Per step the workgroups of a (direction, batch group) exchange h_t (forward) or dG_t
+//    (backward) through a small buffer laid out exactly as the MFMA B-operand image
+//    ([k/4][16 rows][4], 1 KB per 16-k chunk): producers write it with write-through (sc1) stores
+//    and raise one sc1 flag per workgroup; consumers poll the flags with sc1 loads and pull the
+//    image into LDS with LDS-DMA (global_load_lds ... sc1: no VGPRs, L1 bypassed), so the hand-off
+//    is correct for any workgroup->XCD placement (gfx950's per-XCD L2s are not coherent).
+//  * Forward: the 16 x H image is shared by all 8 waves (4 gate-row tiles x 2 K halves).
+//    Backward: K = 4H is split 8 ways; each wave streams its own eighth through a 2-deep ring of
+//    DMA sub-blocks behind counted s_waitcnt vmcnt(N); the 8 partial tiles are summed through LDS.
+//  * The hand-off store and flag go out BEFORE the bulk stores (y / gates / dgx) of the step.
 //  * Every spin is bounded by a wall-clock timeout that raises a status word (sk_lstm_status).
-//  * mode 2 runs the same kernel one step per launch (state through the workspace) and is the
+//  * mode 2 runs the same kernel one step per launch (state through the workspace); it is the
 //    fallback when the grid cannot be co-resident (more workgroups than CUs).
 #include "sk_common.h"
 
@@ -30,9 +34,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
+constexpr int NTHREADS = 512;
 
 #define SK_RLX __ATOMIC_RELAXED
 #define SK_AGENT __HIP_MEMORY_SCOPE_AGENT
+#define SK_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define SK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 struct WsLayout {
   size_t ctrl, flags, xbuf, state, total;
@@ -41,7 +48,7 @@ struct WsLayout {
 
 inline int pick_ks(int H) {
   const int need = (H + 15) / 16;
-  const int opts[4] = {19, 38, 56, 64};
+  const int opts[4] = {20, 38, 56, 64};
   for (int i = 0; i < 4; ++i)
     if (opts[i] >= need) return opts[i];
   return 0;
@@ -101,64 +108,76 @@ struct BwdArgs {
 // Wave 0 waits until every flag of its (direction, batch group) has reached `target`.
 __device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigned target, unsigned* ctrl, int lane) {
   const long long t0 = wall_clock64();
-  for (;;) {
+  for (unsigned it = 0;; ++it) {
     bool ok = true;
     for (int i = lane; i < n; i += 64) ok = ok && (__hip_atomic_load(flags + i, SK_RLX, SK_AGENT) >= target);
     if (__all(ok)) return true;
-    if (__hip_atomic_load(ctrl, SK_RLX, SK_AGENT) != 0u) return false;  // another workgroup gave up
-    if (wall_clock64() - t0 > SPIN_TICKS) {
-      if (lane == 0) __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
-      return false;
+    if ((it & 63u) == 63u) {
+      if (__hip_atomic_load(ctrl, SK_RLX, SK_AGENT) != 0u) return false;  // another workgroup gave up
+      if (wall_clock64() - t0 > SPIN_TICKS) {
+        if (lane == 0) __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
+        return false;
+      }
     }
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(1);
   }
 }
 
-__device__ __forceinline__ f32x4 ld16_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16 /* sc1 */));
+// One 1 KB piece (one MFMA chunk's B-operand image) global -> LDS, write-through-coherent (sc1).
+__device__ __forceinline__ void dma_piece(const float* gsrc_piece, float* lds_piece, int lane) {
+  __builtin_amdgcn_global_load_lds(SK_GLOBAL_PTR(gsrc_piece + lane * 4), SK_LDS_PTR(lds_piece), 16, 0, 16 /* sc1 */);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // ------------------------------------------------------------------------------------ forward
+// Waves: w = mt + 4*kh; mt = gate-row tile (4 units x 4 gates), kh = K half.  Cells live in the
+// kh == 0 waves: lane (u = lane>>4, b = lane&15) of wave mt <-> unit 4*mt+u, batch row b.
 template <int KS>
-__global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
-  constexpr int HP = 16 * KS, LDH = HP + 4;
-  __shared__ __attribute__((aligned(16))) float hs[16 * LDH + 4];
-  int* s_abort = reinterpret_cast<int*>(&hs[16 * LDH]);
+__global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
+  constexpr int HP = 16 * KS, NQ = KS / 2;
+  __shared__ __attribute__((aligned(16))) float hs[16 * HP];  // B-operand image of h_{s-1}: [k/4][16 rows][4]
+  __shared__ __attribute__((aligned(16))) float red[4][64][4];
+  __shared__ int s_abort;
 
   const int ug = blockIdx.x, bg = blockIdx.y, dir = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int mt = w & 3, kh = w >> 2;
   const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;
 
   // ---- W_hh slice -> registers.  MFMA A operand: lane l supplies A[i = l&15][k = l>>4];
-  //      row i = 4*unit_local + gate, k of (chunk s, r) = 16 s + 4 (l>>4) + r.
-  float wreg[4 * KS];
+  //      row i = 4*unit_local + gate; k of (chunk q, r) = 16 (kh*NQ + q) + 4 (l>>4) + r.
+  float wreg[4 * NQ];
   {
     const int i = lane & 15, kq = lane >> 4;
-    const int unit_i = ug * 16 + 4 * w + (i >> 2), g_i = i & 3;
+    const int unit_i = ug * 16 + 4 * mt + (i >> 2), g_i = i & 3;
     const bool rowok = unit_i < H;
     const float* wrow = a.whh + ((size_t)dir * 4 * H + (size_t)g_i * H + unit_i) * H;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = 16 * s + 4 * kq;
+    for (int q = 0; q < NQ; ++q) {
+      const int k = 16 * (kh * NQ + q) + 4 * kq;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (rowok && k < H) v = *reinterpret_cast<const float4*>(wrow + k);
-      wreg[4 * s + 0] = v.x;
-      wreg[4 * s + 1] = v.y;
-      wreg[4 * s + 2] = v.z;
-      wreg[4 * s + 3] = v.w;
+      wreg[4 * q + 0] = v.x;
+      wreg[4 * q + 1] = v.y;
+      wreg[4 * q + 2] = v.z;
+      wreg[4 * q + 3] = v.w;
     }
   }
 
-  // ---- this lane's cell: unit (lane>>4 within the wave), batch row (lane&15)
   const int u_l = lane >> 4, bl = lane & 15;
-  const int unit = ug * 16 + 4 * w + u_l, b = bg * 16 + bl;
-  const bool cellok = unit < H && b < B;
+  const int unit = ug * 16 + 4 * mt + u_l, b = bg * 16 + bl;
+  const bool owner = kh == 0;                      // this wave carries cells
+  const bool cellok = owner && unit < H && b < B;
   const int len_b = (b < B) ? a.lens[b] : 0;
   const size_t xblk = (size_t)16 * HP;  // floats per (parity, dir, batch group) exchange block
   float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
   float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
-  const int xoff = ((ug * 4 + w) * 16 + bl) * 4 + u_l;
-  float* const st_c = a.state + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + (ug * 16 + 4 * w + u_l);
+  const int xoff = ((ug * 4 + mt) * 16 + bl) * 4 + u_l;  // image position of (k = unit, row = bl)
+  float* const st_c = a.state + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + (ug * 16 + 4 * mt + u_l);
   unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
 
   float c_reg = 0.f, h_reg = 0.f;
@@ -171,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
       h_reg = __hip_atomic_load(((a.s_begin - 1) & 1 ? xb1 : xb0) + xoff, SK_RLX, SK_AGENT);
     }
   }
-  if (tid == 0) *s_abort = 0;
+  if (tid == 0) s_abort = 0;
   __syncthreads();
 
   for (int s = a.s_begin; s < a.s_end; ++s) {
@@ -185,73 +204,84 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
     }
     // 2. wait for h_{s-1} of every unit group of this (direction, batch group)
     if (s > a.s_begin && w == 0) {
-      if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) *s_abort = 1;
+      if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
     }
     __syncthreads();
-    if (*s_abort) break;
-    // 3. stage h_{s-1} (16 rows x HP) in LDS as [row][k]
+    if (s_abort) break;
+    // 3. h_{s-1} image (16 rows x HP) -> LDS
     if (s == 0) {
-      for (int i = tid; i < 16 * (HP / 4); i += 256) {
-        const int bb = i / (HP / 4), k4 = (i - bb * (HP / 4)) * 4;
+      for (int i = tid; i < 16 * (HP / 4); i += NTHREADS) {
+        const int bb = i & 15, c = i >> 4;  // row, k/4
         const int brow = bg * 16 + bb;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (brow < B && k4 < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)dir * B + brow) * H + k4);
-        *reinterpret_cast<float4*>(&hs[bb * LDH + k4]) = v;
+        if (brow < B && 4 * c < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)dir * B + brow) * H + 4 * c);
+        *reinterpret_cast<float4*>(&hs[(c * 16 + bb) * 4]) = v;
       }
     } else {
       const float* src = ((s - 1) & 1) ? xb1 : xb0;
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(xblk * 4), 0x00020000);
-      for (int i = tid; i < 4 * HP; i += 256) {  // float4 index: (k/4, row)
-        const int c = i >> 4, bb = i & 15;
-        const f32x4 v = ld16_sc1(rs, (unsigned)i * 16u);
-        *reinterpret_cast<f32x4*>(&hs[bb * LDH + 4 * c]) = v;
-      }
+      for (int p = w; p < KS; p += 8) dma_piece(src + p * 256, hs + p * 256, lane);
+      wait_vmcnt<0>();
     }
     __syncthreads();
-    // 4. gates^T (64 gate rows x 16 batch) += W_slice (64 x HP) * h^T (HP x 16); this wave: 16 rows
+    // 4. gates^T (64 gate rows x 16 batch) = W_slice (64 x HP) * h^T (HP x 16); this wave: 16 rows, half of K
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     {
-      const float* hrow = &hs[(lane & 15) * LDH + 4 * (lane >> 4)];
+      const float* hp = &hs[(kh * NQ) * 256 + lane * 4];
 #pragma unroll
-      for (int q = 0; q < KS; ++q) {
-        const float4 hb = *reinterpret_cast<const float4*>(hrow + 16 * q);
+      for (int q = 0; q < NQ; ++q) {
+        const float4 hb = *reinterpret_cast<const float4*>(hp + q * 256);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], hb.x, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], hb.y, acc1, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], hb.z, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], hb.w, acc1, 0, 0, 0);
       }
     }
-    // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
-    const float gi = sk_sigmoid(acc0[0] + acc1[0] + gxv[0]);
-    const float gf = sk_sigmoid(acc0[1] + acc1[1] + gxv[1]);
-    const float gg = tanhf(acc0[2] + acc1[2] + gxv[2]);
-    const float go = sk_sigmoid(acc0[3] + acc1[3] + gxv[3]);
-    const float c_new = gf * c_reg + gi * gg;
-    const float h_new = go * tanhf(c_new);
-    const bool valid = cellok && t < len_b;
-    if (valid) {
-      c_reg = c_new;
-      h_reg = h_new;
-    }
-    if (cellok) {
-      a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = valid ? h_new : 0.f;
-      if (a.gates && valid) {
-        float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
-        gp[0] = gi;
-        gp[(size_t)H] = gf;
-        gp[(size_t)2 * H] = gg;
-        gp[(size_t)3 * H] = go;
-        a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit] = c_new;
+    f32x4 acc = acc0 + acc1;
+    if (!owner) *reinterpret_cast<f32x4*>(&red[mt][lane][0]) = acc;
+    __syncthreads();
+    if (owner) {
+      acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
+      // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
+      const float gi = sk_sigmoid(acc[0] + gxv[0]);
+      const float gf = sk_sigmoid(acc[1] + gxv[1]);
+      const float gg = tanhf(acc[2] + gxv[2]);
+      const float go = sk_sigmoid(acc[3] + gxv[3]);
+      const float c_new = gf * c_reg + gi * gg;
+      const float h_new = go * tanhf(c_new);
+      const bool valid = cellok && t < len_b;
+      if (valid) {
+        c_reg = c_new;
+        h_reg = h_new;
       }
+      // 6. publish h_s first (write-through) ...
+      __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
+      wait_vmcnt<0>();
+      // (stash what the bulk stores below need; they are issued after the flag)
+      acc[0] = gi;
+      acc[1] = gf;
+      acc[2] = gg;
+      acc[3] = go;
+      gxv[0] = valid ? h_new : 0.f;
+      gxv[1] = c_new;
+      gxv[2] = valid ? 1.f : 0.f;
     }
-    // 6. publish h_s (write-through), then one flag per workgroup
-    __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+    // 7. ... then the bulk stores of the step, off the critical path
+    if (cellok) {
+      a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = gxv[0];
+      if (a.gates && gxv[2] != 0.f) {
+        float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+        gp[0] = acc[0];
+        gp[(size_t)H] = acc[1];
+        gp[(size_t)2 * H] = acc[2];
+        gp[(size_t)3 * H] = acc[3];
+        a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit] = gxv[1];
+      }
+    }
   }
 
-  if (!*s_abort && cellok) {
+  if (!s_abort && cellok) {
     if (a.s_end == T) {
       if (a.hn) a.hn[((size_t)dir * B + b) * H + unit] = h_reg;
       if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = c_reg;
@@ -264,65 +294,118 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_kernel(FwdArgs a) {
 // ------------------------------------------------------------------------------------ backward
 // dh_{prev}[b][u] = sum_{k'} dG[b][k'] W_hh[row(k')][u],  k' = 4*unit_k + gate (gate-interleaved).
 // Transposed MFMA: D[m = out unit][n = batch] = sum_k' A[m][k'] B[k'][n]; wave w takes the k' chunks
-// [w*KS, (w+1)*KS) (a quarter of the units), partial tiles are summed through LDS.
+// [w*NQ, (w+1)*NQ) (an eighth of K = 4H), streamed through its own 2-deep ring of DMA sub-blocks;
+// the 8 partial tiles are summed through LDS.
 template <int KS>
-__device__ __forceinline__ float bwd_matmul(const float (&wreg)[4 * KS], const float* xsrc, size_t xblk_bytes,
-                                            float (*red)[16][17], int w, int lane) {
-  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xsrc), 0, (int)xblk_bytes, 0x00020000);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  const unsigned lane_off = (unsigned)(((lane >> 4) * 16 + (lane & 15)) * 16);
+struct BwdCfg {
+  static constexpr int NQ = KS / 2;                       // 1 KB chunks per wave
+  static constexpr int NSB = 4;                           // sub-blocks per step
+  static constexpr int SB = (NQ + NSB - 1) / NSB;         // chunks per sub-block (last may be short)
+  static constexpr int cnt(int sb) { return (sb * SB >= NQ) ? 0 : ((sb + 1) * SB <= NQ ? SB : NQ - sb * SB); }
+};
+
+template <int KS, int SBI>
+__device__ __forceinline__ void bwd_issue(const float* xsrc, float* ring, int w, int lane) {
+  using C = BwdCfg<KS>;
+  constexpr int n = C::cnt(SBI);
+  float* dst = ring + (SBI & 1) * C::SB * 256;
 #pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    const unsigned cc = (unsigned)(w * KS + q);
-    const f32x4 db = ld16_sc1(rs, cc * 1024u + lane_off);  // dG[b = lane&15][k' = 16 cc + 4 (lane>>4) + 0..3]
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], db[0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], db[1], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], db[2], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], db[3], acc1, 0, 0, 0);
+  for (int j = 0; j < n; ++j) dma_piece(xsrc + (size_t)(w * C::NQ + SBI * C::SB + j) * 256, dst + j * 256, lane);
+}
+
+template <int KS, int SBI>
+__device__ __forceinline__ void bwd_consume(const float (&wreg)[4 * (KS / 2)], const float* ring, int lane, f32x4& acc0,
+                                            f32x4& acc1) {
+  using C = BwdCfg<KS>;
+  constexpr int n = C::cnt(SBI);
+  const float* src = ring + (SBI & 1) * C::SB * 256 + lane * 4;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    const int q = SBI * C::SB + j;
+    const float4 db = *reinterpret_cast<const float4*>(src + j * 256);  // dG[b = lane&15][k' = 16 cc + 4 (lane>>4) + 0..3]
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], db.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], db.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], db.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], db.w, acc1, 0, 0, 0);
   }
+}
+
+// Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
+template <int KS>
+__device__ __forceinline__ float bwd_matmul(const float (&wreg)[4 * (KS / 2)], const float* xsrc, float* ring,
+                                            float (*red)[16][17], int w, int lane) {
+  using C = BwdCfg<KS>;
+  static_assert(C::NSB == 4, "the sub-block schedule below is written for 4 sub-blocks");
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  // The counted waits below assume the DMAs are the YOUNGEST vector-memory operations of this wave:
+  // nothing may be scheduled into this region (the cell loads of the step were issued before it).
+  __builtin_amdgcn_sched_barrier(0);
+  bwd_issue<KS, 0>(xsrc, ring, w, lane);
+  bwd_issue<KS, 1>(xsrc, ring, w, lane);
+  wait_vmcnt<C::cnt(1)>();  // sub-block 0 landed (the newer C::cnt(1) DMAs may still be in flight)
+  bwd_consume<KS, 0>(wreg, ring, lane, acc0, acc1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of ring buffer 0 returned before it is refilled
+  __builtin_amdgcn_sched_barrier(0);
+  bwd_issue<KS, 2>(xsrc, ring, w, lane);
+  wait_vmcnt<C::cnt(2)>();  // sub-block 1 landed
+  bwd_consume<KS, 1>(wreg, ring, lane, acc0, acc1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  bwd_issue<KS, 3>(xsrc, ring, w, lane);
+  wait_vmcnt<C::cnt(3)>();  // sub-block 2 landed
+  bwd_consume<KS, 2>(wreg, ring, lane, acc0, acc1);
+  wait_vmcnt<0>();
+  bwd_consume<KS, 3>(wreg, ring, lane, acc0, acc1);
+  __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[w][4 * (lane >> 4) + r][lane & 15] = acc0[r] + acc1[r];
   __syncthreads();
-  const int m = 4 * w + (lane >> 4), n = lane & 15;  // this lane's own cell
-  const float v = (red[0][m][n] + red[1][m][n]) + (red[2][m][n] + red[3][m][n]);
+  const int m = 4 * (w & 3) + (lane >> 4), n = lane & 15;  // the cell of this lane (owner waves: w < 4)
+  float v = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v += red[k][m][n];
   __syncthreads();
   return v;
 }
 
 template <int KS>
-__global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
-  constexpr int HP = 16 * KS;
-  __shared__ float red[4][16][17];
+__global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
+  using C = BwdCfg<KS>;
+  constexpr int HP = 16 * KS, NQ = C::NQ;
+  __shared__ __attribute__((aligned(16))) float ring_all[8][2 * C::SB * 256];
+  __shared__ float red[8][16][17];
   __shared__ int s_abort;
 
   const int ug = blockIdx.x, bg = blockIdx.y, dir = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;
+  float* const ring = &ring_all[w][0];
 
   // ---- W_hh^T slice -> registers: A[m = out unit i][k'] = W_hh[gate r * H + unit_k][ug*16 + i]
-  float wreg[4 * KS];
+  float wreg[4 * NQ];
   {
     const int i = lane & 15, kq = lane >> 4;
     const int uout = ug * 16 + i;
     const float* wbase = a.whh + (size_t)dir * 4 * H * H + uout;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int unit_k = 4 * (w * KS + s) + kq;
+    for (int s = 0; s < NQ; ++s) {
+      const int unit_k = 4 * (w * NQ + s) + kq;
       const bool ok = uout < H && unit_k < H;
 #pragma unroll
       for (int r = 0; r < 4; ++r) wreg[4 * s + r] = ok ? wbase[((size_t)r * H + unit_k) * H] : 0.f;
     }
   }
 
-  const int u_l = lane >> 4, bl = lane & 15;
-  const int unit = ug * 16 + 4 * w + u_l, b = bg * 16 + bl;
-  const bool cellok = unit < H && b < B;
+  const int mt = w & 3, u_l = lane >> 4, bl = lane & 15;
+  const int unit = ug * 16 + 4 * mt + u_l, b = bg * 16 + bl;
+  const bool owner = w < 4;
+  const bool cellok = owner && unit < H && b < B;
   const int len_b = (b < B) ? a.lens[b] : 0;
   const size_t xblk = (size_t)HP * 64;  // floats per (parity, dir, batch group) exchange block
   float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
   float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
-  const size_t xoff = ((size_t)unit * 16 + bl) * 4;
+  const size_t xoff = ((size_t)unit * 16 + bl) * 4;  // image position of k' = 4*unit + 0..3, row bl
   const size_t soff = ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit;
   float* const st_dh = a.state + soff;
   float* const st_dc = a.state + (size_t)2 * NBG * 16 * HP + soff;
@@ -330,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
 
   // carry = gradient wrt h that passes straight through a frozen (padded) step
   float carry = 0.f, dc_rec = 0.f, dh_rec = 0.f;
-  if (a.s_begin > 0) {
+  if (a.s_begin > 0 && owner) {
     carry = *st_dh;
     dc_rec = *st_dc;
   }
@@ -361,11 +444,11 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       }
       __syncthreads();
       if (s_abort) break;
-      dh_rec = bwd_matmul<KS>(wreg, ((s - 1) & 1) ? xb1 : xb0, xblk * 4, red, w, lane) + carry;
+      dh_rec = bwd_matmul<KS>(wreg, ((s - 1) & 1) ? xb1 : xb0, ring, red, w, lane) + carry;
     } else {
       dh_rec = 0.f;
     }
-    // 3. cell backward
+    // 3. cell backward (owner waves)
     f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
       const float dh = dyv + dh_rec;
@@ -381,6 +464,16 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     } else {
       carry = dh_rec;  // frozen step: h_t = h_{t-1}
     }
+    // 4. publish dG_s first, in gate-interleaved order: 16 B per cell, 1 KB contiguous per wave ...
+    if (owner) {
+      float* xdst = (s & 1) ? xb1 : xb0;
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
+      wait_vmcnt<0>();
+    }
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+    // 5. ... then the bulk store of the step (dgx, zero at padded positions)
     if (cellok) {
       float* dp = a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
       dp[0] = dpre[0];
@@ -388,15 +481,6 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
       dp[(size_t)2 * H] = dpre[2];
       dp[(size_t)3 * H] = dpre[3];
     }
-    // 4. publish dG_s in gate-interleaved order: 16 B per cell, 1 KB contiguous per wave
-    {
-      float* xdst = (s & 1) ? xb1 : xb0;
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
   }
 
   if (s_abort) return;
@@ -407,12 +491,12 @@ __global__ __launch_bounds__(256, 1) void lstm_bwd_kernel(BwdArgs a) {
     }
     __syncthreads();
     if (s_abort) return;
-    dh_rec = bwd_matmul<KS>(wreg, ((T - 1) & 1) ? xb1 : xb0, xblk * 4, red, w, lane) + carry;
+    dh_rec = bwd_matmul<KS>(wreg, ((T - 1) & 1) ? xb1 : xb0, ring, red, w, lane) + carry;
     if (cellok) {
       if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
       if (a.dc0) a.dc0[((size_t)dir * B + b) * H + unit] = dc_rec;
     }
-  } else {
+  } else if (owner) {
     *st_dh = carry;
     *st_dc = dc_rec;
   }
@@ -441,18 +525,18 @@ __global__ __launch_bounds__(256) void hprev_kernel(const float* __restrict__ y,
 
 template <int KS>
 int launch_fwd(const FwdArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_fwd_kernel<KS>, grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(lstm_fwd_kernel<KS>, grid, dim3(NTHREADS), 0, st, a);
   return 0;
 }
 template <int KS>
 int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_bwd_kernel<KS>, grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL(lstm_bwd_kernel<KS>, grid, dim3(NTHREADS), 0, st, a);
   return 0;
 }
 
 int dispatch_fwd(int KS, const FwdArgs& a, dim3 grid, hipStream_t st) {
   switch (KS) {
-    case 19: return launch_fwd<19>(a, grid, st);
+    case 20: return launch_fwd<20>(a, grid, st);
     case 38: return launch_fwd<38>(a, grid, st);
     case 56: return launch_fwd<56>(a, grid, st);
     default: return launch_fwd<64>(a, grid, st);
@@ -460,7 +544,7 @@ int dispatch_fwd(int KS, const FwdArgs& a, dim3 grid, hipStream_t st) {
 }
 int dispatch_bwd(int KS, const BwdArgs& a, dim3 grid, hipStream_t st) {
   switch (KS) {
-    case 19: return launch_bwd<19>(a, grid, st);
+    case 20: return launch_bwd<20>(a, grid, st);
     case 38: return launch_bwd<38>(a, grid, st);
     case 56: return launch_bwd<56>(a, grid, st);
     default: return launch_bwd<64>(a, grid, st);
