@@ -45,6 +45,7 @@ except ImportError:  # the frozen copy exp/<...>/arch.py is imported from anothe
             sys.path.insert(0, os.path.abspath(cand))
             break
     import sepkern  # noqa: F401
+from sepkern import dist as skdist
 from sepkern import ops
 from sepkern.engine import Engine
 from sepkern._lib import SepkernError
@@ -257,9 +258,7 @@ class SepDNN(nn.Module):
     return eng.flat, eng.grad
 
   def _allreduce_grads(self):
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-      dist.all_reduce(self._engine.grad)            # one RCCL collective over the whole gradient
+    skdist.allreduce_grads(self._engine.grad)       # one RCCL collective over the whole gradient
 
   def init_hidden(self, batch_size):
     """h0, c0 ~ N(0,1), shape (2L, B, H), fresh for every batch (reference archs/uPIT.py:121-127)."""
@@ -314,12 +313,9 @@ def compute_loss_padded(model, mix, sources, lens, plotdir=""):
   model.zero_grad()
   model.hidden = model.init_hidden(batch)
 
-  norm_override = 0.0
-  import torch.distributed as dist
-  if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-    gn = (lens.sum().float() * model.feat_dim).reshape(1)
-    dist.all_reduce(gn)
-    norm_override = float(gn.item())
+  # data-parallel: divide by the GLOBAL frame count so that the summed gradients equal the
+  # single-device gradient of the global batch (0.0 = single process, kernel uses sum(lens)*F)
+  norm_override = skdist.global_norm(int(lens.sum().item()), model.feat_dim, mix.device) if skdist.is_parallel() else 0.0
 
   mask_out = model.forward_padded(mix, lens)
   # mask_out: tensor of shape (seq_length, batch, feat_dim*num_spk)

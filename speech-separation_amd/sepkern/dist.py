@@ -1,0 +1,68 @@
+"""Utterance-level data parallelism: one process per GPU, torch.distributed over RCCL ("nccl").
+
+The reference is single-GPU (steps/qsub_train.sh:5 `-l gpu=1`); this is new functionality whose
+contract is "same update as one device seeing the global batch" for everything except BatchNorm,
+whose batch statistics stay per-rank (as torch's DistributedDataParallel does by default):
+  * utterances are sharded by index across ranks (no data-path collective),
+  * the PIT loss of every rank is divided by the GLOBAL norm sum(len)*F (one scalar all-reduce,
+    known before the forward pass because it depends on lengths only),
+  * the flat fp32 gradient buffer is summed with ONE all-reduce per step, after which every rank
+    runs the identical clip + Adam update.
+These helpers are backend-agnostic so the N>1 path is covered by world_size-2 gloo tests on CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def is_parallel():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world():
+    return dist.get_world_size() if is_parallel() else 1
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def init_from_env(backend=None):
+    """Initialise the process group from torchrun's environment (RANK / WORLD_SIZE / MASTER_*).
+    Returns (rank, world, local_rank).  No-op for a single process."""
+    w = int(os.environ.get("WORLD_SIZE", "1"))
+    r = int(os.environ.get("RANK", "0"))
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    if w > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or os.environ.get("SEPKERN_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(lr)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+        else:
+            dist.init_process_group(backend)
+    return r, w, lr
+
+
+def shard_indices(n, rank_, world_):
+    """Utterance indices of this rank: a strided shard, every index exactly once over all ranks."""
+    return list(range(rank_, n, world_))
+
+
+def global_norm(local_frames, feat_dim, device):
+    """sum over ALL ranks of sum(len_b) * F  (reference archs/uPIT.py:197 on the global batch).
+    Returns a python float; 0.0 means "not parallel: let the kernel use its local norm"."""
+    if not is_parallel():
+        return 0.0
+    t = torch.tensor([float(local_frames) * feat_dim], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return float(t.item())
+
+
+def allreduce_grads(flat_grad):
+    """Sum the flat gradient buffer over ranks in place (one collective over xGMI)."""
+    if is_parallel():
+        dist.all_reduce(flat_grad)
+    return flat_grad

@@ -1,0 +1,123 @@
+"""The N>1 path on CPU: world_size-2 gloo run of the data-parallel helpers (sepkern.dist) that the
+arch module uses on the GPU (global-norm all-reduce before the forward, one all-reduce of the flat
+gradient after the backward, strided utterance sharding).  The per-rank compute here is the CPU
+oracle; BatchNorm is put in eval mode because its batch statistics are per-rank by design
+(DESIGN.md), so the summed shard gradients must equal the single-process global-batch gradient."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _samples(n):
+    rng = np.random.default_rng(5)
+    out = []
+    for i in range(n):
+        T = int(rng.integers(4, 9))
+        d = {"mix": np.abs(rng.standard_normal((T, 33))).astype(np.float32)}
+        for s in range(2):
+            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((T, 33))).astype(np.float32)
+        out.append(d)
+    return out
+
+
+def _model():
+    from oracle import upit as OU
+    torch.manual_seed(11)
+    m = OU.OracleSepDNN(feat_dim=33, num_spk=2, hidden_dim=12, num_layers=2)
+    with torch.no_grad():
+        m.bn.running_mean.normal_(0, 0.1)
+        m.bn.running_var.uniform_(0.5, 1.5)
+    m.train()
+    m.bn.eval()
+    return m
+
+
+def _loss_sum(m, samples, hidden, norm):
+    """sum_b min_p L / S / norm for the given samples (oracle)."""
+    from oracle import upit as OU
+    loss, local_norm, _ = OU.compute_loss(m, OU.collate(samples), hidden)
+    return loss * local_norm / norm
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SEPKERN_DIST_BACKEND="gloo")
+    torch.set_num_threads(1)
+    from sepkern import dist as skdist
+    from oracle import upit as OU
+    r, w, _ = skdist.init_from_env()
+    assert (r, w) == (rank, world) and skdist.is_parallel() and skdist.world() == world
+    samples = _samples(6)
+    mine = [samples[i] for i in skdist.shard_indices(len(samples), rank, world)]
+    m = _model()
+    torch.manual_seed(100)
+    h_all = (torch.randn(4, 6, 12), torch.randn(4, 6, 12))
+    order_all = OU.collate_order([len(d["mix"]) for d in samples])
+    # hidden rows of my utterances, in my collated order
+    my_ids = skdist.shard_indices(len(samples), rank, world)
+    my_order = OU.collate_order([len(samples[i]["mix"]) for i in my_ids])
+    pos = {int(u): k for k, u in enumerate(order_all)}
+    rows = [pos[my_ids[j]] for j in my_order]
+    hidden = (h_all[0][:, rows].contiguous(), h_all[1][:, rows].contiguous())
+    frames = sum(len(d["mix"]) for d in mine)
+    gnorm = skdist.global_norm(frames, 33, torch.device("cpu"))
+    loss = _loss_sum(m, mine, hidden, gnorm)
+    m.zero_grad()
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    skdist.allreduce_grads(flat)
+    tot = torch.tensor([float(loss)], dtype=torch.float64)
+    dist.all_reduce(tot)
+    q.put((rank, gnorm, float(tot), flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_dp_equals_single_process_global_batch():
+    sys.path.insert(0, PKG)
+    from oracle import upit as OU
+    from sepkern import dist as skdist
+    assert sorted(skdist.shard_indices(7, 0, 2) + skdist.shard_indices(7, 1, 2)) == list(range(7))
+    assert skdist.global_norm(10, 33, torch.device("cpu")) == 0.0 and not skdist.is_parallel()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single process, global batch
+    samples = _samples(6)
+    m = _model()
+    torch.manual_seed(100)
+    h_all = (torch.randn(4, 6, 12), torch.randn(4, 6, 12))
+    loss, norm, _ = OU.compute_loss(m, OU.collate(samples), h_all)
+    m.zero_grad()
+    loss.backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).numpy()
+    for rank, gnorm, tot, flat in res:
+        assert gnorm == float(norm)
+        np.testing.assert_allclose(tot, float(loss), rtol=1e-5)
+        np.testing.assert_allclose(flat, ref, rtol=2e-4, atol=1e-7)
+    np.testing.assert_array_equal(res[0][3], res[1][3])          # every rank holds the identical summed gradient

@@ -1,0 +1,93 @@
+"""The recipe's data path end to end on the GPU, through the step programs that mirror the
+reference's steps/*.py CLIs: synthetic wav tree -> extract_feats (train + test) -> train_qsub ->
+eval_qsub on the frozen arch copy -> reconstruct_sources.  Every file format of SURVEY.md Appendix A
+is checked, numerics against the CPU oracle (BASELINE config 1: 8 synthetic utterances)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.io.wavfile
+import torch
+
+from conftest import PKG
+from oracle import stft as OS
+
+pytestmark = pytest.mark.gpu
+STEPS = os.path.join(PKG, "steps")
+
+
+def run(*cmd, cwd=None):
+    env = dict(os.environ, SEPKERN_HOME=PKG, PYTHONPATH=PKG + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable] + list(cmd), cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "%s failed:\n%s\n%s" % (cmd[0], r.stdout[-2000:], r.stderr[-3000:])
+    return r.stdout
+
+
+def test_recipe_steps_end_to_end(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    from sepkern import synth
+    root = str(tmp_path)
+    wavroot, data = os.path.join(root, "wav8k"), os.path.join(root, "data", "syn")
+    ids = synth.write_wav_tree(wavroot, 8, num_spk=2, min_s=1.0, max_s=2.0, id_list=os.path.join(root, "id_lists", "syn.txt"))
+    synth.write_data_dir(data, wavroot, ids)
+    assert open(os.path.join(data, "wav.scp")).readline().split(' ')[1].startswith(wavroot + "/mix/")
+
+    # ---- stage 1: features (train = magnitudes of mix+sources, test = complex mix)
+    ftrain, ftest = os.path.join(root, "feats", "syn_train"), os.path.join(root, "feats", "syn_test")
+    run(os.path.join(STEPS, "extract_feats.py"), data, "train", ftrain)
+    lines = open(os.path.join(data, "feats_train.scp")).read().splitlines()
+    assert [l.split(' ')[0] for l in lines] == ids and all(l.endswith(".npz") for l in lines)
+    assert open(os.path.join(data, "utt2num_spk")).read().splitlines() == ["%s 2" % i for i in ids]
+    for i in ids[:3]:
+        z = np.load(os.path.join(ftrain, i + ".npz"))
+        assert z.files == ["mix", "s1", "s2"]
+        for key, sub in (("mix", "mix"), ("s1", "s1"), ("s2", "s2")):
+            _, pcm = scipy.io.wavfile.read(os.path.join(wavroot, sub, i + ".wav"))
+            ref = OS.stft_mag(OS.pcm16_to_float(pcm))
+            assert z[key].dtype == np.float32 and z[key].shape == ref.shape == (257, 1 + len(pcm) // 128)
+            np.testing.assert_allclose(z[key], ref, atol=1e-5 * ref.max())
+    run(os.path.join(STEPS, "extract_feats.py"), data, "test", ftest)
+    z = np.load(os.path.join(ftest, ids[0] + ".npz"))
+    _, pcm = scipy.io.wavfile.read(os.path.join(wavroot, "mix", ids[0] + ".wav"))
+    assert z.files == ["mix"] and z["mix"].dtype == np.complex64
+    np.testing.assert_allclose(z["mix"], OS.stft(OS.pcm16_to_float(pcm)), atol=1e-5 * np.abs(z["mix"]).max())
+
+    # ---- stage 2: training (2x64 via the conf-file mechanism, strings as in steps/train_qsub.py:87-91)
+    exp = os.path.join(root, "exp", "uPIT_syn")
+    os.makedirs(os.path.join(exp, "train_stats"), exist_ok=True)
+    shutil.copy(os.path.join(PKG, "archs", "uPIT.py"), os.path.join(exp, "arch.py"))     # run_train.sh:56
+    with open(os.path.join(exp, "conf"), "w") as f:
+        f.write("hidden_dim=64\nnum_layers=2\n")
+    out = run(os.path.join(STEPS, "train_qsub.py"), "uPIT", "0", data, exp, "--model-config", os.path.join(exp, "conf"),
+              "--batch-size", "4", "--num-epochs", "5", "--seed", "1", "--cv-data-dir", data)
+    assert "For epoch: 005 loss is:" in out and "cv set loss is" in out
+    for f in ("intermediate_models/init.mdl", "intermediate_models/005.mdl", "final.mdl"):
+        assert os.path.isfile(os.path.join(exp, f))
+    tl = [l.split() for l in open(os.path.join(exp, "train_stats", "train_loss.txt")).read().splitlines()]
+    assert [l[0] for l in tl] == ["001", "002", "003", "004", "005"]
+    losses = [float(l[1]) for l in tl]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert open(os.path.join(exp, "train_stats", "cv_loss.txt")).read().split()[0] == "005"
+    sd = torch.load(os.path.join(exp, "final.mdl"), map_location="cpu")
+    assert list(sd.keys())[0] == "blstm.weight_ih_l0" and sd["blstm.weight_hh_l1_reverse"].shape == (256, 64)
+
+    # ---- stage 3: masks from the FROZEN arch copy, then reconstruction
+    mdir = os.path.join(exp, "masks")
+    run(os.path.join(STEPS, "eval_qsub.py"), os.path.join(exp, "arch.py"), "0", os.path.join(exp, "final.mdl"), data, mdir,
+        "--model-config", os.path.join(exp, "conf"), "--batch-size", "3", "--seed", "2")
+    run(os.path.join(STEPS, "reconstruct_sources.py"), data, exp)
+    for i in ids:
+        mz = np.load(os.path.join(mdir, i + ".npz"))
+        spec = np.load(os.path.join(ftest, i + ".npz"))["mix"]
+        assert mz.files == ["s1", "s2"]
+        for k in mz.files:
+            assert mz[k].shape == spec.shape and mz[k].dtype == np.float32 and 0 <= mz[k].min() and mz[k].max() <= 1
+            fs, got = scipy.io.wavfile.read(os.path.join(exp, "wav", k, i + ".wav"))
+            _, ref = OS.reconstruct(spec, mz[k])
+            assert fs == 8000 and got.dtype == np.int16 and got.shape == ref.shape == (128 * (spec.shape[1] - 1),)
+            d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 5e-3
