@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel stats + separate FETCH_SIZE / WRITE_SIZE PMC passes) into
+the text summaries committed next to this script.
+
+    python profiles/summarize.py <tag> <trace_dir> [<fetch_dir> <write_dir>]  > profiles/<tag>_summary.txt
+
+HBM bytes follow MI355X_MICROARCH.md: counters are in KB; on gfx950 FETCH_SIZE reports half the bytes
+of wide coalesced reads, so fetch bytes are shown both raw and x2-corrected; WRITE_SIZE is exact.
+"""
+import collections
+import csv
+import glob
+import sys
+
+
+def find(d, pat):
+    f = glob.glob(d + "/**/*" + pat, recursive=True)
+    return f[0] if f else None
+
+
+def main():
+    tag, trace = sys.argv[1], sys.argv[2]
+    print("# rocprofv3 summary %s" % tag)
+    print("# command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline")
+    rows = list(csv.DictReader(open(find(trace, "kernel_stats.csv"))))
+    print("%-78s %6s %12s %12s %7s" % ("kernel", "calls", "total_ms", "avg_us", "pct"))
+    for r in rows[:24]:
+        print("%-78s %6s %12.3f %12.1f %7s" % (r["Name"][:78], r["Calls"], float(r["TotalDurationNs"]) / 1e6,
+                                                 float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    if len(sys.argv) >= 5:
+        print("\n# PMC passes (separate runs: --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE; bench.py --steps 2 --warmup 1)")
+        for name, d in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+                agg[r["Kernel_Name"][:78]].append(float(r["Counter_Value"]))
+            print("%s per launch (KB%s)" % (name, "; x2 = gfx950 wide-read correction" if name == "FETCH_SIZE" else ""))
+            for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:10]:
+                avg = sum(v) / len(v)
+                extra = "  x2 -> %10.1f MB" % (avg * 2 / 1024) if name == "FETCH_SIZE" else "        %10.1f MB" % (avg / 1024)
+                print("   %-78s n=%4d avg=%12.1f KB%s" % (k, len(v), avg, extra))
+
+
+if __name__ == "__main__":
+    main()
