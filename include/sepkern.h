@@ -75,6 +75,14 @@ int sk_mask_istft(const void* mix_c64, const int64_t* mix_offs, const int64_t* m
 int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                 int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
                 int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, sk_stream_t stream);
+/* Same product with K split into `splitk` slices (for weight gradients: few output tiles, K = T*B rows):
+ * slices write dense partial slabs into ws (>= sk_gemm_workspace_bytes), a second kernel adds them in
+ * fixed slice order and applies bias / accumulate / act -- deterministic, no atomics. */
+size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
+int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                       int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
+                       int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws,
+                       sk_stream_t stream);
 
 /* ---------------------------------------------------------------- BLSTM recurrence
  * One bidirectional LSTM layer's time recurrence (the part of nn.LSTM, reference

@@ -7,13 +7,20 @@
 // rounding-order differences only.
 //
 // Tiling: 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of 32x32
-// (64 accumulator VGPRs); K step 16, LDS double-buffered, operands kept k-major in LDS so the
-// per-lane A/B fragment reads are conflict-free ds_read_b32 of 32 consecutive dwords.
+// (64 accumulator VGPRs); K step 32, LDS double-buffered, operands kept k-major in LDS so the
+// per-lane A/B fragment reads are conflict-free ds_read_b32 of 32 consecutive dwords.  BK = 32 gives
+// every wave 64 MFMAs (4096 cycles) between barriers, enough to cover a loaded HBM round trip with
+// the one-tile-ahead register prefetch.
 #include "sk_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LD = 132;
+constexpr int BM = 128, BN = 128, BK = 32;
+// LDS row stride (floats) of a k-major operand image [BK][LD]: 132 keeps float4 rows 16-byte aligned for
+// operands that are k-major in memory; 129 makes the 4x4 transposing stash of [dim][K] operands
+// conflict-free (bank = 4q + r + row).  Fragment reads (32 consecutive floats) are conflict-free for both.
+constexpr int LD_K = 132, LD_T = 129;
+constexpr int PIECES = BK * BM / 4 / 256;  // float4 pieces per thread per operand tile
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GemmArgs {
@@ -24,6 +31,8 @@ struct GemmArgs {
   int M, N, K, lda, ldb, ldc;
   int accumulate, act, vecA, vecB;
   int tilesN;
+  int splitk, kchunk;  // split-K: blockIdx.y = slice, K range [y*kchunk, min(K,(y+1)*kchunk)), partials to slabs
+  float* slabs;        // (batch, splitk, M, N) dense fp32 partial products when splitk > 1
   int64_t sA, sB, sC, sbias;
 };
 
@@ -35,9 +44,9 @@ struct GemmArgs {
 //  KMAJOR == true : operand stored [K][tile dim]            (already k-major)
 template <bool KMAJOR>
 __device__ __forceinline__ void fetch(const float* __restrict__ P, int ld, int dim0, int dimLimit, int k0, int K,
-                                      bool fast, int tid, float4 (&r)[2]) {
+                                      bool fast, int tid, float4 (&r)[PIECES]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < PIECES; ++i) {
     const int idx = tid + 256 * i;
     int row, col, rowLimit, colLimit;  // element (row, col..col+3) of the stored matrix
     if (KMAJOR) {
@@ -46,8 +55,8 @@ __device__ __forceinline__ void fetch(const float* __restrict__ P, int ld, int d
       rowLimit = K;
       colLimit = dimLimit;
     } else {
-      row = dim0 + (idx >> 2);
-      col = k0 + (idx & 3) * 4;
+      row = dim0 + idx / (BK / 4);
+      col = k0 + (idx % (BK / 4)) * 4;
       rowLimit = dimLimit;
       colLimit = K;
     }
@@ -67,16 +76,16 @@ __device__ __forceinline__ void fetch(const float* __restrict__ P, int ld, int d
   }
 }
 
-template <bool KMAJOR>
-__device__ __forceinline__ void stash(float (*S)[LD], int tid, const float4 (&r)[2]) {
+template <bool KMAJOR, int LD>
+__device__ __forceinline__ void stash(float (*S)[LD], int tid, const float4 (&r)[PIECES]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < PIECES; ++i) {
     const int idx = tid + 256 * i;
     if (KMAJOR) {
       const int kr = idx >> 5, c4 = (idx & 31) * 4;
       *reinterpret_cast<float4*>(&S[kr][c4]) = r[i];
     } else {
-      const int row = idx >> 2, k4 = (idx & 3) * 4;
+      const int row = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
       S[k4 + 0][row] = r[i].x;
       S[k4 + 1][row] = r[i].y;
       S[k4 + 2][row] = r[i].z;
@@ -87,8 +96,9 @@ __device__ __forceinline__ void stash(float (*S)[LD], int tid, const float4 (&r)
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+  constexpr int LDA = TA ? LD_K : LD_T, LDB = TB ? LD_T : LD_K;
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -101,11 +111,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
   const int m0 = (tile / g.tilesN) * BM, n0 = (tile % g.tilesN) * BN;
   const bool fullA = g.vecA && (m0 + BM <= g.M), fullB = g.vecB && (n0 + BN <= g.N);
-  const int z = blockIdx.z;
+  const int z = blockIdx.z, ks = blockIdx.y;
   const float* A = g.A + z * g.sA;
   const float* B = g.B + z * g.sB;
-  float* C = g.C + z * g.sC;
-  const float* bias = g.bias ? g.bias + z * g.sbias : nullptr;
+  const bool partial = g.splitk > 1;
+  float* C = partial ? g.slabs + ((int64_t)z * g.splitk + ks) * g.M * g.N : g.C + z * g.sC;
+  const int ldc = partial ? g.N : g.ldc;
+  const float* bias = (g.bias && !partial) ? g.bias + z * g.sbias : nullptr;
+  const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);  // kchunk is a multiple of BK
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -115,13 +128,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (g.K + BK - 1) / BK;
-  float4 ra[2], rb[2];
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  float4 ra[PIECES], rb[PIECES];
   // A is k-major in memory when TA (stored K x M); B is k-major when !TB (stored K x N)
-  fetch<TA>(A, g.lda, m0, g.M, 0, g.K, fullA && BK <= g.K, tid, ra);
-  fetch<!TB>(B, g.ldb, n0, g.N, 0, g.K, fullB && BK <= g.K, tid, rb);
-  stash<TA>(As[0], tid, ra);
-  stash<!TB>(Bs[0], tid, rb);
+  fetch<TA>(A, g.lda, m0, g.M, kbeg, kend, fullA && kbeg + BK <= kend, tid, ra);
+  fetch<!TB>(B, g.ldb, n0, g.N, kbeg, kend, fullB && kbeg + BK <= kend, tid, rb);
+  stash<TA, LDA>(As[0], tid, ra);
+  stash<!TB, LDB>(Bs[0], tid, rb);
   __syncthreads();
 
   const int kh = lane >> 5, l31 = lane & 31;
@@ -129,9 +142,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
-      const bool kfull = (kt + 2) * BK <= g.K;  // block-uniform
-      fetch<TA>(A, g.lda, m0, g.M, (kt + 1) * BK, g.K, fullA && kfull, tid, ra);
-      fetch<!TB>(B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, fullB && kfull, tid, rb);
+      const int k0 = kbeg + (kt + 1) * BK;
+      const bool kfull = k0 + BK <= kend;  // block-uniform
+      fetch<TA>(A, g.lda, m0, g.M, k0, kend, fullA && kfull, tid, ra);
+      fetch<!TB>(B, g.ldb, n0, g.N, k0, kend, fullB && kfull, tid, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
@@ -145,8 +159,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
     if (more) {
-      stash<TA>(As[cur ^ 1], tid, ra);
-      stash<!TB>(Bs[cur ^ 1], tid, rb);
+      stash<TA, LDA>(As[cur ^ 1], tid, ra);
+      stash<!TB, LDB>(Bs[cur ^ 1], tid, rb);
     }
     __syncthreads();
     cur ^= 1;
@@ -164,22 +178,77 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (row < g.M) {
-          float* cp = C + (int64_t)row * g.ldc + col;
+          float* cp = C + (int64_t)row * ldc + col;
           float v = acc[i][j][r] + bv;
-          if (g.accumulate) v += *cp;
-          if (g.act == 1) v = sk_sigmoid(v);
+          if (!partial) {
+            if (g.accumulate) v += *cp;
+            if (g.act == 1) v = sk_sigmoid(v);
+          }
           *cp = v;
         }
       }
     }
 }
 
+// C = act(sum_ks slabs[z][ks] + bias (+ C)), slices added in fixed order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+  const int z = blockIdx.z;
+  const int64_t mn = (int64_t)g.M * g.N;
+  const float* sl = g.slabs + (int64_t)z * g.splitk * mn;
+  float* C = g.C + z * g.sC;
+  const float* bias = g.bias ? g.bias + z * g.sbias : nullptr;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < mn; i += (int64_t)gridDim.x * 1024) {
+    // N % 4 == 0 is required by the host for the vector path; otherwise fall back to scalars
+    if ((g.N & 3) == 0) {
+      float4 a = *reinterpret_cast<const float4*>(sl + i);
+      for (int k = 1; k < g.splitk; ++k) {
+        const float4 b = *reinterpret_cast<const float4*>(sl + k * mn + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      const int row = (int)(i / g.N), col = (int)(i - (int64_t)row * g.N);
+      float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float* cp = C + (int64_t)row * g.ldc + col + e;
+        float x = v[e] + (bias ? bias[col + e] : 0.f);
+        if (g.accumulate) x += *cp;
+        if (g.act == 1) x = sk_sigmoid(x);
+        *cp = x;
+      }
+    } else {
+      for (int e = 0; e < 4 && i + e < mn; ++e) {
+        float a = sl[i + e];
+        for (int k = 1; k < g.splitk; ++k) a += sl[k * mn + i + e];
+        const int row = (int)((i + e) / g.N), col = (int)((i + e) - (int64_t)row * g.N);
+        float* cp = C + (int64_t)row * g.ldc + col;
+        float x = a + (bias ? bias[col] : 0.f);
+        if (g.accumulate) x += *cp;
+        if (g.act == 1) x = sk_sigmoid(x);
+        *cp = x;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk) {
+  if (splitk <= 1) return 0;
+  return sk_align((size_t)M * N * batch * splitk * sizeof(float), 256);
+}
 
 extern "C" int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                            int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA,
                            int64_t sB, int64_t sC, int64_t sbias, sk_stream_t stream) {
+  return sk_gemm_f32_splitk(A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, accumulate, act, batch, sA, sB, sC,
+                            sbias, 1, nullptr, stream);
+}
+
+extern "C" int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                           int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA,
+                           int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm_f32: null pointer");
+  SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm_f32: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm_f32: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm_f32: leading dimension too small");
   SK_CHECK_ARG(act == 0 || act == 1, "sk_gemm_f32: unknown activation %d", act);
@@ -191,9 +260,13 @@ extern "C" int sk_gemm_f32(const float* A, const float* B, float* C, const float
   g.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
   g.tilesN = (int)sk_cdiv(N, BN);
   g.sA = sA; g.sB = sB; g.sC = sC; g.sbias = sbias;
+  g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), BK) * BK);
+  splitk = (int)sk_cdiv(K, g.kchunk);  // slices that actually hold work
+  g.splitk = splitk;
+  g.slabs = (float*)ws;
   const int64_t tiles = sk_cdiv(M, BM) * g.tilesN;
   SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm_f32: too many tiles");
-  dim3 grid((unsigned)tiles, 1, (unsigned)batch);
+  dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
   if (!transA && !transB)
     hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
@@ -204,5 +277,11 @@ extern "C" int sk_gemm_f32(const float* A, const float* B, float* C, const float
   else
     hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
   SK_CHECK_LAUNCH("sk_gemm_f32");
+  if (splitk > 1) {
+    const int64_t quads = sk_cdiv((int64_t)M * N, 4);
+    const unsigned nb = (unsigned)(sk_cdiv(quads, 256) > 2048 ? 2048 : sk_cdiv(quads, 256));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb, 1, (unsigned)batch), dim3(256), 0, st, g);
+    SK_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
   return SK_OK;
 }

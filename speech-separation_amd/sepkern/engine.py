@@ -166,7 +166,8 @@ class Engine:
 
         dz = torch.empty_like(dmask)
         ops.sigmoid_bwd(dmask, ctx["mask"], dz)
-        ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), S * F, 2 * H, R, S * F, 2 * H, 2 * H, transA=True, accumulate=acc)
+        ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), S * F, 2 * H, R, S * F, 2 * H, 2 * H, transA=True, accumulate=acc,
+                 splitk=0)
         ops.colsum(dz, R, S * F, S * F, self.g("lin.bias"), accumulate=acc)
         dxbn = torch.empty(R, 2 * H, device=dev)
         ops.gemm(dz, self.p("lin.weight"), dxbn, R, 2 * H, S * F, S * F, 2 * H, 2 * H)
@@ -190,9 +191,10 @@ class Engine:
             ops.lstm_hprev(y, h0[2 * l:2 * l + 2], lens, hprev, T, B, H)
             # dW_hh[d] = dgx[:, d]^T hprev[:, d]   (two directions as a batch of 2)
             ops.gemm(dgx, hprev, self.g("weight_hh_l%d" % l), 4 * H, H, R, 8 * H, 2 * H, H, transA=True,
-                     accumulate=acc, batch=2, sA=4 * H, sB=H, sC=4 * H * H)
+                     accumulate=acc, batch=2, sA=4 * H, sB=H, sC=4 * H * H, splitk=0)
             # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
-            ops.gemm(dgx, inp, self.g("weight_ih_l%d" % l), 8 * H, I, R, 8 * H, I, I, transA=True, accumulate=acc)
+            ops.gemm(dgx, inp, self.g("weight_ih_l%d" % l), 8 * H, I, R, 8 * H, I, I, transA=True, accumulate=acc,
+                     splitk=0)
             db = torch.empty(8 * H, device=dev)
             ops.colsum(dgx, R, 8 * H, 8 * H, db)
             put("bias_ih_l%d" % l, db.view(2, 4 * H))

@@ -76,19 +76,47 @@ def device_info():
 
 
 # ----------------------------------------------------------------------------- GEMM
+_SLOTS = None
+
+
+def pick_splitk(M, N, K, batch=1):
+    """Slices for a weight-gradient-shaped product (few output tiles, long K): minimise the
+    wave-quantisation loss over the resident block slots (2 blocks of 128x128 per CU) plus the
+    cost of writing and re-reading the partial slabs."""
+    global _SLOTS
+    if _SLOTS is None:
+        _SLOTS = 2 * device_info()[0]
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+    if tiles >= 4 * _SLOTS or K < 2048:
+        return 1
+    work = 2.0 * M * N * K * batch / 100e12                      # seconds at ~100 TFLOP/s
+    best, best_t = 1, None
+    for s in range(1, 33):
+        if K // s < 512:
+            break
+        blocks = tiles * s
+        waves = -(-blocks // _SLOTS)
+        t = work * waves * _SLOTS / blocks + (0 if s == 1 else 2.0 * s * M * N * batch * 4 / 4e12)
+        if best_t is None or t < best_t * 0.98:
+            best, best_t = s, t
+    return best
+
+
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, accumulate=False, act=0,
-         batch=1, sA=0, sB=0, sC=0, sbias=0):
+         batch=1, sA=0, sB=0, sC=0, sbias=0, splitk=1):
     """Cout[M,N] = act(opA(A) opB(B) + bias (+ Cout)).  A/B/Cout are tensors whose data_ptr() is the
-    first element of the operand (views are fine: leading dimensions are explicit)."""
+    first element of the operand (views are fine: leading dimensions are explicit).  splitk > 1 (or 0 =
+    choose) splits K into deterministic partial slabs -- for weight gradients."""
     for t in (A, B, Cout, bias):
         _chk(t)
+    if splitk == 0:
+        splitk = pick_splitk(M, N, K, batch)
+    ws = None
+    if splitk > 1:
+        ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), "gemm")
     with _timed("gemm_f32_kernel", 2.0 * M * N * K * batch):
-        _gemm_call(A, B, Cout, M, N, K, lda, ldb, ldc, transA, transB, bias, accumulate, act, batch, sA, sB, sC, sbias)
-
-
-def _gemm_call(A, B, Cout, M, N, K, lda, ldb, ldc, transA, transB, bias, accumulate, act, batch, sA, sB, sC, sbias):
-    _lib.call("sk_gemm_f32", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA),
-              int(transB), int(accumulate), int(act), batch, sA, sB, sC, sbias, _stream())
+        _lib.call("sk_gemm_f32_splitk", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA),
+                  int(transB), int(accumulate), int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws), _stream())
 
 
 # ----------------------------------------------------------------------------- STFT / iSTFT

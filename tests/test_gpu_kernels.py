@@ -64,6 +64,23 @@ def test_gemm_accumulate_sigmoid_batch_and_ld(ops):
     np.testing.assert_allclose(out.cpu().numpy(), torch.sigmoid(X.double() @ W.double().t() + b.double()).numpy(), atol=2e-6)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(300, 260, 5000, 5), (140, 257, 3000, 3), (129, 64, 4096, 0)])
+def test_gemm_splitk_is_deterministic_and_matches_fp64(ops, M, N, K, S):
+    g = torch.Generator().manual_seed(K)
+    A, B = torch.randn(K, 2 * M, generator=g), torch.randn(K, 2 * N, generator=g)     # weight-gradient shape (TN)
+    bias, C0 = torch.randn(N, generator=g), torch.randn(2, M, N, generator=g)
+    ref = torch.stack([A[:, d * M:(d + 1) * M].double().t() @ B[:, d * N:(d + 1) * N].double() for d in range(2)]) \
+        + bias.double() + C0.double()
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        ops.gemm(dev(A), dev(B), C, M, N, K, 2 * M, 2 * N, N, transA=True, bias=dev(bias), accumulate=True, batch=2,
+                 sA=M, sB=N, sC=M * N, splitk=S)
+        outs.append(C.cpu())
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
+    assert torch.equal(outs[0], outs[1])                     # fixed-order slab reduction: bitwise reproducible
+
+
 # ------------------------------------------------------------------------------------ STFT / iSTFT
 def _sig(n, seed):
     rng = np.random.default_rng(seed)
