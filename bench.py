@@ -117,10 +117,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    # rehearsal on a 1-GPU box: SEPKERN_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 (use with
+    # SEPKERN_DIST_BACKEND=gloo and SEPKERN_LSTM_MODE=2, since two processes cannot both keep a
+    # persistent grid resident on one GPU)
+    if os.environ.get("SEPKERN_BENCH_ONE_DEVICE") == "1":
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from sepkern import dist as skdist
+    skdist.init_from_env()                                # nccl (= RCCL over xGMI) unless SEPKERN_DIST_BACKEND says otherwise
 
     from sepkern import ops, synth, _lib
     from sepkern.optim import ClipAdam

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-shape timing of sk_gemm_f32 on the shapes of the 3x896, 32x400 training step (diagnostic)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sepkern import ops  # noqa: E402
+
+H, R, F = 896, 12800, 257
+SHAPES = [  # name, M, N, K, transA, transB, batch, splitk
+    ("fwd  L1/2  NT x*Wih^T", R, 8 * H, 2 * H, False, True, 1, 1),
+    ("fwd  L0    NT K=257", R, 8 * H, F, False, True, 1, 1),
+    ("fwd  lin   NT N=514", R, 2 * F, 2 * H, False, True, 1, 1),
+    ("dgrad L1/2 NN dgx*Wih", R, 2 * H, 8 * H, False, False, 1, 1),
+    ("dgrad lin  NN K=514", R, 2 * H, 2 * F, False, False, 1, 1),
+    ("wgrad Wih  TN", 8 * H, 2 * H, R, True, False, 1, 0),
+    ("wgrad Wih  TN no split", 8 * H, 2 * H, R, True, False, 1, 1),
+    ("wgrad Whh  TN batch2", 4 * H, H, R, True, False, 2, 0),
+    ("wgrad Wih0 TN N=257", 8 * H, F, R, True, False, 1, 0),
+    ("wgrad lin  TN M=514", 2 * F, 2 * H, R, True, False, 1, 0),
+]
+
+
+def main():
+    for name, M, N, K, tA, tB, batch, sk in SHAPES:
+        A = torch.randn((K, M * batch) if tA else (M, K), device="cuda")
+        B = torch.randn((N, K) if tB else (K, N * batch), device="cuda")
+        C = torch.empty(batch, M, N, device="cuda")
+        lda, ldb = A.shape[1], B.shape[1]
+        kw = dict(transA=tA, transB=tB, batch=batch, sA=M if batch > 1 else 0, sB=N if batch > 1 else 0, sC=M * N, splitk=sk)
+        used = ops.pick_splitk(M, N, K, batch) if sk == 0 else sk
+        for _ in range(2):
+            ops.gemm(A, B, C, M, N, K, lda, ldb, N, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 10
+        e0.record()
+        for _ in range(n):
+            ops.gemm(A, B, C, M, N, K, lda, ldb, N, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        print("%-26s M=%6d N=%5d K=%6d b=%d splitk=%2d  %8.3f ms  %7.1f TFLOP/s" %
+              (name, M, N, K, batch, used, ms, 2.0 * M * N * K * batch / ms / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    main()

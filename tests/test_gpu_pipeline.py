@@ -91,3 +91,27 @@ def test_recipe_steps_end_to_end(tmp_path):
             assert fs == 8000 and got.dtype == np.int16 and got.shape == ref.shape == (128 * (spec.shape[1] - 1),)
             d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
             assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
+    """bench.py's N>1 path (barriers, global-norm + gradient all-reduce, max-over-ranks timing, one JSON line
+    from rank 0) with 2 ranks on cuda:0 over gloo; the per-step LSTM mode because two processes cannot both
+    keep a persistent grid resident on one GPU.  The real N>1 runs use nccl (= RCCL), one rank per GPU."""
+    import json
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SEPKERN_BENCH_ONE_DEVICE="1", SEPKERN_DIST_BACKEND="gloo", SEPKERN_LSTM_MODE="2")
+    root = os.path.dirname(PKG)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--hidden", "64", "--layers", "2", "--batch", "4",
+                        "--frames", "40"], cwd=root, env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2 * 4 * 40
+    assert d["value"] > 0 and d["unit"] == "frames/s" and "cpu_baseline" not in d
