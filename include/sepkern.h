@@ -143,10 +143,11 @@ int sk_sigmoid_bwd(const float* dmask, const float* m, float* dz, int64_t n, sk_
  *   pair_sse (B,S,S): pair[b][s][r] = sum_{t,f} (mask[t,b,s,f]*mix[t,b,f] - src_r[t,b,f])^2
  *   perm_loss (S!,B) in itertools.permutations order; best_perm (B) = argmin (first minimum)
  *   out[0] = loss/norm, out[1] = norm = sum(lens)*F, out[2] = sum_b min loss / S
- * norm_override > 0 replaces norm (data-parallel training divides by the GLOBAL norm). */
+ * norm_dev (device scalar, may be NULL) replaces norm when given: data-parallel training divides by the
+ * GLOBAL norm, all-reduced on the device without a host round trip. */
 size_t sk_pit_workspace_bytes(int T, int B, int S);
 int sk_pit_mse_fwd(const float* mask, const float* mix, const float* const* src_host, const int32_t* lens,
-                   int T, int B, int F, int S, float norm_override, float* pair_sse, float* perm_loss,
+                   int T, int B, int F, int S, const float* norm_dev, float* pair_sse, float* perm_loss,
                    int32_t* best_perm, float* out, void* ws, sk_stream_t stream);
 /* dmask = gscale[0] * 2 * (mask*mix - src_{best_perm[b][s]}) * mix / (S * norm), norm = out[1] */
 int sk_pit_mse_bwd(const float* mask, const float* mix, const float* const* src_host,

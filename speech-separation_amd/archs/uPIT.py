@@ -156,8 +156,8 @@ class _PitFn(torch.autograd.Function):
   """out = [loss/norm, norm, sum_b min_p L/S] (reference archs/uPIT.py:181-197,206)."""
 
   @staticmethod
-  def forward(ctx, mask, mix, lens, norm_override, *srcs):
-    res = ops.pit_mse_fwd(mask, mix, list(srcs), lens, norm_override)
+  def forward(ctx, mask, mix, lens, norm_dev, *srcs):
+    res = ops.pit_mse_fwd(mask, mix, list(srcs), lens, norm_dev)
     ctx.save_for_backward(mask, mix, res["best_perm"], res["out"], *srcs)
     ctx.mark_non_differentiable(res["best_perm"])
     return res["out"], res["best_perm"]
@@ -314,8 +314,8 @@ def compute_loss_padded(model, mix, sources, lens, plotdir=""):
   model.hidden = model.init_hidden(batch)
 
   # data-parallel: divide by the GLOBAL frame count so that the summed gradients equal the
-  # single-device gradient of the global batch (0.0 = single process, kernel uses sum(lens)*F)
-  norm_override = skdist.global_norm(int(lens.sum().item()), model.feat_dim, mix.device) if skdist.is_parallel() else 0.0
+  # single-device gradient of the global batch (None = single process, kernel uses sum(lens)*F)
+  norm_override = skdist.global_norm(lens, model.feat_dim)
 
   mask_out = model.forward_padded(mix, lens)
   # mask_out: tensor of shape (seq_length, batch, feat_dim*num_spk)

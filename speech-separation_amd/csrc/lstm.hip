@@ -128,6 +128,28 @@ __device__ __forceinline__ void dma_piece(const float* gsrc_piece, float* lds_pi
   __builtin_amdgcn_global_load_lds(SK_GLOBAL_PTR(gsrc_piece + lane * 4), SK_LDS_PTR(lds_piece), 16, 0, 16 /* sc1 */);
 }
 
+// Diagnostic build only (-DSK_LSTM_STAMPS, libsepkern_stamps.so): wave 0 of workgroup (0,0,0) accumulates the
+// 100 MHz wall-clock ticks spent in each phase of the step into words 8.. of the workspace's control block.
+// No stamp executes in the shipped library.
+#ifdef SK_LSTM_STAMPS
+#define SK_STAMP_DECL long long st_t = wall_clock64(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SK_STAMP(i)                                   \
+  do {                                                \
+    const long long n__ = wall_clock64();             \
+    st_acc[i] += n__ - st_t;                          \
+    st_t = n__;                                       \
+  } while (0)
+#define SK_STAMP_FLUSH(ctrl)                                                                   \
+  do {                                                                                         \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)            \
+      for (int i__ = 0; i__ < 8; ++i__) ((long long*)(ctrl))[4 + i__] = st_acc[i__];           \
+  } while (0)
+#else
+#define SK_STAMP_DECL
+#define SK_STAMP(i)
+#define SK_STAMP_FLUSH(ctrl)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -192,9 +214,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
   }
   if (tid == 0) s_abort = 0;
   __syncthreads();
+  SK_STAMP_DECL
 
   for (int s = a.s_begin; s < a.s_end; ++s) {
     const int t = dir ? T - 1 - s : s;
+    SK_STAMP(7);
     // 1. this step's input-projection terms (independent of the recurrence: issue early)
     float gxv[4] = {0.f, 0.f, 0.f, 0.f};
     if (cellok) {
@@ -208,6 +232,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
     }
     __syncthreads();
     if (s_abort) break;
+    SK_STAMP(0);
     // 3. h_{s-1} image (16 rows x HP) -> LDS
     if (s == 0) {
       for (int i = tid; i < 16 * (HP / 4); i += NTHREADS) {
@@ -223,6 +248,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
       wait_vmcnt<0>();
     }
     __syncthreads();
+    SK_STAMP(1);
     // 4. gates^T (64 gate rows x 16 batch) = W_slice (64 x HP) * h^T (HP x 16); this wave: 16 rows, half of K
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     {
@@ -237,8 +263,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
       }
     }
     f32x4 acc = acc0 + acc1;
+    SK_STAMP(2);
     if (!owner) *reinterpret_cast<f32x4*>(&red[mt][lane][0]) = acc;
     __syncthreads();
+    SK_STAMP(3);
     if (owner) {
       acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
       // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
@@ -255,7 +283,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
       }
       // 6. publish h_s first (write-through) ...
       __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
+      SK_STAMP(4);
       wait_vmcnt<0>();
+      SK_STAMP(5);
       // (stash what the bulk stores below need; they are issued after the flag)
       acc[0] = gi;
       acc[1] = gf;
@@ -279,7 +309,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
         a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit] = gxv[1];
       }
     }
+    SK_STAMP(6);
   }
+  SK_STAMP_FLUSH(a.ctrl);
 
   if (!s_abort && cellok) {
     if (a.s_end == T) {
@@ -419,9 +451,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   }
   if (tid == 0) s_abort = 0;
   __syncthreads();
+  SK_STAMP_DECL
 
   for (int s = a.s_begin; s < a.s_end; ++s) {
     const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
+    SK_STAMP(7);
     const bool valid = cellok && t < len_b;
     // 1. saved activations of this cell (independent of the recurrence: issue early)
     float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cprev = 0.f, dyv = 0.f;
@@ -444,7 +478,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       }
       __syncthreads();
       if (s_abort) break;
+      SK_STAMP(0);
       dh_rec = bwd_matmul<KS>(wreg, ((s - 1) & 1) ? xb1 : xb0, ring, red, w, lane) + carry;
+      SK_STAMP(2);
     } else {
       dh_rec = 0.f;
     }
@@ -468,8 +504,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
     if (owner) {
       float* xdst = (s & 1) ? xb1 : xb0;
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
+      SK_STAMP(4);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
       wait_vmcnt<0>();
+      SK_STAMP(5);
     }
     __syncthreads();
     if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
@@ -481,7 +519,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       dp[(size_t)2 * H] = dpre[2];
       dp[(size_t)3 * H] = dpre[3];
     }
+    SK_STAMP(6);
   }
+  SK_STAMP_FLUSH(a.ctrl);
 
   if (s_abort) return;
   if (a.final_mm) {

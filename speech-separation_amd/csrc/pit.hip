@@ -73,11 +73,9 @@ __device__ __forceinline__ void nth_perm(int idx, int S, int* perm) {
 
 __global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restrict__ partial, int nch,
                                                            const int32_t* __restrict__ lens, int B, int F, int S,
-                                                           float norm_override, float* __restrict__ pair_sse,
+                                                           const float* __restrict__ norm_dev, float* __restrict__ pair_sse,
                                                            float* __restrict__ perm_loss, int32_t* __restrict__ best_perm,
                                                            float* __restrict__ out) {
-  __shared__ float s_min[256];
-  __shared__ float s_len[256];
   __shared__ float red[4];
   int nperm = 1;
   for (int i = 2; i <= S; ++i) nperm *= i;
@@ -107,12 +105,10 @@ __global__ __launch_bounds__(256) void pit_finalize_kernel(const float* __restri
     my_min += best;
     my_len += (float)lens[b];
   }
-  (void)s_min;
-  (void)s_len;
   const float tot = sk_block_sum256(my_min, red);
   const float len = sk_block_sum256(my_len, red);
   if (threadIdx.x == 0) {
-    const float norm = norm_override > 0.f ? norm_override : len * (float)F;
+    const float norm = norm_dev ? norm_dev[0] : len * (float)F;
     const float lsum = tot / (float)S;
     out[0] = lsum / norm;
     out[1] = norm;
@@ -148,7 +144,7 @@ extern "C" size_t sk_pit_workspace_bytes(int T, int B, int S) {
 }
 
 extern "C" int sk_pit_mse_fwd(const float* mask, const float* mix, const float* const* src_host, const int32_t* lens,
-                              int T, int B, int F, int S, float norm_override, float* pair_sse, float* perm_loss,
+                              int T, int B, int F, int S, const float* norm_dev, float* pair_sse, float* perm_loss,
                               int32_t* best_perm, float* out, void* ws, sk_stream_t stream) {
   SK_CHECK_ARG(mask && mix && src_host && lens && pair_sse && perm_loss && best_perm && out && ws,
                "sk_pit_mse_fwd: null pointer");
@@ -167,7 +163,7 @@ extern "C" int sk_pit_mse_fwd(const float* mask, const float* mix, const float* 
     default: hipLaunchKernelGGL(pit_pair_kernel<4>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
   }
   SK_CHECK_LAUNCH("pit_pair_kernel");
-  hipLaunchKernelGGL(pit_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nch, lens, B, F, S, norm_override,
+  hipLaunchKernelGGL(pit_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nch, lens, B, F, S, norm_dev,
                      pair_sse, perm_loss, best_perm, out);
   SK_CHECK_LAUNCH("pit_finalize_kernel");
   return SK_OK;

@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsepkern.so")
+LIB_PATH = os.environ.get("SEPKERN_LIB") or os.path.join(_HERE, "libsepkern.so")   # SEPKERN_LIB: diagnostic builds
 
 SK_VERSION = 100
 
@@ -40,7 +40,7 @@ PROTOTYPES = {
     "sk_colsum": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
     "sk_sigmoid_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "sk_pit_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sk_pit_mse_fwd": (_i, [_p, _p, C.POINTER(_p), _p, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p]),
+    "sk_pit_mse_fwd": (_i, [_p, _p, C.POINTER(_p), _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "sk_pit_mse_bwd": (_i, [_p, _p, C.POINTER(_p), _p, _p, _p, _i, _i, _i, _i, _p, _p]),
     "sk_optim_workspace_bytes": (_sz, [_i64]),
     "sk_grad_norm": (_i, [_p, _i64, _f, _p, _p, _p]),

@@ -51,14 +51,15 @@ def shard_indices(n, rank_, world_):
     return list(range(rank_, n, world_))
 
 
-def global_norm(local_frames, feat_dim, device):
-    """sum over ALL ranks of sum(len_b) * F  (reference archs/uPIT.py:197 on the global batch).
-    Returns a python float; 0.0 means "not parallel: let the kernel use its local norm"."""
+def global_norm(lens, feat_dim):
+    """Device scalar sum over ALL ranks of sum(len_b) * F (reference archs/uPIT.py:197 on the global batch),
+    or None when not parallel (the kernel then uses its local norm).  Stays on the device: the
+    all-reduce is enqueued on the stream, no host round trip per step."""
     if not is_parallel():
-        return 0.0
-    t = torch.tensor([float(local_frames) * feat_dim], dtype=torch.float64, device=device)
+        return None
+    t = (lens.sum().to(torch.float32) * float(feat_dim)).reshape(1)
     dist.all_reduce(t)
-    return float(t.item())
+    return t
 
 
 def allreduce_grads(flat_grad):

@@ -219,8 +219,9 @@ def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True):
 
 
 # ----------------------------------------------------------------------------- PIT-MSE
-def pit_mse_fwd(mask, mix, srcs, lens, norm_override=0.0):
-    """mask (T,B,S*F), mix (T,B,F), srcs list of S (T,B,F), lens int32 (B) ->
+def pit_mse_fwd(mask, mix, srcs, lens, norm_dev=None):
+    """mask (T,B,S*F), mix (T,B,F), srcs list of S (T,B,F), lens int32 (B), norm_dev: optional device
+    scalar replacing sum(lens)*F (the global norm under data parallelism) ->
     dict(out (3,), pair (B,S,S), perm_loss (S!,B), best_perm (B))."""
     T, B, F = mix.shape
     S = len(srcs)
@@ -239,7 +240,8 @@ def pit_mse_fwd(mask, mix, srcs, lens, norm_override=0.0):
     out = torch.empty(3, device=dev)
     ws = workspace(_lib.load().sk_pit_workspace_bytes(T, B, S), "pit")
     sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
-    _lib.call("sk_pit_mse_fwd", _ptr(mask), _ptr(mix), sp, _ptr(lens), T, B, F, S, float(norm_override), _ptr(pair),
+    _chk(norm_dev)
+    _lib.call("sk_pit_mse_fwd", _ptr(mask), _ptr(mix), sp, _ptr(lens), T, B, F, S, _ptr(norm_dev), _ptr(pair),
               _ptr(perm_loss), _ptr(best), _ptr(out), _ptr(ws), _stream())
     return dict(out=out, pair=pair, perm_loss=perm_loss, best_perm=best)
 

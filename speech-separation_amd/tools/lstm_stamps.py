@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase time of the persistent BLSTM kernels (needs `make -C csrc stamps` and
+SEPKERN_LIB=.../libsepkern_stamps.so).  Prints 100 MHz wall-clock ticks per step for workgroup (0,0,0)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sepkern import ops  # noqa: E402
+
+T, B, H = 400, 32, 896
+NAMES_F = ["wait flags+barrier", "DMA h + barrier", "MFMA", "LDS reduce barrier", "cell + h store", "drain vmcnt(0)",
+           "barrier+flag+bulk stores", "gx prefetch issue"]
+NAMES_B = ["wait flags+barrier", "-", "matmul (DMA ring+MFMA+reduce)", "-", "cell backward", "dG store + drain",
+           "barrier+flag+dgx stores", "saved-activation loads issue"]
+
+
+def stamps(ws):
+    return ws[:256].view(torch.int64)[4:12].cpu().tolist()
+
+
+def main():
+    torch.manual_seed(0)
+    gx = torch.randn(T, B, 2, 4 * H, device="cuda") * 0.5
+    whh = torch.randn(2, 4 * H, H, device="cuda") / 30
+    h0, c0 = torch.randn(2, B, H, device="cuda"), torch.randn(2, B, H, device="cuda")
+    lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    y, cs = torch.empty(T, B, 2 * H, device="cuda"), torch.empty(T, B, 2, H, device="cuda")
+    for rep in range(2):
+        g = gx.clone()
+        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, None, None, T, B, H, 1)
+        ops.lstm_status(ws)
+        sf = stamps(ws)
+        dy = torch.randn(T, B, 2 * H, device="cuda")
+        ws = ops.lstm_bwd(dy, whh, g, cs, c0, lens, g, None, None, T, B, H, 1)
+        ops.lstm_status(ws)
+        sb = stamps(ws)
+    print("forward  (us per step, workgroup 0):")
+    for n, v in zip(NAMES_F, sf):
+        print("   %-34s %7.3f" % (n, v / 100.0 / T))
+    print("   %-34s %7.3f" % ("total", sum(sf) / 100.0 / T))
+    print("backward (us per step, workgroup 0):")
+    for n, v in zip(NAMES_B, sb):
+        print("   %-34s %7.3f" % (n, v / 100.0 / T))
+    print("   %-34s %7.3f" % ("total", sum(sb) / 100.0 / T))
+
+
+if __name__ == "__main__":
+    main()

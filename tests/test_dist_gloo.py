@@ -77,8 +77,7 @@ def _worker(rank, world, port, q):
     pos = {int(u): k for k, u in enumerate(order_all)}
     rows = [pos[my_ids[j]] for j in my_order]
     hidden = (h_all[0][:, rows].contiguous(), h_all[1][:, rows].contiguous())
-    frames = sum(len(d["mix"]) for d in mine)
-    gnorm = skdist.global_norm(frames, 33, torch.device("cpu"))
+    gnorm = float(skdist.global_norm(torch.tensor([len(d["mix"]) for d in mine], dtype=torch.int32), 33))
     loss = _loss_sum(m, mine, hidden, gnorm)
     m.zero_grad()
     loss.backward()
@@ -96,7 +95,7 @@ def test_two_rank_dp_equals_single_process_global_batch():
     from oracle import upit as OU
     from sepkern import dist as skdist
     assert sorted(skdist.shard_indices(7, 0, 2) + skdist.shard_indices(7, 1, 2)) == list(range(7))
-    assert skdist.global_norm(10, 33, torch.device("cpu")) == 0.0 and not skdist.is_parallel()
+    assert skdist.global_norm(torch.tensor([10]), 33) is None and not skdist.is_parallel()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
