@@ -85,7 +85,7 @@ struct FwdArgs {
   float* state;
   unsigned* flags;
   unsigned* ctrl;
-  int T, B, H, NBG, s_begin, s_end;
+  int T, B, H, NBG, G, s_begin, s_end;
 };
 
 struct BwdArgs {
@@ -102,7 +102,7 @@ struct BwdArgs {
   float* state;
   unsigned* flags;
   unsigned* ctrl;
-  int T, B, H, NBG, s_begin, s_end, final_mm;
+  int T, B, H, NBG, G, s_begin, s_end, final_mm;
 };
 
 // Wave 0 waits until every flag of its (direction, batch group) has reached `target`.
@@ -158,17 +158,23 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ------------------------------------------------------------------------------------ forward
 // Waves: w = mt + 4*kh; mt = gate-row tile (4 units x 4 gates), kh = K half.  Cells live in the
 // kh == 0 waves: lane (u = lane>>4, b = lane&15) of wave mt <-> unit 4*mt+u, batch row b.
+// A workgroup carries G batch groups (blockIdx.y*G .. +G-1) that share its register-resident W slice and
+// are processed in turn every step, so that any batch size fits a co-resident grid; while one group's
+// h_t is in flight to the other workgroups the next group computes.
+constexpr int GMAX = 8;
+
 template <int KS>
 __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int HP = 16 * KS, NQ = KS / 2;
   __shared__ __attribute__((aligned(16))) float hs[16 * HP];  // B-operand image of h_{s-1}: [k/4][16 rows][4]
   __shared__ __attribute__((aligned(16))) float red[4][64][4];
+  __shared__ float st_c[GMAX][256], st_h[GMAX][256];          // per-group cell state of the owner lanes
   __shared__ int s_abort;
 
-  const int ug = blockIdx.x, bg = blockIdx.y, dir = blockIdx.z;
+  const int ug = blockIdx.x, by = blockIdx.y, dir = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int mt = w & 3, kh = w >> 2;
-  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;
+  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG, G = a.G;
 
   // ---- W_hh slice -> registers.  MFMA A operand: lane l supplies A[i = l&15][k = l>>4];
   //      row i = 4*unit_local + gate; k of (chunk q, r) = 16 (kh*NQ + q) + 4 (l>>4) + r.
@@ -191,134 +197,157 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
   }
 
   const int u_l = lane >> 4, bl = lane & 15;
-  const int unit = ug * 16 + 4 * mt + u_l, b = bg * 16 + bl;
-  const bool owner = kh == 0;                      // this wave carries cells
-  const bool cellok = owner && unit < H && b < B;
-  const int len_b = (b < B) ? a.lens[b] : 0;
+  const int unit = ug * 16 + 4 * mt + u_l;
+  const bool owner = kh == 0;  // this wave carries cells
+  const int oi = mt * 64 + lane;
   const size_t xblk = (size_t)16 * HP;  // floats per (parity, dir, batch group) exchange block
-  float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
-  float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
   const int xoff = ((ug * 4 + mt) * 16 + bl) * 4 + u_l;  // image position of (k = unit, row = bl)
-  float* const st_c = a.state + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + (ug * 16 + 4 * mt + u_l);
-  unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
 
-  float c_reg = 0.f, h_reg = 0.f;
-  if (cellok) {
-    if (a.s_begin == 0) {
-      c_reg = a.c0[((size_t)dir * B + b) * H + unit];
-      h_reg = a.h0[((size_t)dir * B + b) * H + unit];
-    } else {
-      c_reg = *st_c;
-      h_reg = __hip_atomic_load(((a.s_begin - 1) & 1 ? xb1 : xb0) + xoff, SK_RLX, SK_AGENT);
+  if (owner) {
+    for (int gi = 0; gi < G; ++gi) {
+      const int bg = by * G + gi, b = bg * 16 + bl;
+      float c = 0.f, h = 0.f;
+      if (bg < NBG && unit < H && b < B) {
+        if (a.s_begin == 0) {
+          c = a.c0[((size_t)dir * B + b) * H + unit];
+          h = a.h0[((size_t)dir * B + b) * H + unit];
+        } else {
+          c = a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
+          h = __hip_atomic_load(a.xbuf + ((size_t)(((a.s_begin - 1) & 1) * 2 + dir) * NBG + bg) * xblk + xoff, SK_RLX, SK_AGENT);
+        }
+      }
+      st_c[gi][oi] = c;
+      st_h[gi][oi] = h;
     }
   }
   if (tid == 0) s_abort = 0;
   __syncthreads();
   SK_STAMP_DECL
 
-  for (int s = a.s_begin; s < a.s_end; ++s) {
+  bool aborted = false;
+  for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? T - 1 - s : s;
-    SK_STAMP(7);
-    // 1. this step's input-projection terms (independent of the recurrence: issue early)
-    float gxv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (cellok) {
-      const float* gp = a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+    for (int gi = 0; gi < G; ++gi) {
+      const int bg = by * G + gi;
+      if (bg >= NBG) break;
+      const int b = bg * 16 + bl;
+      const bool cellok = owner && unit < H && b < B;
+      const int len_b = (b < B) ? a.lens[b] : 0;
+      float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
+      float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
+      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+      SK_STAMP(7);
+      // 1. this step's input-projection terms (independent of the recurrence: issue early)
+      float gxv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (cellok) {
+        const float* gp = a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
-    }
-    // 2. wait for h_{s-1} of every unit group of this (direction, batch group)
-    if (s > a.s_begin && w == 0) {
-      if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
-    }
-    __syncthreads();
-    if (s_abort) break;
-    SK_STAMP(0);
-    // 3. h_{s-1} image (16 rows x HP) -> LDS
-    if (s == 0) {
-      for (int i = tid; i < 16 * (HP / 4); i += NTHREADS) {
-        const int bb = i & 15, c = i >> 4;  // row, k/4
-        const int brow = bg * 16 + bb;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (brow < B && 4 * c < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)dir * B + brow) * H + 4 * c);
-        *reinterpret_cast<float4*>(&hs[(c * 16 + bb) * 4]) = v;
+        for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
       }
-    } else {
-      const float* src = ((s - 1) & 1) ? xb1 : xb0;
-      for (int p = w; p < KS; p += 8) dma_piece(src + p * 256, hs + p * 256, lane);
-      wait_vmcnt<0>();
-    }
-    __syncthreads();
-    SK_STAMP(1);
-    // 4. gates^T (64 gate rows x 16 batch) = W_slice (64 x HP) * h^T (HP x 16); this wave: 16 rows, half of K
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    {
-      const float* hp = &hs[(kh * NQ) * 256 + lane * 4];
+      // 2. wait for h_{s-1} of every unit group of this (direction, batch group)
+      if (s > a.s_begin && w == 0) {
+        if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
+      }
+      __syncthreads();
+      if (s_abort) {
+        aborted = true;
+        break;
+      }
+      SK_STAMP(0);
+      // 3. h_{s-1} image (16 rows x HP) -> LDS
+      if (s == 0) {
+        for (int i = tid; i < 16 * (HP / 4); i += NTHREADS) {
+          const int bb = i & 15, c = i >> 4;  // row, k/4
+          const int brow = bg * 16 + bb;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (brow < B && 4 * c < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)dir * B + brow) * H + 4 * c);
+          *reinterpret_cast<float4*>(&hs[(c * 16 + bb) * 4]) = v;
+        }
+      } else {
+        const float* src = ((s - 1) & 1) ? xb1 : xb0;
+        for (int p = w; p < KS; p += 8) dma_piece(src + p * 256, hs + p * 256, lane);
+        wait_vmcnt<0>();
+      }
+      __syncthreads();
+      SK_STAMP(1);
+      // 4. gates^T (64 gate rows x 16 batch) = W_slice (64 x HP) * h^T (HP x 16); this wave: 16 rows, half of K
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      {
+        const float* hp = &hs[(kh * NQ) * 256 + lane * 4];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const float4 hb = *reinterpret_cast<const float4*>(hp + q * 256);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], hb.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], hb.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], hb.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], hb.w, acc1, 0, 0, 0);
+        for (int q = 0; q < NQ; ++q) {
+          const float4 hb = *reinterpret_cast<const float4*>(hp + q * 256);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], hb.x, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], hb.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], hb.z, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], hb.w, acc1, 0, 0, 0);
+        }
       }
-    }
-    f32x4 acc = acc0 + acc1;
-    SK_STAMP(2);
-    if (!owner) *reinterpret_cast<f32x4*>(&red[mt][lane][0]) = acc;
-    __syncthreads();
-    SK_STAMP(3);
-    if (owner) {
-      acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
-      // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
-      const float gi = sk_sigmoid(acc[0] + gxv[0]);
-      const float gf = sk_sigmoid(acc[1] + gxv[1]);
-      const float gg = tanhf(acc[2] + gxv[2]);
-      const float go = sk_sigmoid(acc[3] + gxv[3]);
-      const float c_new = gf * c_reg + gi * gg;
-      const float h_new = go * tanhf(c_new);
-      const bool valid = cellok && t < len_b;
-      if (valid) {
-        c_reg = c_new;
-        h_reg = h_new;
+      f32x4 acc = acc0 + acc1;
+      SK_STAMP(2);
+      if (!owner) *reinterpret_cast<f32x4*>(&red[mt][lane][0]) = acc;
+      __syncthreads();
+      SK_STAMP(3);
+      float y_out = 0.f, c_out = 0.f;
+      bool valid = false;
+      if (owner) {
+        acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
+        // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
+        float c_reg = st_c[gi][oi], h_reg = st_h[gi][oi];
+        const float gi_ = sk_sigmoid(acc[0] + gxv[0]);
+        const float gf = sk_sigmoid(acc[1] + gxv[1]);
+        const float gg = tanhf(acc[2] + gxv[2]);
+        const float go = sk_sigmoid(acc[3] + gxv[3]);
+        const float c_new = gf * c_reg + gi_ * gg;
+        const float h_new = go * tanhf(c_new);
+        valid = cellok && t < len_b;
+        if (valid) {
+          c_reg = c_new;
+          h_reg = h_new;
+          st_c[gi][oi] = c_reg;
+          st_h[gi][oi] = h_reg;
+        }
+        // 6. publish h_s first (write-through) ...
+        __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
+        SK_STAMP(4);
+        wait_vmcnt<0>();
+        SK_STAMP(5);
+        acc[0] = gi_;
+        acc[1] = gf;
+        acc[2] = gg;
+        acc[3] = go;
+        y_out = valid ? h_new : 0.f;
+        c_out = c_new;
       }
-      // 6. publish h_s first (write-through) ...
-      __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
-      SK_STAMP(4);
-      wait_vmcnt<0>();
-      SK_STAMP(5);
-      // (stash what the bulk stores below need; they are issued after the flag)
-      acc[0] = gi;
-      acc[1] = gf;
-      acc[2] = gg;
-      acc[3] = go;
-      gxv[0] = valid ? h_new : 0.f;
-      gxv[1] = c_new;
-      gxv[2] = valid ? 1.f : 0.f;
-    }
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
-    // 7. ... then the bulk stores of the step, off the critical path
-    if (cellok) {
-      a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = gxv[0];
-      if (a.gates && gxv[2] != 0.f) {
-        float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
-        gp[0] = acc[0];
-        gp[(size_t)H] = acc[1];
-        gp[(size_t)2 * H] = acc[2];
-        gp[(size_t)3 * H] = acc[3];
-        a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit] = gxv[1];
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+      // 7. ... then the bulk stores of the step, off the critical path
+      if (cellok) {
+        a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = y_out;
+        if (a.gates && valid) {
+          float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+          gp[0] = acc[0];
+          gp[(size_t)H] = acc[1];
+          gp[(size_t)2 * H] = acc[2];
+          gp[(size_t)3 * H] = acc[3];
+          a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit] = c_out;
+        }
       }
+      SK_STAMP(6);
     }
-    SK_STAMP(6);
   }
   SK_STAMP_FLUSH(a.ctrl);
 
-  if (!s_abort && cellok) {
-    if (a.s_end == T) {
-      if (a.hn) a.hn[((size_t)dir * B + b) * H + unit] = h_reg;
-      if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = c_reg;
-    } else {
-      *st_c = c_reg;
+  if (!aborted && owner) {
+    for (int gi = 0; gi < G; ++gi) {
+      const int bg = by * G + gi, b = bg * 16 + bl;
+      if (bg >= NBG || unit >= H || b >= B) continue;
+      if (a.s_end == T) {
+        if (a.hn) a.hn[((size_t)dir * B + b) * H + unit] = st_h[gi][oi];
+        if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = st_c[gi][oi];
+      } else {
+        a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_c[gi][oi];
+      }
     }
   }
 }
@@ -407,11 +436,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   constexpr int HP = 16 * KS, NQ = C::NQ;
   __shared__ __attribute__((aligned(16))) float ring_all[8][2 * C::SB * 256];
   __shared__ float red[8][16][17];
+  __shared__ float st_carry[GMAX][256], st_dc[GMAX][256];  // per-group recurrent state of the owner lanes
   __shared__ int s_abort;
 
-  const int ug = blockIdx.x, bg = blockIdx.y, dir = blockIdx.z;
+  const int ug = blockIdx.x, by = blockIdx.y, dir = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;
+  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG, G = a.G;
   float* const ring = &ring_all[w][0];
 
   // ---- W_hh^T slice -> registers: A[m = out unit i][k'] = W_hh[gate r * H + unit_k][ug*16 + i]
@@ -430,117 +460,148 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   }
 
   const int mt = w & 3, u_l = lane >> 4, bl = lane & 15;
-  const int unit = ug * 16 + 4 * mt + u_l, b = bg * 16 + bl;
+  const int unit = ug * 16 + 4 * mt + u_l;
   const bool owner = w < 4;
-  const bool cellok = owner && unit < H && b < B;
-  const int len_b = (b < B) ? a.lens[b] : 0;
+  const int oi = (w & 3) * 64 + lane;
   const size_t xblk = (size_t)HP * 64;  // floats per (parity, dir, batch group) exchange block
-  float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
-  float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
   const size_t xoff = ((size_t)unit * 16 + bl) * 4;  // image position of k' = 4*unit + 0..3, row bl
-  const size_t soff = ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit;
-  float* const st_dh = a.state + soff;
-  float* const st_dc = a.state + (size_t)2 * NBG * 16 * HP + soff;
-  unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+  const size_t st2 = (size_t)2 * NBG * 16 * HP;
 
   // carry = gradient wrt h that passes straight through a frozen (padded) step
-  float carry = 0.f, dc_rec = 0.f, dh_rec = 0.f;
-  if (a.s_begin > 0 && owner) {
-    carry = *st_dh;
-    dc_rec = *st_dc;
+  if (owner) {
+    for (int gi = 0; gi < G; ++gi) {
+      const int bg = by * G + gi;
+      float cy = 0.f, dc = 0.f;
+      if (a.s_begin > 0 && bg < NBG) {
+        const size_t soff = ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit;
+        cy = a.state[soff];
+        dc = a.state[st2 + soff];
+      }
+      st_carry[gi][oi] = cy;
+      st_dc[gi][oi] = dc;
+    }
   }
   if (tid == 0) s_abort = 0;
   __syncthreads();
   SK_STAMP_DECL
 
-  for (int s = a.s_begin; s < a.s_end; ++s) {
+  bool aborted = false;
+  for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
-    SK_STAMP(7);
-    const bool valid = cellok && t < len_b;
-    // 1. saved activations of this cell (independent of the recurrence: issue early)
-    float gi = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cprev = 0.f, dyv = 0.f;
-    if (valid) {
-      const float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
-      gi = gp[0];
-      gf = gp[(size_t)H];
-      gg = gp[(size_t)2 * H];
-      go = gp[(size_t)3 * H];
-      ct = a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit];
-      const int tp = dir ? t + 1 : t - 1;
-      const bool has_prev = dir ? (t + 1 < len_b) : (t > 0);
-      cprev = has_prev ? a.cs[(((size_t)tp * B + b) * 2 + dir) * H + unit] : a.c0[((size_t)dir * B + b) * H + unit];
-      dyv = a.dy[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit];
-    }
-    // 2. recurrent gradient from the step processed before this one
-    if (s > 0) {
-      if (s > a.s_begin && w == 0) {
-        if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
+    for (int gi = 0; gi < G; ++gi) {
+      const int bg = by * G + gi;
+      if (bg >= NBG) break;
+      const int b = bg * 16 + bl;
+      const bool cellok = owner && unit < H && b < B;
+      const int len_b = (b < B) ? a.lens[b] : 0;
+      float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
+      float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
+      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+      SK_STAMP(7);
+      const bool valid = cellok && t < len_b;
+      // 1. saved activations of this cell (independent of the recurrence: issue early)
+      float gi_ = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cprev = 0.f, dyv = 0.f;
+      if (valid) {
+        const float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+        gi_ = gp[0];
+        gf = gp[(size_t)H];
+        gg = gp[(size_t)2 * H];
+        go = gp[(size_t)3 * H];
+        ct = a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit];
+        const int tp = dir ? t + 1 : t - 1;
+        const bool has_prev = dir ? (t + 1 < len_b) : (t > 0);
+        cprev = has_prev ? a.cs[(((size_t)tp * B + b) * 2 + dir) * H + unit] : a.c0[((size_t)dir * B + b) * H + unit];
+        dyv = a.dy[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit];
+      }
+      // 2. recurrent gradient from the step processed before this one
+      float dh_rec = 0.f;
+      if (s > 0) {
+        if (s > a.s_begin && w == 0) {
+          if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
+        }
+        __syncthreads();
+        if (s_abort) {
+          aborted = true;
+          break;
+        }
+        SK_STAMP(0);
+        dh_rec = bwd_matmul<KS>(wreg, ((s - 1) & 1) ? xb1 : xb0, ring, red, w, lane);
+        SK_STAMP(2);
+      }
+      // 3. cell backward (owner waves)
+      f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
+      if (owner) {
+        float carry = st_carry[gi][oi], dc_rec = st_dc[gi][oi];
+        dh_rec += carry;
+        if (valid) {
+          const float dh = dyv + dh_rec;
+          const float tc = tanhf(ct);
+          const float dout = dh * tc;
+          const float dc = dc_rec + dh * go * (1.0f - tc * tc);
+          dpre[0] = dc * gg * gi_ * (1.0f - gi_);
+          dpre[1] = dc * cprev * gf * (1.0f - gf);
+          dpre[2] = dc * gi_ * (1.0f - gg * gg);
+          dpre[3] = dout * go * (1.0f - go);
+          dc_rec = dc * gf;
+          carry = 0.f;
+        } else {
+          carry = dh_rec;  // frozen step: h_t = h_{t-1}
+        }
+        st_carry[gi][oi] = carry;
+        st_dc[gi][oi] = dc_rec;
+        // 4. publish dG_s first, in gate-interleaved order: 16 B per cell, 1 KB contiguous per wave ...
+        float* xdst = (s & 1) ? xb1 : xb0;
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
+        SK_STAMP(4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
+        wait_vmcnt<0>();
+        SK_STAMP(5);
       }
       __syncthreads();
-      if (s_abort) break;
-      SK_STAMP(0);
-      dh_rec = bwd_matmul<KS>(wreg, ((s - 1) & 1) ? xb1 : xb0, ring, red, w, lane) + carry;
-      SK_STAMP(2);
-    } else {
-      dh_rec = 0.f;
+      if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+      // 5. ... then the bulk store of the step (dgx, zero at padded positions)
+      if (cellok) {
+        float* dp = a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
+        dp[0] = dpre[0];
+        dp[(size_t)H] = dpre[1];
+        dp[(size_t)2 * H] = dpre[2];
+        dp[(size_t)3 * H] = dpre[3];
+      }
+      SK_STAMP(6);
     }
-    // 3. cell backward (owner waves)
-    f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
-    if (valid) {
-      const float dh = dyv + dh_rec;
-      const float tc = tanhf(ct);
-      const float dout = dh * tc;
-      const float dc = dc_rec + dh * go * (1.0f - tc * tc);
-      dpre[0] = dc * gg * gi * (1.0f - gi);
-      dpre[1] = dc * cprev * gf * (1.0f - gf);
-      dpre[2] = dc * gi * (1.0f - gg * gg);
-      dpre[3] = dout * go * (1.0f - go);
-      dc_rec = dc * gf;
-      carry = 0.f;
-    } else {
-      carry = dh_rec;  // frozen step: h_t = h_{t-1}
-    }
-    // 4. publish dG_s first, in gate-interleaved order: 16 B per cell, 1 KB contiguous per wave ...
-    if (owner) {
-      float* xdst = (s & 1) ? xb1 : xb0;
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
-      SK_STAMP(4);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
-      wait_vmcnt<0>();
-      SK_STAMP(5);
-    }
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
-    // 5. ... then the bulk store of the step (dgx, zero at padded positions)
-    if (cellok) {
-      float* dp = a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
-      dp[0] = dpre[0];
-      dp[(size_t)H] = dpre[1];
-      dp[(size_t)2 * H] = dpre[2];
-      dp[(size_t)3 * H] = dpre[3];
-    }
-    SK_STAMP(6);
   }
   SK_STAMP_FLUSH(a.ctrl);
 
-  if (s_abort) return;
-  if (a.final_mm) {
-    // gradient wrt the initial state: one more product with the last published dG (s_end == T)
-    if (T > a.s_begin && w == 0) {
-      if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane) && lane == 0) s_abort = 1;
+  if (aborted) return;
+  for (int gi = 0; gi < G; ++gi) {
+    const int bg = by * G + gi;
+    if (bg >= NBG) break;
+    const int b = bg * 16 + bl;
+    const bool cellok = owner && unit < H && b < B;
+    if (a.final_mm) {
+      // gradient wrt the initial state: one more product with the last published dG (s_end == T)
+      float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
+      float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
+      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+      if (T > a.s_begin && w == 0) {
+        if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane) && lane == 0) s_abort = 1;
+      }
+      __syncthreads();
+      if (s_abort) return;
+      float dh_rec = bwd_matmul<KS>(wreg, ((T - 1) & 1) ? xb1 : xb0, ring, red, w, lane);
+      if (cellok) {
+        dh_rec += st_carry[gi][oi];
+        if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
+        if (a.dc0) a.dc0[((size_t)dir * B + b) * H + unit] = st_dc[gi][oi];
+      }
+    } else if (owner) {
+      const size_t soff = ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit;
+      a.state[soff] = st_carry[gi][oi];
+      a.state[st2 + soff] = st_dc[gi][oi];
     }
-    __syncthreads();
-    if (s_abort) return;
-    dh_rec = bwd_matmul<KS>(wreg, ((T - 1) & 1) ? xb1 : xb0, ring, red, w, lane) + carry;
-    if (cellok) {
-      if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
-      if (a.dc0) a.dc0[((size_t)dir * B + b) * H + unit] = dc_rec;
-    }
-  } else if (owner) {
-    *st_dh = carry;
-    *st_dc = dc_rec;
   }
 }
+
 
 // hprev[t][b][dir][:] = recurrent input of step (t, dir) for row b (see sk_lstm_hprev)
 __global__ __launch_bounds__(256) void hprev_kernel(const float* __restrict__ y, const float* __restrict__ h0,
@@ -601,6 +662,15 @@ int num_cus() {
   return n;
 }
 
+// Smallest number of batch groups per workgroup for which the whole grid (one workgroup per CU) is
+// co-resident; 0 if even GMAX groups per workgroup do not fit (then the caller launches per step).
+int groups_per_wg(int KS, int NBG) {
+  const int cus = num_cus();
+  for (int g = 1; g <= GMAX; ++g)
+    if (KS * ((NBG + g - 1) / g) * 2 <= cus) return g;
+  return 0;
+}
+
 int check_common(const char* fn, int T, int B, int H, const float* whh, int mode) {
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
@@ -634,10 +704,12 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
-  dim3 grid((unsigned)L.KS, (unsigned)L.NBG, 2);
-  const int nwg = L.KS * L.NBG * 2;
-  const bool fits = nwg <= num_cus();
-  SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode needs %d co-resident workgroups, device has %d CUs", nwg, num_cus());
+  const int G = groups_per_wg(L.KS, L.NBG);
+  const bool fits = G > 0;
+  a.G = fits ? G : 1;
+  const int nby = (L.NBG + a.G - 1) / a.G;
+  dim3 grid((unsigned)L.KS, (unsigned)nby, 2);
+  SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));  // status word + flags
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T;
@@ -668,10 +740,12 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* whh, const float* gates
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
   const int want_d0 = (dh0 || dc0) ? 1 : 0;
-  dim3 grid((unsigned)L.KS, (unsigned)L.NBG, 2);
-  const int nwg = L.KS * L.NBG * 2;
-  const bool fits = nwg <= num_cus();
-  SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_bwd: persistent mode needs %d co-resident workgroups, device has %d CUs", nwg, num_cus());
+  const int G = groups_per_wg(L.KS, L.NBG);
+  const bool fits = G > 0;
+  a.G = fits ? G : 1;
+  const int nby = (L.NBG + a.G - 1) / a.G;
+  dim3 grid((unsigned)L.KS, (unsigned)nby, 2);
+  SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_bwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;

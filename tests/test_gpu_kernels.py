@@ -259,6 +259,8 @@ def _layer_case(T, B, H, I, lens, seed):
     (7, 20, 300, 33, [7] * 5 + [6] * 5 + [4] * 5 + [1] * 5),
     (6, 32, 600, 40, [6] * 16 + [5] * 8 + [2] * 8),
     (4, 32, 896, 24, [4] * 20 + [3] * 12),
+    (5, 100, 600, 20, [5] * 40 + [4] * 30 + [2] * 29 + [1]),     # the reference's default batch: 3 batch groups per workgroup
+    (4, 40, 896, 16, [4] * 17 + [3] * 20 + [1] * 3),             # 3 batch groups over 2 workgroup rows, last one ragged
 ])
 def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
     w, x, h0, c0 = _layer_case(T, B, H, I, lens, seed=T * 100 + H)
