@@ -96,7 +96,9 @@ int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bi
  *   gates (T,B,2,4H)  post-activation i,f,g,o and cs (T,B,2,H) cell states, saved for the
  *                     backward pass (both NULL for inference)
  *   ws    workspace of sk_lstm_workspace_bytes(); zeroed by the call itself
- * mode: 0 auto, 1 persistent (one launch, flag-synchronised time loop), 2 one launch per step. */
+ * mode (low byte): 0 auto, 1 persistent (one launch, flag-synchronised time loop), 2 one launch per step.
+ * mode >> 8: minimum number of 16-row batch groups a workgroup carries (0/1 = as few as fit): a larger
+ * value shrinks the persistent grid, leaving CUs free for kernels running concurrently on other streams. */
 size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 float* y, float* gates, float* cs, float* hn, float* cn, void* ws,

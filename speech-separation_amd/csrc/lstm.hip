@@ -664,9 +664,9 @@ int num_cus() {
 
 // Smallest number of batch groups per workgroup for which the whole grid (one workgroup per CU) is
 // co-resident; 0 if even GMAX groups per workgroup do not fit (then the caller launches per step).
-int groups_per_wg(int KS, int NBG) {
+int groups_per_wg(int KS, int NBG, int gmin) {
   const int cus = num_cus();
-  for (int g = 1; g <= GMAX; ++g)
+  for (int g = (gmin < 1 ? 1 : gmin); g <= GMAX; ++g)
     if (KS * ((NBG + g - 1) / g) * 2 <= cus) return g;
   return 0;
 }
@@ -675,7 +675,7 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG(mode >= 0 && mode <= 2, "%s: unknown mode %d", fn, mode);
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && (mode >> 8) <= GMAX, "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
 
@@ -695,6 +695,8 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   SK_CHECK_ARG(((uintptr_t)h0 % 16) == 0, "sk_lstm_fwd: h0 must be 16-byte aligned");
   int rc = check_common("sk_lstm_fwd", T, B, H, whh, mode);
   if (rc) return rc;
+  const int gmin = mode >> 8;  // bits 8..: minimum batch groups per workgroup (frees CUs for concurrent kernels)
+  mode &= 0xff;
   const WsLayout L = ws_layout(B, H);
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
@@ -704,7 +706,7 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
-  const int G = groups_per_wg(L.KS, L.NBG);
+  const int G = groups_per_wg(L.KS, L.NBG, gmin);
   const bool fits = G > 0;
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
@@ -730,6 +732,8 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* whh, const float* gates
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
   if (rc) return rc;
+  const int gmin = mode >> 8;
+  mode &= 0xff;
   const WsLayout L = ws_layout(B, H);
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
@@ -740,7 +744,7 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* whh, const float* gates
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
   const int want_d0 = (dh0 || dc0) ? 1 : 0;
-  const int G = groups_per_wg(L.KS, L.NBG);
+  const int G = groups_per_wg(L.KS, L.NBG, gmin);
   const bool fits = G > 0;
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;

@@ -103,7 +103,7 @@ def pick_splitk(M, N, K, batch=1):
 
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, accumulate=False, act=0,
-         batch=1, sA=0, sB=0, sC=0, sbias=0, splitk=1):
+         batch=1, sA=0, sB=0, sC=0, sbias=0, splitk=1, ws_tag="gemm"):
     """Cout[M,N] = act(opA(A) opB(B) + bias (+ Cout)).  A/B/Cout are tensors whose data_ptr() is the
     first element of the operand (views are fine: leading dimensions are explicit).  splitk > 1 (or 0 =
     choose) splits K into deterministic partial slabs -- for weight gradients."""
@@ -113,7 +113,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
         splitk = pick_splitk(M, N, K, batch)
     ws = None
     if splitk > 1:
-        ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), "gemm")
+        ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
     with _timed("gemm_f32_kernel", 2.0 * M * N * K * batch):
         _lib.call("sk_gemm_f32_splitk", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA),
                   int(transB), int(accumulate), int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws), _stream())
@@ -258,8 +258,8 @@ def pit_mse_bwd(mask, mix, srcs, best_perm, out, gscale):
 
 
 # ----------------------------------------------------------------------------- BN / column ops
-def bn_ws(R, Ccols):
-    return workspace(_lib.load().sk_bn_workspace_bytes(R, Ccols), "bn")
+def bn_ws(R, Ccols, tag="bn"):
+    return workspace(_lib.load().sk_bn_workspace_bytes(R, Ccols), tag)
 
 
 def bn_stats(x2d, mean, var):
@@ -284,8 +284,8 @@ def bn_bwd(dout, x2d, mean, var, gamma, dx, dgamma, dbeta, eps):
               _ptr(dbeta), _ptr(bn_ws(R, Cc)), R, Cc, float(eps), _stream())
 
 
-def colsum(x, R, Ccols, ld, out, accumulate=False):
-    _lib.call("sk_colsum", _ptr(x), R, Ccols, ld, _ptr(out), int(accumulate), _ptr(bn_ws(R, Ccols)), _stream())
+def colsum(x, R, Ccols, ld, out, accumulate=False, ws_tag="bn"):
+    _lib.call("sk_colsum", _ptr(x), R, Ccols, ld, _ptr(out), int(accumulate), _ptr(bn_ws(R, Ccols, ws_tag)), _stream())
 
 
 def sigmoid_bwd(dmask, m, dz):
