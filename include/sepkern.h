@@ -110,6 +110,12 @@ int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float*
 int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs,
                 const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0, void* ws,
                 int T, int B, int H, int mode, sk_stream_t stream);
+/* Same, with the gradient wrt the final state (dhn, dcn: (2,B,H), either may be NULL = 0) as an extra input:
+ * needed when hn/cn feed a later computation (the RSH arch carries the hidden state from pass to pass,
+ * reference archs/RSH.py:172). */
+int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
+                      const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
+                      void* ws, int T, int B, int H, int mode, sk_stream_t stream);
 /* After a persistent launch has completed: 0, or SK_ETIMEOUT if a bounded spin gave up
  * (reads one word of the workspace back to the host; synchronises the stream). */
 int sk_lstm_status(const void* ws, sk_stream_t stream);
@@ -155,6 +161,26 @@ int sk_pit_mse_fwd(const float* mask, const float* mix, const float* const* src_
 int sk_pit_mse_bwd(const float* mask, const float* mix, const float* const* src_host,
                    const int32_t* best_perm, const float* out, const float* gscale,
                    int T, int B, int F, int S, float* dmask, sk_stream_t stream);
+
+/* ---------------------------------------------------------------- RSH arch (reference archs/RSH.py)
+ * One pass of the greedy source-assignment loss (archs/RSH.py:225-244): mask (T,B,F); x (T,B,ldx) whose
+ * first F columns are the mixture; src_host[r] -> (T,B,F), r < S (host array of device pointers).
+ *   sse (S,B) raw per-source SSE of mask*mix; used (S,B) int32 in/out: sources already assigned to row b are
+ *   excluded; sel (B) = chosen source (first minimum), which is then marked used;
+ *   out[0] = sum_b min / S (this pass's loss term), out[1] = sum(lens)*F (its norm term). */
+size_t sk_rsh_workspace_bytes(int T, int B, int S);
+int sk_rsh_loss_fwd(const float* mask, const float* x, int ldx, const float* const* src_host, const int32_t* lens,
+                    int T, int B, int F, int S, int32_t* used, float* sse, int32_t* sel, float* out, void* ws,
+                    sk_stream_t stream);
+/* dmask = gscale[0] * (2/S) * (mask*mix - src_{sel[b]}) * mix */
+int sk_rsh_loss_bwd(const float* mask, const float* x, int ldx, const float* const* src_host, const int32_t* sel,
+                    const float* gscale, int T, int B, int F, int S, float* dmask, sk_stream_t stream);
+/* Attention update between passes (archs/RSH.py:254-257 / :278-281): x_out = act(x_in - [0 | mask]) on rows of
+ * 2F = [mixture | attention]; act = relu when relu != 0 (training), identity otherwise (test). */
+int sk_att_update(const float* x_in, const float* mask, float* x_out, int64_t rows, int F, int relu, sk_stream_t stream);
+/* dx_in = dx_out * gate, dmask = -(dx_out * gate)[attention half], gate = (x_out > 0) with relu, 1 without */
+int sk_att_update_bwd(const float* dx_out, const float* x_out, float* dx_in, float* dmask, int64_t rows, int F,
+                      int relu, sk_stream_t stream);
 
 /* ---------------------------------------------------------------- clip_grad_norm_ + Adam
  * Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step()

@@ -142,12 +142,14 @@ class _NetFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, anchor, model, x, lens, h0, c0):
     ctx.model = model
-    return model._engine.forward(x, lens, h0, c0, model.training, save=True)
+    mask, _, _, ctx.fwd = model._engine.forward(x, lens, h0, c0, model.training, save=True)
+    return mask
 
   @staticmethod
   def backward(ctx, dmask):
     model = ctx.model
-    model._engine.backward(dmask)
+    model._engine.backward(ctx.fwd, dmask)
+    ctx.fwd = None
     model._allreduce_grads()
     return None, None, None, None, None, None
 
@@ -231,7 +233,7 @@ class SepDNN(nn.Module):
       eng.running_mean, eng.running_var = self.bn.running_mean, self.bn.running_var
       return eng
     with torch.cuda.device(dev):
-      eng = Engine(self.feat_dim, self.num_spk, self.hidden_dim, self.num_layers, dev)
+      eng = Engine(self.feat_dim, self.num_spk * self.feat_dim, self.hidden_dim, self.num_layers, dev)
     with torch.no_grad():
       for p, v in self._named_views(eng, eng.p):
         v.copy_(p.data)
@@ -282,7 +284,7 @@ class SepDNN(nn.Module):
       self.bn.num_batches_tracked += 1
     if torch.is_grad_enabled():
       return _NetFn.apply(self._anchor, self, x, lens, h0, c0)
-    return eng.forward(x, lens, h0, c0, self.training, save=False)
+    return eng.forward(x, lens, h0, c0, self.training, save=False)[0]
 
   def forward(self, x):
     # x: packed sequence of dim feat_dim  ->  tensor of shape (batch, seq_length, feat_dim*num_spk)

@@ -98,6 +98,8 @@ struct BwdArgs {
   float* dgx;
   float* dh0;
   float* dc0;
+  const float* dhn;  // gradient wrt the final state (2,B,H), may be NULL (= 0)
+  const float* dcn;
   float* xbuf;
   float* state;
   unsigned* flags;
@@ -476,6 +478,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
         const size_t soff = ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit;
         cy = a.state[soff];
         dc = a.state[st2 + soff];
+      } else if (bg < NBG && unit < H && bg * 16 + bl < B) {
+        // gradient arriving at the final state: it reaches the last valid step through the frozen ones
+        const size_t o = ((size_t)dir * B + bg * 16 + bl) * H + unit;
+        if (a.dhn) cy = a.dhn[o];
+        if (a.dcn) dc = a.dcn[o];
       }
       st_carry[gi][oi] = cy;
       st_dc[gi][oi] = dc;
@@ -729,6 +736,12 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
 extern "C" int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs, const float* c0,
                            const int32_t* lens, float* dgx, float* dh0, float* dc0, void* ws, int T, int B, int H,
                            int mode, sk_stream_t stream) {
+  return sk_lstm_bwd_state(dy, nullptr, nullptr, whh, gates, cs, c0, lens, dgx, dh0, dc0, ws, T, B, H, mode, stream);
+}
+
+extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const float* whh,
+                                 const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
+                                 float* dh0, float* dc0, void* ws, int T, int B, int H, int mode, sk_stream_t stream) {
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
   if (rc) return rc;
@@ -739,7 +752,7 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* whh, const float* gates
   char* base = (char*)ws;
   BwdArgs a;
   a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens;
-  a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0;
+  a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0; a.dhn = dhn; a.dcn = dcn;
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "sk_lstm_workspace_bytes": (_sz, [_i, _i, _i]),
     "sk_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "sk_lstm_bwd_state": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_status": (_i, [_p, _p]),
     "sk_lstm_hprev": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "sk_bn_workspace_bytes": (_sz, [_i, _i]),
@@ -42,6 +43,11 @@ PROTOTYPES = {
     "sk_pit_workspace_bytes": (_sz, [_i, _i, _i]),
     "sk_pit_mse_fwd": (_i, [_p, _p, C.POINTER(_p), _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "sk_pit_mse_bwd": (_i, [_p, _p, C.POINTER(_p), _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "sk_rsh_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sk_rsh_loss_fwd": (_i, [_p, _p, _i, C.POINTER(_p), _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "sk_rsh_loss_bwd": (_i, [_p, _p, _i, C.POINTER(_p), _p, _p, _i, _i, _i, _i, _p, _p]),
+    "sk_att_update": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
+    "sk_att_update_bwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
     "sk_optim_workspace_bytes": (_sz, [_i64]),
     "sk_grad_norm": (_i, [_p, _i64, _f, _p, _p, _p]),
     "sk_clip_adam": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),

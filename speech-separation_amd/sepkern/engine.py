@@ -26,16 +26,17 @@ class ParamLayout:
     """Offsets (in floats) of every parameter block inside the flat buffer.
 
     Per layer: weight_ih (2,4H,I) | weight_hh (2,4H,H) | bias_ih (2,4H) | bias_hh (2,4H); then
-    lin.weight (S*F, 2H), lin.bias, bn.weight, bn.bias.  Every block starts 16-byte aligned.
+    lin.weight (out_dim, 2H), lin.bias, bn.weight, bn.bias.  Every block starts 16-byte aligned.
+    uPIT: in_dim = F, out_dim = S*F; RSH: in_dim = 2F (mixture | attention), out_dim = F.
     """
 
-    def __init__(self, feat_dim, num_spk, hidden, layers):
-        self.F, self.S, self.H, self.L = feat_dim, num_spk, hidden, layers
+    def __init__(self, in_dim, out_dim, hidden, layers):
+        self.I, self.O, self.H, self.L = in_dim, out_dim, hidden, layers
         self.blocks = {}
         off = 0
         H = hidden
         for l in range(layers):
-            I = feat_dim if l == 0 else 2 * H
+            I = in_dim if l == 0 else 2 * H
             for name, shape in (("weight_ih", (2, 4 * H, I)), ("weight_hh", (2, 4 * H, H)),
                                 ("bias_ih", (2, 4 * H)), ("bias_hh", (2, 4 * H))):
                 n = 1
@@ -43,7 +44,7 @@ class ParamLayout:
                     n *= s
                 self.blocks["%s_l%d" % (name, l)] = (off, shape)
                 off = _align(off + n)
-        for name, shape in (("lin.weight", (num_spk * feat_dim, 2 * H)), ("lin.bias", (num_spk * feat_dim,)),
+        for name, shape in (("lin.weight", (out_dim, 2 * H)), ("lin.bias", (out_dim,)),
                             ("bn.weight", (2 * H,)), ("bn.bias", (2 * H,))):
             n = 1
             for s in shape:
@@ -63,11 +64,11 @@ class ParamLayout:
 class Engine:
     """Forward / backward of the network on one device."""
 
-    def __init__(self, feat_dim, num_spk, hidden, layers, device):
+    def __init__(self, in_dim, out_dim, hidden, layers, device):
         if hidden % 4 != 0 or hidden > 1024:
             raise SepkernError("hidden_dim must be a multiple of 4 and <= 1024 (got %d)" % hidden)
-        self.F, self.S, self.H, self.L = feat_dim, num_spk, hidden, layers
-        self.layout = ParamLayout(feat_dim, num_spk, hidden, layers)
+        self.I, self.O, self.H, self.L = in_dim, out_dim, hidden, layers
+        self.layout = ParamLayout(in_dim, out_dim, hidden, layers)
         self.device = device
         self.flat = torch.zeros(self.layout.total, device=device)
         self.grad = torch.zeros(self.layout.total, device=device)
@@ -83,7 +84,6 @@ class Engine:
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
         self._calls = 0
-        self.ctx = None
 
     def p(self, name):
         return self.layout.view(self.flat, name)
@@ -102,18 +102,22 @@ class Engine:
             ops.lstm_status(ws)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, lens, h0, c0, training, save):
-        """x (T,B,F) fp32, lens int32 (B) on device, h0/c0 (2L,B,H) -> mask (T,B,S*F)."""
-        T, B, F = x.shape
-        if F != self.F:
-            raise SepkernError("feature dim %d != model feat_dim %d" % (F, self.F))
-        H, L, S = self.H, self.L, self.S
+    def forward(self, x, lens, h0, c0, training, save, want_state=False):
+        """x (T,B,in_dim) fp32, lens int32 (B) on device, h0/c0 (2L,B,H) ->
+        (mask (T,B,out_dim), hn, cn (2L,B,H) or None, ctx or None).  ctx feeds backward(); several may be alive
+        (the RSH arch runs the network num_spk times per batch)."""
+        T, B, I0 = x.shape
+        if I0 != self.I:
+            raise SepkernError("input feature dim %d != model input dim %d" % (I0, self.I))
+        H, L, O = self.H, self.L, self.O
         R = T * B
         x = x.contiguous()
         dev = x.device
         saved = []
-        inp, I = x, F
+        inp, I = x, I0
         ws = None
+        hn = torch.empty(2 * L, B, H, device=dev) if want_state else None
+        cn = torch.empty(2 * L, B, H, device=dev) if want_state else None
         for l in range(L):
             wih = self.p("weight_ih_l%d" % l)
             whh = self.p("weight_hh_l%d" % l)
@@ -126,7 +130,8 @@ class Engine:
             y = torch.empty(T, B, 2 * H, device=dev)
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
             ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
-                              None, None, T, B, H, self.lstm_mode)
+                              hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
+                              T, B, H, self.lstm_mode)
             saved.append((inp, gx, cs, y))
             inp, I = y, 2 * H
         self._check_status(ws)
@@ -140,24 +145,24 @@ class Engine:
             mean, var = self.running_mean, self.running_var
         xbn = torch.empty(R, 2 * H, device=dev)
         ops.bn_apply(y2d, mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
-        mask = torch.empty(T, B, S * F, device=dev)
-        ops.gemm(xbn, self.p("lin.weight"), mask, R, S * F, 2 * H, 2 * H, 2 * H, S * F, transB=True,
+        mask = torch.empty(T, B, O, device=dev)
+        ops.gemm(xbn, self.p("lin.weight"), mask, R, O, 2 * H, 2 * H, 2 * H, O, transB=True,
                  bias=self.p("lin.bias"), act=1)
+        ctx = None
         if save:
-            self.ctx = dict(saved=saved, mean=mean, var=var, xbn=xbn, mask=mask, lens=lens, h0=h0, c0=c0,
-                            T=T, B=B, training=training)
-        return mask
+            ctx = dict(saved=saved, mean=mean, var=var, xbn=xbn, mask=mask, lens=lens, h0=h0, c0=c0,
+                       T=T, B=B, training=training)
+        return mask, hn, cn, ctx
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dmask):
-        """Gradient of every parameter from dmask (T,B,S*F); consumes the context of the last forward."""
-        ctx = self.ctx
+    def backward(self, ctx, dmask, dhn=None, dcn=None, want_dx=False, want_dstate=False):
+        """Parameter gradients (into the flat gradient buffer) from dmask (T,B,out_dim) and, optionally, the
+        gradient wrt the final state (dhn, dcn (2L,B,H)).  Returns (dx (T,B,in_dim) or None, dh0, dc0 or None)."""
         if ctx is None:
             raise SepkernError("backward called without a saved forward")
         if not ctx["training"]:
             raise SepkernError("backward through eval-mode BatchNorm is not built")
-        self.ctx = None
-        T, B, H, L, S, F = ctx["T"], ctx["B"], self.H, self.L, self.S, self.F
+        T, B, H, L, O, I0 = ctx["T"], ctx["B"], self.H, self.L, self.O, self.I
         R = T * B
         dev = dmask.device
         acc = not self.grads_fresh
@@ -172,11 +177,11 @@ class Engine:
 
         dz = torch.empty_like(dmask)
         ops.sigmoid_bwd(dmask, ctx["mask"], dz)
-        ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), S * F, 2 * H, R, S * F, 2 * H, 2 * H, transA=True, accumulate=acc,
+        ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), O, 2 * H, R, O, 2 * H, 2 * H, transA=True, accumulate=acc,
                  splitk=0)
-        ops.colsum(dz, R, S * F, S * F, self.g("lin.bias"), accumulate=acc)
+        ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc)
         dxbn = torch.empty(R, 2 * H, device=dev)
-        ops.gemm(dz, self.p("lin.weight"), dxbn, R, 2 * H, S * F, S * F, 2 * H, 2 * H)
+        ops.gemm(dz, self.p("lin.weight"), dxbn, R, 2 * H, O, O, 2 * H, 2 * H)
         del dz
         y_top = ctx["saved"][-1][3].view(R, 2 * H)
         dy = torch.empty(R, 2 * H, device=dev)
@@ -187,6 +192,9 @@ class Engine:
         put("bn.bias", dbeta)
         del dxbn
         ws = None
+        dh0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
+        dc0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
+        dx = None
         overlap = self.overlap and L > 1 and self.lstm_mode == 0
         if overlap and self.side is None:
             self.side = torch.cuda.Stream(device=dev)
@@ -194,15 +202,20 @@ class Engine:
         keep = []                                        # tensors used on the side stream stay alive until the join
         for l in range(L - 1, -1, -1):
             inp, gates, cs, y = ctx["saved"][l]
-            I = F if l == 0 else 2 * H
+            I = I0 if l == 0 else 2 * H
             whh = self.p("weight_hh_l%d" % l)
             dgx = gates                                  # overwritten in place, cell by cell
             # with weight-gradient GEMMs in flight on the side stream, carry 2 batch groups per workgroup
             mode = self.lstm_mode | ((2 << 8) if (overlap and l < L - 1) else 0)
-            ws = ops.lstm_bwd(dy, whh, gates, cs, c0[2 * l:2 * l + 2], lens, dgx, None, None, T, B, H, mode)
-            if l > 0:                                    # the only product the next recurrence waits for
+            sl = slice(2 * l, 2 * l + 2)
+            ws = ops.lstm_bwd(dy, whh, gates, cs, c0[sl], lens, dgx, dh0[sl] if want_dstate else None,
+                              dc0[sl] if want_dstate else None, T, B, H, mode,
+                              dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None)
+            if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, I, device=dev)
                 ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy_next, R, I, 8 * H, 8 * H, I, I)
+                if l == 0:
+                    dx = dy_next.view(T, B, I)
             stream = self.side if (overlap and l > 0) else main
             if stream is not main:
                 stream.wait_stream(main)
@@ -228,3 +241,4 @@ class Engine:
         del keep
         self._check_status(ws)
         self.grads_fresh = False
+        return dx, dh0, dc0

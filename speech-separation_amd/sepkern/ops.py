@@ -257,6 +257,55 @@ def pit_mse_bwd(mask, mix, srcs, best_perm, out, gscale):
     return dmask
 
 
+# ----------------------------------------------------------------------------- RSH loss / attention
+def rsh_loss_fwd(mask, x, srcs, lens, used):
+    """One greedy-assignment pass.  mask (T,B,F), x (T,B,2F) [mixture | attention], srcs list of S (T,B,F),
+    used (S,B) int32 (updated in place) -> dict(out (2,) = [loss term, norm term], sse (S,B), sel (B))."""
+    T, B, F = mask.shape
+    S = len(srcs)
+    for t in [mask, x] + list(srcs):
+        _chk(t)
+        if not t.is_contiguous():
+            raise _lib.SepkernError("rsh_loss needs contiguous tensors")
+    _chk(lens, torch.int32)
+    _chk(used, torch.int32)
+    dev = mask.device
+    sse = torch.empty(S, B, device=dev)
+    sel = torch.empty(B, dtype=torch.int32, device=dev)
+    out = torch.empty(2, device=dev)
+    ws = workspace(_lib.load().sk_rsh_workspace_bytes(T, B, S), "rsh")
+    sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
+    _lib.call("sk_rsh_loss_fwd", _ptr(mask), _ptr(x), x.shape[2], sp, _ptr(lens), T, B, F, S, _ptr(used), _ptr(sse),
+              _ptr(sel), _ptr(out), _ptr(ws), _stream())
+    return dict(out=out, sse=sse, sel=sel)
+
+
+def rsh_loss_bwd(mask, x, srcs, sel, gscale):
+    T, B, F = mask.shape
+    S = len(srcs)
+    dmask = torch.empty_like(mask)
+    sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
+    _chk(gscale)
+    _lib.call("sk_rsh_loss_bwd", _ptr(mask), _ptr(x), x.shape[2], sp, _ptr(sel), _ptr(gscale), T, B, F, S, _ptr(dmask),
+              _stream())
+    return dmask
+
+
+def att_update(x, mask, relu):
+    out = torch.empty_like(x)
+    F = mask.shape[-1]
+    _lib.call("sk_att_update", _ptr(x), _ptr(mask), _ptr(out), x.numel() // (2 * F), F, int(relu), _stream())
+    return out
+
+
+def att_update_bwd(dx_out, x_out, F, relu):
+    dx_in = torch.empty_like(dx_out)
+    dmask = torch.empty(dx_out.shape[:-1] + (F,), device=dx_out.device)
+    _lib.call("sk_att_update_bwd", _ptr(dx_out), _ptr(x_out), _ptr(dx_in), _ptr(dmask), dx_out.numel() // (2 * F), F,
+              int(relu), _stream())
+    return dx_in, dmask
+
+
 # ----------------------------------------------------------------------------- BN / column ops
 def bn_ws(R, Ccols, tag="bn"):
     return workspace(_lib.load().sk_bn_workspace_bytes(R, Ccols), tag)
@@ -308,11 +357,11 @@ def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0):
     return ws
 
 
-def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0):
+def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=None, dcn=None):
     ws = lstm_ws(T, B, H)
     with _timed("lstm_bwd_kernel", 2.0 * T * B * 2 * 4 * H * H):
-        _lib.call("sk_lstm_bwd", _ptr(dy), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0), _ptr(lens), _ptr(dgx), _ptr(dh0),
-                  _ptr(dc0), _ptr(ws), T, B, H, mode, _stream())
+        _lib.call("sk_lstm_bwd_state", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
+                  _ptr(lens), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(ws), T, B, H, mode, _stream())
     return ws
 
 

@@ -31,6 +31,17 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def load_reference_rsh():
+    """archs/RSH.py with the same three shims as uPIT (numpy_type_map import, collections.Mapping, .cuda())."""
+    load_reference_upit()                      # installs the shims and the plot stub
+    src = open(os.path.join(REF, "archs/RSH.py")).read()
+    src = src.replace("from torch.utils.data.dataloader import default_collate, numpy_type_map",
+                      "from torch.utils.data.dataloader import default_collate")
+    mod = types.ModuleType("ref_RSH")
+    exec(compile(src, os.path.join(REF, "archs/RSH.py"), "exec"), mod.__dict__)
+    return mod
+
+
 def load_reference_upit():
     collections.Mapping = collections.abc.Mapping
     torch.Tensor.cuda = lambda self, *a, **k: self
@@ -78,6 +89,87 @@ def capture_hidden(model):
         return h
     model.init_hidden = wrapped
     return rec
+
+
+def rsh_samples(rng, spec, feat_dim, test=False):
+    """spec: list of (T, num_spk).  'combo' = [mixture | ones] as TrainSet/TestSet build it (archs/RSH.py:104-106)."""
+    out = []
+    for i, (T, n) in enumerate(spec):
+        mix = np.abs(rng.standard_normal((T, feat_dim))).astype(np.float32)
+        d = {"combo": np.concatenate((mix, np.ones(mix.shape)), axis=1)}
+        if test:
+            d["name"] = "utt%02d.npz" % i
+            d["num_spk"] = n
+        else:
+            for s in range(n):
+                d["source%d" % (s + 1)] = (np.abs(rng.standard_normal((T, feat_dim))) * 0.6).astype(np.float32)
+        out.append(d)
+    return out
+
+
+def main_rsh():
+    m = load_reference_rsh()
+    torch.set_num_threads(4)
+    spec = [(9, 2), (7, 3), (11, 2), (8, 3), (7, 2)]
+    # ---- training loss + grads over a mixed 2-/3-speaker batch
+    torch.manual_seed(2024)
+    model = m.SepDNN(-1)
+    model.train()
+    hid = []
+    orig = model.init_hidden
+    model.init_hidden = lambda b: hid.append(orig(b)) or hid[-1]
+    rng = np.random.default_rng(2024)
+    samples = rsh_samples(rng, spec, 257)
+    batch = m.Collator("combo")(samples)
+    loss, norm = m.compute_loss(model, 0, batch)
+    loss.backward()
+    fx = {"seed": np.array(2024), "spec": np.array(spec), "loss": loss.detach().numpy(), "norm": norm.detach().numpy(),
+          "sub_batch_lens": np.array(batch.sub_batch_lens),
+          "running_mean": model.bn.running_mean.numpy().copy(), "running_var": model.bn.running_var.numpy().copy(),
+          "num_batches_tracked": model.bn.num_batches_tracked.numpy().copy()}
+    for j, (h, c) in enumerate(hid):
+        fx["h0_%d" % j], fx["c0_%d" % j] = h.numpy(), c.numpy()
+    for i, d in enumerate(samples):
+        for k, v in d.items():
+            fx["sample%d_%s" % (i, k)] = v.astype(np.float32)
+    for k, v in param_checksums(model).items():
+        fx["wsum_" + k] = v
+    for k, p in model.named_parameters():
+        g = p.grad
+        fx["gnorm_" + k] = np.array(float(g.double().norm()))
+        flat = g.flatten()
+        fx["gslice_" + k] = flat[:: max(1, flat.numel() // 64)][:64].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "ref_rsh_loss.npz"), **fx)
+
+    # ---- compute_masks (eval mode, running stats, no relu in the attention update)
+    torch.manual_seed(555)
+    model = m.SepDNN(-1)
+    with torch.no_grad():
+        model.bn.running_mean.normal_(0.0, 0.05)
+        model.bn.running_var.uniform_(0.5, 1.5)
+    model.eval()
+    hid = []
+    orig = model.init_hidden
+    model.init_hidden = lambda b: hid.append(orig(b)) or hid[-1]
+    rng = np.random.default_rng(555)
+    tspec = [(8, 2), (6, 3), (10, 2)]
+    samples = rsh_samples(rng, tspec, 257, test=True)
+    batch = m.Collator("combo")(samples)
+    outdir = "/tmp/ref_rsh_masks_fixture"
+    os.makedirs(outdir, exist_ok=True)
+    with torch.no_grad():
+        m.compute_masks(model, batch, outdir)
+    fx = {"seed": np.array(555), "spec": np.array(tspec), "running_mean": model.bn.running_mean.numpy(),
+          "running_var": model.bn.running_var.numpy()}
+    for j, (h, c) in enumerate(hid):
+        fx["h0_%d" % j], fx["c0_%d" % j] = h.numpy(), c.numpy()
+    for i, d in enumerate(samples):
+        fx["sample%d_combo" % i] = d["combo"].astype(np.float32)
+        z = np.load(os.path.join(outdir, d["name"]))
+        for k in z.files:
+            fx["mask_%s_%s" % (d["name"], k)] = z[k]
+    np.savez_compressed(os.path.join(HERE, "ref_rsh_masks.npz"), **fx)
+    print("rsh fixtures written: loss", float(loss), "norm", float(norm))
 
 
 def main():
@@ -182,4 +274,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rsh":
+        main_rsh()
+    else:
+        main()
+        main_rsh()
