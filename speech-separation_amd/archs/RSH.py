@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Recurrent-selective-hearing arch plug-in, MI355X-native: drop-in for the reference's archs/RSH.py.
+
+Same module-level protocol as archs/uPIT.py (TrainSet, TestSet, .collator, SepDNN, compute_loss,
+compute_cv_loss, compute_masks).  One mask is estimated per pass of a BLSTM over [mixture | attention]
+(2F inputs, F outputs); the attention is reduced by each estimated mask and the LSTM state is carried from
+pass to pass (reference archs/RSH.py:172,209), so the backward pass chains through both -- which is why the
+BLSTM kernels take dhn/dcn and return dx, dh0, dc0 (sepkern.model.NetFn).  Per-pass loss is the greedy
+not-yet-used-source minimum (archs/RSH.py:225-244, sk_rsh_loss_fwd/bwd); the attention update is
+relu(att - mask) in training and att - mask at test time (archs/RSH.py:254-257, 278-281, sk_att_update).
+Conf keys beyond the reference: hidden_dim (600), num_layers (2).  There is no CPU path.
+"""
+import collections.abc
+import os
+import re
+import shutil
+import sys
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pack_sequence
+from torch.utils.data import Dataset
+from torch.utils.data.dataloader import default_collate
+
+try:
+    import sepkern  # noqa: F401
+except ImportError:  # the frozen copy exp/<...>/arch.py is imported from another directory
+    for cand in (os.environ.get("SEPKERN_HOME"), "speech-separation_amd",
+                 os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")):
+        if cand and os.path.isdir(os.path.join(cand, "sepkern")):
+            sys.path.insert(0, os.path.abspath(cand))
+            break
+    import sepkern  # noqa: F401
+from sepkern import dist as skdist
+from sepkern import ops
+from sepkern.model import SepDNNBase, to_padded as _to_padded
+
+
+class MultiSpkBatch():
+  """sub_batches[k]: the samples that have k sources, collated like a uPIT batch (archs/RSH.py:70-85)."""
+
+  def __init__(self, max_spk, length):
+    self.sub_batches = list()
+    self.sub_batch_lens = list()
+    self.max_spk = max_spk
+    self.length = length
+
+  def __len__(self):
+    return self.length
+
+  def __getitem__(self, idx):
+    return self.sub_batches[idx]
+
+  def append(self, elem):
+    self.sub_batches.append(elem)
+
+
+# Define collating function (that constructs packed sequences from a batch)
+class Collator():
+  """Groups a batch by speaker count ('num_spk' entry at test time, number of source keys otherwise) and
+  collates every group as archs/uPIT.py does (reference archs/RSH.py:21-68)."""
+
+  def __init__(self, sort_key):
+    self.key = sort_key
+
+  def collate_sub_batch(self, batch):
+    if isinstance(batch[0], collections.abc.Mapping):
+      sort_inds = np.argsort(np.array([len(d[self.key]) for d in batch]))[::-1]
+      return {key: self.collate_sub_batch([batch[i][key] for i in sort_inds]) for key in batch[0]}
+    if isinstance(batch[0], np.ndarray):
+      if re.search('[SaUO]', batch[0].dtype.str) is not None:
+        raise TypeError("batch must contain tensors, numbers, dicts or lists; found {}".format(batch[0].dtype))
+      return pack_sequence([(torch.from_numpy(b)).float() for b in batch])
+    return default_collate(batch)
+
+  def __call__(self, batch):
+    if not self.key:
+      return default_collate(batch)
+    if "num_spk" in batch[0].keys():
+      counts = [int(d["num_spk"]) for d in batch]
+    else:
+      counts = [len(d.keys()) - 1 for d in batch]
+    max_spk = max(counts)
+    batch_out = MultiSpkBatch(max_spk + 1, len(batch))
+    for num_spk in range(max_spk + 1):
+      inds = [i for i in range(len(batch)) if counts[i] == num_spk]
+      batch_out.sub_batch_lens.append(len(inds))
+      batch_out.append(self.collate_sub_batch([batch[i] for i in inds]) if inds else {})
+    return batch_out
+
+
+def _read_scp(path):
+  return [line.rstrip('\n').split(' ')[1] for line in open(path)]
+
+
+def _combo(mix_mag_spec):
+  # [mixture | attention mask of ones] (archs/RSH.py:104-106)
+  return np.concatenate((mix_mag_spec, np.ones(mix_mag_spec.shape)), axis=1)
+
+
+# Define dataset
+class TrainSet(Dataset):
+
+  def __init__(self, datadir, location=""):
+    self.list = _read_scp(datadir + "/feats_train.scp")
+    if location:
+      staged = []
+      for path in self.list:
+        dst = location + '/' + path
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        if not os.path.exists(dst):
+          shutil.copy2(path, dst)
+        staged.append(dst)
+      self.list = staged
+    self.collator = Collator('combo')
+
+  def __len__(self):
+    return len(self.list)
+
+  def __getitem__(self, idx):
+    feat = np.load(self.list[idx])
+    mix_mag_spec = feat['mix'].transpose()
+    sample = {'combo': _combo(mix_mag_spec)}
+    if len(feat.files) == 1:
+      sample["source1"] = mix_mag_spec
+    else:
+      for src in range(len(feat.files) - 1):
+        sample["source" + str(src + 1)] = feat['s' + str(src + 1)].transpose()
+    return sample
+
+
+class TestSet(Dataset):
+
+  def __init__(self, datadir):
+    self.list = _read_scp(datadir + "/feats_test.scp")
+    self.num_spks = [int(line.rstrip('\n').split(' ')[1]) for line in open(datadir + "/utt2num_spk")]
+    self.collator = Collator('combo')
+
+  def __len__(self):
+    return len(self.list)
+
+  def __getitem__(self, idx):
+    mix_mag_spec = np.abs(np.load(self.list[idx])['mix']).transpose()
+    return {'combo': _combo(mix_mag_spec), 'name': os.path.basename(self.list[idx]), 'num_spk': self.num_spks[idx]}
+
+
+class _PassLossFn(torch.autograd.Function):
+  """One pass of the greedy assignment loss: out = [sum_b min / num_spk, sum(lens) * F]."""
+
+  @staticmethod
+  def forward(ctx, mask, x, lens, used, *srcs):
+    res = ops.rsh_loss_fwd(mask, x, list(srcs), lens, used)
+    ctx.save_for_backward(mask, x, res["sel"], *srcs)
+    ctx.mark_non_differentiable(res["sel"])
+    return res["out"], res["sel"]
+
+  @staticmethod
+  def backward(ctx, gout, _gsel):
+    mask, x, sel = ctx.saved_tensors[:3]
+    srcs = list(ctx.saved_tensors[3:])
+    dmask = ops.rsh_loss_bwd(mask, x, srcs, sel, gout[0:1].contiguous())
+    return (dmask, None, None, None) + (None,) * len(srcs)
+
+
+class _AttFn(torch.autograd.Function):
+  """combos <- act(combos - [0 | mask]); act = relu in training (archs/RSH.py:254-257), identity at test."""
+
+  @staticmethod
+  def forward(ctx, x, mask, relu):
+    out = ops.att_update(x, mask, relu)
+    ctx.save_for_backward(out)
+    ctx.relu, ctx.F = relu, mask.shape[-1]
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    (out,) = ctx.saved_tensors
+    dx, dmask = ops.att_update_bwd(dout.contiguous(), out, ctx.F, ctx.relu)
+    return dx, dmask, None
+
+
+# define nnet
+class SepDNN(SepDNNBase):
+  def __init__(self, gpuid, **kwargs):
+    super(SepDNN, self).__init__()
+    self.feat_dim = int(kwargs.get('feat_dim', 257))
+    for key in kwargs.keys():
+      print('modelparam:', key, kwargs[key])
+    self._build(gpuid, self.feat_dim * 2, self.feat_dim, int(kwargs.get('hidden_dim', 600)),
+                int(kwargs.get('num_layers', 2)))
+
+  def forward_padded(self, x, lens):
+    """x (T,B,2F) -> mask (T,B,F); self.hidden is replaced by the LSTM's final state (archs/RSH.py:172)."""
+    h0, c0 = self.hidden
+    mask, hn, cn = self.run_net(x, lens, h0, c0, want_state=True)
+    self.hidden = (hn, cn)
+    return mask
+
+  def forward(self, x):
+    xp, lens = _to_padded(x, self.lin.weight.device)
+    return self.forward_padded(xp, lens).permute(1, 0, 2)
+
+
+def compute_cv_loss(model, epoch, batch_sample, plotdir=""):
+  if plotdir:
+    loss, norm = compute_loss(model, epoch, batch_sample, plotdir)
+  else:
+    loss, norm = compute_loss(model, epoch, batch_sample)
+  return loss, norm
+
+
+# define training pass
+def compute_loss(model, epoch, batch_sample, plotdir=""):
+  dev = model.lin.weight.device
+  F = model.feat_dim
+  model.zero_grad()
+  loss = 0
+  norm = 0
+
+  for num_spk in range(batch_sample.max_spk):
+    if batch_sample.sub_batch_lens[num_spk] > 0:
+      batch = batch_sample.sub_batch_lens[num_spk]
+      combos, lens = _to_padded(batch_sample[num_spk]['combo'], dev)
+      # combos: (seq_length, batch, feat_dim*2)
+      model.hidden = model.init_hidden(batch)
+      sources = [_to_padded(batch_sample[num_spk]['source' + str(i + 1)], dev)[0] for i in range(num_spk)]
+      used = torch.zeros(num_spk, batch, dtype=torch.int32, device=dev)       # source_usage of archs/RSH.py:218
+      for dnn_pass in range(num_spk):
+        mask_out = model.forward_padded(combos, lens)
+        # mask_out: (seq_length, batch, feat_dim)
+        out, sel = _PassLossFn.apply(mask_out, combos, lens, used, *sources)
+        loss = loss + out[0]
+        norm = norm + out[1].detach()
+        if plotdir:
+          sys.path.append('tools')
+          import plot
+          os.system("mkdir -p " + plotdir)
+          c0 = combos[:, 0].detach().cpu().numpy()
+          prefix = plotdir + '/' + str(num_spk) + '-Spk_Pass-' + str(dnn_pass + 1) + '_'
+          if dnn_pass == 0:
+            plot.plot_spec(c0[:, 0:F], plotdir + '/' + str(num_spk) + '-Spk_Mix.png')
+          plot.plot_spec(c0, prefix + 'Input.png')
+          plot.plot_spec(mask_out[:, 0].detach().cpu().numpy(), prefix + 'Mask_Out.png')
+          plot.plot_spec((mask_out[:, 0] * combos[:, 0, :F]).detach().cpu().numpy(), prefix + 'Masked_Mix.png')
+          plot.plot_spec(sources[int(sel[0])][:, 0].cpu().numpy(), prefix + 'Chosen_Source.png')
+        combos = _AttFn.apply(combos, mask_out, True)
+
+  # data-parallel: the global frame count normalises every rank's loss (sepkern.dist)
+  if skdist.is_parallel():
+    gn = norm.reshape(1).clone()
+    torch.distributed.all_reduce(gn)
+    norm = gn[0]
+  return loss / norm, norm
+
+
+# define test pass
+def compute_masks(model, batch_sample, out_dir):
+  dev = model.lin.weight.device
+  model.zero_grad()
+
+  for num_spk in range(batch_sample.max_spk):
+    if batch_sample.sub_batch_lens[num_spk] > 0:
+      batch = batch_sample.sub_batch_lens[num_spk]
+      combos, lens = _to_padded(batch_sample[num_spk]['combo'], dev)
+      name = batch_sample[num_spk]['name']
+      model.hidden = model.init_hidden(batch)
+      lens_h = lens.cpu().numpy()
+      dicts = [dict() for _ in range(batch)]
+      with torch.no_grad():
+        for dnn_pass in range(num_spk):
+          mask_out = model.forward_padded(combos, lens)
+          combos = ops.att_update(combos, mask_out, False)
+          mask_np = mask_out.permute(1, 0, 2).cpu().numpy()
+          for i in range(batch):
+            dicts[i]['s' + str(dnn_pass + 1)] = mask_np[i].transpose()[:, 0:lens_h[i]]
+      for i in range(batch):
+        np.savez_compressed(out_dir + '/' + name[i], **(dicts[i]))

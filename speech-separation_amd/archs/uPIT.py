@@ -47,7 +47,7 @@ except ImportError:  # the frozen copy exp/<...>/arch.py is imported from anothe
     import sepkern  # noqa: F401
 from sepkern import dist as skdist
 from sepkern import ops
-from sepkern.engine import Engine
+from sepkern.model import SepDNNBase, to_padded as _to_padded
 from sepkern._lib import SepkernError
 
 
@@ -131,29 +131,6 @@ class TestSet(Dataset):
     return {'mix': mix_mag_spec, 'name': os.path.basename(self.list[idx])}
 
 
-class _Params(nn.Module):
-  """A bag of named parameters/buffers (keeps the reference's state_dict keys, e.g. blstm.weight_ih_l0)."""
-
-
-class _NetFn(torch.autograd.Function):
-  """mask = net(x); backward runs the libsepkern backward kernels and leaves the gradients in the
-  flat gradient buffer that every param.grad is a view of."""
-
-  @staticmethod
-  def forward(ctx, anchor, model, x, lens, h0, c0):
-    ctx.model = model
-    mask, _, _, ctx.fwd = model._engine.forward(x, lens, h0, c0, model.training, save=True)
-    return mask
-
-  @staticmethod
-  def backward(ctx, dmask):
-    model = ctx.model
-    model._engine.backward(ctx.fwd, dmask)
-    ctx.fwd = None
-    model._allreduce_grads()
-    return None, None, None, None, None, None
-
-
 class _PitFn(torch.autograd.Function):
   """out = [loss/norm, norm, sum_b min_p L/S] (reference archs/uPIT.py:181-197,206)."""
 
@@ -173,131 +150,28 @@ class _PitFn(torch.autograd.Function):
 
 
 # define nnet
-class SepDNN(nn.Module):
+class SepDNN(SepDNNBase):
   def __init__(self, gpuid, **kwargs):
     super(SepDNN, self).__init__()
-    self.gpuid = gpuid
-    if int(gpuid) < 0:
-      raise SepkernError("SepDNN(gpuid=%s): this build has no CPU path; it runs on an MI355X only" % gpuid)
     self.feat_dim = int(kwargs.get('feat_dim', 257))
     self.num_spk = int(kwargs.get('num_spk', 2))
-    self.hidden_dim = int(kwargs.get('hidden_dim', 600))
-    self.num_layers = int(kwargs.get('num_layers', 2))
     for key in kwargs.keys():
       print('modelparam:', key, kwargs[key])
-    H, L = self.hidden_dim, self.num_layers
-
-    # Initial values exactly as the reference draws them (archs/uPIT.py:115-119: nn.LSTM, nn.Linear,
-    # nn.BatchNorm1d constructed in this order consume the RNG identically); the modules are only
-    # used as initialisers, the kernels never call them.
-    init_lstm = nn.LSTM(self.feat_dim, H, num_layers=L, bidirectional=True)
-    init_lin = nn.Linear(H * 2, self.feat_dim * self.num_spk)
-    init_bn = nn.BatchNorm1d(H * 2)
-    self.blstm = _Params()
-    for name, p in init_lstm.named_parameters():
-      self.blstm.register_parameter(name, nn.Parameter(p.detach().clone()))
-    self.lin = _Params()
-    self.lin.register_parameter('weight', nn.Parameter(init_lin.weight.detach().clone()))
-    self.lin.register_parameter('bias', nn.Parameter(init_lin.bias.detach().clone()))
-    self.bn = _Params()
-    self.bn.register_parameter('weight', nn.Parameter(init_bn.weight.detach().clone()))
-    self.bn.register_parameter('bias', nn.Parameter(init_bn.bias.detach().clone()))
-    self.bn.register_buffer('running_mean', init_bn.running_mean.clone())
-    self.bn.register_buffer('running_var', init_bn.running_var.clone())
-    self.bn.register_buffer('num_batches_tracked', init_bn.num_batches_tracked.clone())
-
-    self.hidden = None
-    self.next_hidden = None          # tests: (h0, c0) used by the next init_hidden call
-    self.hidden_generator = None
-    self._engine = None
-    self._anchor = None
-
-  # ---- parameter storage: every nn.Parameter is a view into the engine's flat buffer
-  def _named_views(self, eng, flat_view):
-    for l in range(self.num_layers):
-      for d, sfx in enumerate(("", "_reverse")):
-        for base in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
-          yield getattr(self.blstm, "%s_l%d%s" % (base, l, sfx)), flat_view("%s_l%d" % (base, l))[d]
-    yield self.lin.weight, flat_view("lin.weight")
-    yield self.lin.bias, flat_view("lin.bias")
-    yield self.bn.weight, flat_view("bn.weight")
-    yield self.bn.bias, flat_view("bn.bias")
-
-  def _bind(self):
-    """(Re)attach parameters to the flat buffers; cheap when already bound."""
-    dev = self.lin.weight.device
-    if dev.type != 'cuda':
-      raise SepkernError("SepDNN must be moved to the GPU (model.cuda()) before use; there is no CPU path")
-    eng = self._engine
-    if eng is not None and eng.device == dev and self.lin.weight.data_ptr() == eng.p("lin.weight").data_ptr():
-      eng.running_mean, eng.running_var = self.bn.running_mean, self.bn.running_var
-      return eng
-    with torch.cuda.device(dev):
-      eng = Engine(self.feat_dim, self.num_spk * self.feat_dim, self.hidden_dim, self.num_layers, dev)
-    with torch.no_grad():
-      for p, v in self._named_views(eng, eng.p):
-        v.copy_(p.data)
-        p.data = v
-      for p, gv in self._named_views(eng, eng.g):
-        if p.grad is not None:
-          gv.copy_(p.grad)
-        p.grad = gv
-    eng.running_mean, eng.running_var = self.bn.running_mean, self.bn.running_var
-    self._engine = eng
-    self._anchor = torch.zeros(1, device=dev, requires_grad=True)
-    return eng
-
-  def zero_grad(self, set_to_none=False):
-    # gradients stay views of the flat buffer; the next backward overwrites them
-    if self._engine is not None:
-      self._engine.zero_grad()
-    else:
-      super(SepDNN, self).zero_grad(set_to_none=False)
-
-  def flat_parameters(self):
-    """(params, grads): the two flat fp32 buffers (for sepkern.optim.ClipAdam and the DP all-reduce)."""
-    eng = self._bind()
-    return eng.flat, eng.grad
-
-  def _allreduce_grads(self):
-    skdist.allreduce_grads(self._engine.grad)       # one RCCL collective over the whole gradient
-
-  def init_hidden(self, batch_size):
-    """h0, c0 ~ N(0,1), shape (2L, B, H), fresh for every batch (reference archs/uPIT.py:121-127)."""
-    if self.next_hidden is not None:
-      h, self.next_hidden = self.next_hidden, None
-      return h
-    dev = self.lin.weight.device
-    shape = (2 * self.num_layers, batch_size, self.hidden_dim)
-    return (torch.randn(shape, device=dev, generator=self.hidden_generator),
-            torch.randn(shape, device=dev, generator=self.hidden_generator))
+    # the reference hard-codes 2 x 600 (archs/uPIT.py:115-119); hidden_dim / num_layers widen it
+    self._build(gpuid, self.feat_dim, self.feat_dim * self.num_spk, int(kwargs.get('hidden_dim', 600)),
+                int(kwargs.get('num_layers', 2)))
 
   def forward_padded(self, x, lens):
     """x (T,B,F) time-major zero-padded CUDA tensor, lens int32 CUDA (B) -> mask (T,B,F*S)."""
-    eng = self._bind()
     if self.hidden is None:
       self.hidden = self.init_hidden(x.shape[1])
     h0, c0 = self.hidden
-    h0 = h0.to(x.device, torch.float32).contiguous()
-    c0 = c0.to(x.device, torch.float32).contiguous()
-    if self.training:
-      self.bn.num_batches_tracked += 1
-    if torch.is_grad_enabled():
-      return _NetFn.apply(self._anchor, self, x, lens, h0, c0)
-    return eng.forward(x, lens, h0, c0, self.training, save=False)[0]
+    return self.run_net(x, lens, h0, c0)
 
   def forward(self, x):
     # x: packed sequence of dim feat_dim  ->  tensor of shape (batch, seq_length, feat_dim*num_spk)
     xp, lens = _to_padded(x, self.lin.weight.device)
     return self.forward_padded(xp, lens).permute(1, 0, 2)
-
-
-def _to_padded(packed, device):
-  """PackedSequence (as the Collator builds it) -> zero-padded time-major CUDA tensor + int32 lengths."""
-  if not isinstance(packed, PackedSequence):
-    raise TypeError("expected a PackedSequence from the arch's collator")
-  x, lens = pad_packed_sequence(packed.to(device))
-  return x.contiguous(), lens.to(device=device, dtype=torch.int32)
 
 
 def compute_cv_loss(model, epoch, batch_sample, plotdir=""):

@@ -1,0 +1,167 @@
+"""Shared machinery of the arch plug-ins (archs/uPIT.py, archs/RSH.py): an nn.Module whose parameters keep the
+reference's names (state_dict-compatible) but live as views in the engine's flat parameter / gradient
+buffers, plus the autograd bridge to the libsepkern forward/backward."""
+import torch
+import torch.nn as nn
+from torch.nn.utils.rnn import PackedSequence, pad_packed_sequence
+
+from . import dist as skdist
+from .engine import Engine
+from ._lib import SepkernError
+
+
+class _Params(nn.Module):
+  """A bag of named parameters/buffers (keeps the reference's state_dict keys, e.g. blstm.weight_ih_l0)."""
+
+
+class NetFn(torch.autograd.Function):
+  """(mask, hn, cn) = net(x, h0, c0).  backward runs the libsepkern backward kernels: parameter gradients
+  go to the flat gradient buffer every param.grad is a view of; gradients wrt x, h0, c0 are returned
+  (the RSH arch chains passes through the attention input and the carried hidden state)."""
+
+  @staticmethod
+  def forward(ctx, anchor, model, x, lens, h0, c0, want_state):
+    ctx.model = model
+    mask, hn, cn, ctx.fwd = model._engine.forward(x, lens, h0, c0, model.training, save=True, want_state=want_state)
+    if not want_state:
+      return mask
+    return mask, hn, cn
+
+  @staticmethod
+  def backward(ctx, dmask, dhn=None, dcn=None):
+    model = ctx.model
+    want_dx = ctx.needs_input_grad[2]
+    want_ds = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+    dx, dh0, dc0 = model._engine.backward(ctx.fwd, dmask.contiguous(),
+                                          dhn.contiguous() if dhn is not None else None,
+                                          dcn.contiguous() if dcn is not None else None,
+                                          want_dx=want_dx, want_dstate=want_ds)
+    ctx.fwd = None
+    model._pending -= 1
+    if model._pending <= 0:
+      model._allreduce_grads()        # once per step, after the last pass's backward
+    return None, None, dx, None, dh0, dc0, None
+
+
+class SepDNNBase(nn.Module):
+  """BLSTM(in_dim -> H, L layers, bidirectional) -> BatchNorm1d(2H) -> Linear(2H -> out_dim) -> sigmoid."""
+
+  def _build(self, gpuid, in_dim, out_dim, hidden_dim, num_layers):
+    self.gpuid = gpuid
+    if int(gpuid) < 0:
+      raise SepkernError("SepDNN(gpuid=%s): this build has no CPU path; it runs on an MI355X only" % gpuid)
+    self.in_dim, self.out_dim = int(in_dim), int(out_dim)
+    self.hidden_dim, self.num_layers = int(hidden_dim), int(num_layers)
+    H, L = self.hidden_dim, self.num_layers
+    # Initial values exactly as the reference draws them (nn.LSTM, nn.Linear, nn.BatchNorm1d constructed in
+    # this order consume the RNG identically, archs/uPIT.py:115-119 / archs/RSH.py:155-159); the modules are
+    # only used as initialisers, the kernels never call them.
+    init_lstm = nn.LSTM(self.in_dim, H, num_layers=L, bidirectional=True)
+    init_lin = nn.Linear(H * 2, self.out_dim)
+    init_bn = nn.BatchNorm1d(H * 2)
+    self.blstm = _Params()
+    for name, p in init_lstm.named_parameters():
+      self.blstm.register_parameter(name, nn.Parameter(p.detach().clone()))
+    self.lin = _Params()
+    self.lin.register_parameter('weight', nn.Parameter(init_lin.weight.detach().clone()))
+    self.lin.register_parameter('bias', nn.Parameter(init_lin.bias.detach().clone()))
+    self.bn = _Params()
+    self.bn.register_parameter('weight', nn.Parameter(init_bn.weight.detach().clone()))
+    self.bn.register_parameter('bias', nn.Parameter(init_bn.bias.detach().clone()))
+    self.bn.register_buffer('running_mean', init_bn.running_mean.clone())
+    self.bn.register_buffer('running_var', init_bn.running_var.clone())
+    self.bn.register_buffer('num_batches_tracked', init_bn.num_batches_tracked.clone())
+    self.hidden = None
+    self.next_hidden = None          # tests: (h0, c0) used by the next init_hidden call
+    self.hidden_generator = None
+    self._engine = None
+    self._anchor = None
+    self._pending = 0
+
+  # ---- parameter storage: every nn.Parameter is a view into the engine's flat buffer
+  def _named_views(self, flat_view):
+    for l in range(self.num_layers):
+      for d, sfx in enumerate(("", "_reverse")):
+        for base in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"):
+          yield getattr(self.blstm, "%s_l%d%s" % (base, l, sfx)), flat_view("%s_l%d" % (base, l))[d]
+    yield self.lin.weight, flat_view("lin.weight")
+    yield self.lin.bias, flat_view("lin.bias")
+    yield self.bn.weight, flat_view("bn.weight")
+    yield self.bn.bias, flat_view("bn.bias")
+
+  def _bind(self):
+    """(Re)attach parameters to the flat buffers; cheap when already bound."""
+    dev = self.lin.weight.device
+    if dev.type != 'cuda':
+      raise SepkernError("SepDNN must be moved to the GPU (model.cuda()) before use; there is no CPU path")
+    eng = self._engine
+    if eng is not None and eng.device == dev and self.lin.weight.data_ptr() == eng.p("lin.weight").data_ptr():
+      eng.running_mean, eng.running_var = self.bn.running_mean, self.bn.running_var
+      return eng
+    with torch.cuda.device(dev):
+      eng = Engine(self.in_dim, self.out_dim, self.hidden_dim, self.num_layers, dev)
+    with torch.no_grad():
+      for p, v in self._named_views(eng.p):
+        v.copy_(p.data)
+        p.data = v
+      for p, gv in self._named_views(eng.g):
+        if p.grad is not None:
+          gv.copy_(p.grad)
+        p.grad = gv
+    eng.running_mean, eng.running_var = self.bn.running_mean, self.bn.running_var
+    self._engine = eng
+    self._anchor = torch.zeros(1, device=dev, requires_grad=True)
+    return eng
+
+  def zero_grad(self, set_to_none=False):
+    # gradients stay views of the flat buffer; the next backward overwrites them
+    self._pending = 0
+    if self._engine is not None:
+      self._engine.zero_grad()
+    else:
+      super(SepDNNBase, self).zero_grad(set_to_none=False)
+
+  def flat_parameters(self):
+    """(params, grads): the two flat fp32 buffers (for sepkern.optim.ClipAdam and the DP all-reduce)."""
+    eng = self._bind()
+    return eng.flat, eng.grad
+
+  def _allreduce_grads(self):
+    skdist.allreduce_grads(self._engine.grad)       # one RCCL collective over the whole gradient
+
+  def init_hidden(self, batch_size):
+    """h0, c0 ~ N(0,1), shape (2L, B, H), fresh for every batch (reference archs/uPIT.py:121-127)."""
+    if self.next_hidden is not None:
+      if isinstance(self.next_hidden, list):         # a queue: one pair per init_hidden call (RSH sub-batches)
+        h = self.next_hidden.pop(0)
+        if not self.next_hidden:
+          self.next_hidden = None
+        return h
+      h, self.next_hidden = self.next_hidden, None
+      return h
+    dev = self.lin.weight.device
+    shape = (2 * self.num_layers, batch_size, self.hidden_dim)
+    return (torch.randn(shape, device=dev, generator=self.hidden_generator),
+            torch.randn(shape, device=dev, generator=self.hidden_generator))
+
+  def run_net(self, x, lens, h0, c0, want_state=False):
+    """x (T,B,in_dim) time-major zero-padded CUDA tensor, lens int32 CUDA (B) -> mask (T,B,out_dim)
+    [, hn, cn (2L,B,H)].  Differentiable when grad is enabled."""
+    eng = self._bind()
+    h0 = h0.to(x.device, torch.float32).contiguous()
+    c0 = c0.to(x.device, torch.float32).contiguous()
+    if self.training:
+      self.bn.num_batches_tracked += 1
+    if torch.is_grad_enabled():
+      self._pending += 1
+      return NetFn.apply(self._anchor, self, x, lens, h0, c0, want_state)
+    mask, hn, cn, _ = eng.forward(x, lens, h0, c0, self.training, save=False, want_state=want_state)
+    return (mask, hn, cn) if want_state else mask
+
+
+def to_padded(packed, device):
+  """PackedSequence (as the Collators build it) -> zero-padded time-major CUDA tensor + int32 lengths."""
+  if not isinstance(packed, PackedSequence):
+    raise TypeError("expected a PackedSequence from the arch's collator")
+  x, lens = pad_packed_sequence(packed.to(device))
+  return x.contiguous(), lens.to(device=device, dtype=torch.int32)

@@ -268,8 +268,10 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
     wr = [[tuple(t.clone().requires_grad_(True) for t in w[0][d]) for d in range(2)]]
     h0r, c0r = h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
     y_ref, hn_ref, cn_ref = OU.blstm_padded(x, lens, wr, h0r, c0r)
-    dy = torch.randn(T, B, 2 * H, generator=torch.Generator().manual_seed(1))
-    (y_ref * dy).sum().backward()
+    gd = torch.Generator().manual_seed(1)
+    dy = torch.randn(T, B, 2 * H, generator=gd)
+    dhn, dcn = torch.randn(2, B, H, generator=gd), torch.randn(2, B, H, generator=gd)   # the final state feeds a later pass (RSH)
+    ((y_ref * dy).sum() + (hn_ref * dhn).sum() + (cn_ref * dcn).sum()).backward()
     # ---- kernels
     lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
     wih = torch.stack([w[0][d][0] for d in range(2)]).cuda()          # (2,4H,I)
@@ -288,7 +290,7 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
     np.testing.assert_allclose(hn.cpu().numpy(), hn_ref.detach().numpy(), **tol)
     np.testing.assert_allclose(cn.cpu().numpy(), cn_ref.detach().numpy(), **tol)
     dh0, dc0 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
-    ws = ops.lstm_bwd(dev(dy), whh, gx, cs, dev(c0), lens_d, gx, dh0, dc0, T, B, H, mode)
+    ws = ops.lstm_bwd(dev(dy), whh, gx, cs, dev(c0), lens_d, gx, dh0, dc0, T, B, H, mode, dhn=dev(dhn), dcn=dev(dcn))
     ops.lstm_status(ws)
     gtol = dict(rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(dh0.cpu().numpy(), h0r.grad.numpy(), **gtol)
