@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--aux", action="store_true", help="also time the STFT / iSTFT kernels (extra JSON fields)")
+    ap.add_argument("--arch", choices=["upit", "rsh"], default="upit",
+                    help="rsh: the recurrent-selective-hearing arch (BASELINE configs[4]); not the headline metric")
     return ap.parse_args()
 
 
@@ -131,12 +133,19 @@ def main():
     from sepkern.optim import ClipAdam
     _lib.load()
     import uPIT
+    if args.arch == "rsh":
+        import RSH as arch_mod
+    else:
+        arch_mod = uPIT
 
     H, L, S, B, T = args.hidden, args.layers, args.num_spk, args.batch, args.frames
     torch.manual_seed(0)                                  # identical initial weights on every rank
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # SepDNN prints its conf keys like the reference does
-        model = uPIT.SepDNN(local, num_spk=str(S), hidden_dim=str(H), num_layers=str(L))
+        if args.arch == "rsh":
+            model = arch_mod.SepDNN(local, hidden_dim=str(H), num_layers=str(L))
+        else:
+            model = uPIT.SepDNN(local, num_spk=str(S), hidden_dim=str(H), num_layers=str(L))
     model.cuda()
     model.train()
     model.hidden_generator = torch.Generator(device="cuda")
@@ -148,8 +157,15 @@ def main():
     frames_per_step = int(lens.sum().item()) * world
     loss_acc = torch.zeros(2, device="cuda")
 
+    if args.arch == "rsh":
+        combos = torch.cat([mix, torch.ones_like(mix)], 2).contiguous()        # [mixture | attention = 1] (archs/RSH.py:104-106)
+        groups = [(S, combos, srcs, lens)]
+
     def step():
-        loss, norm = uPIT.compute_loss_padded(model, mix, srcs, lens)
+        if args.arch == "rsh":
+            loss, norm = arch_mod.compute_loss_padded(model, groups)
+        else:
+            loss, norm = uPIT.compute_loss_padded(model, mix, srcs, lens)
         loss_acc[0] += loss.detach() * norm               # epoch loss bookkeeping stays on the device
         loss_acc[1] += norm
         loss.backward()
@@ -184,15 +200,17 @@ def main():
         sys.exit("bench: loss is not finite/positive (%r)" % final_loss)
 
     res = {
-        "metric": "frames/sec uPIT BLSTM training on WSJ0-2mix-shaped synth",
+        "metric": "frames/sec uPIT BLSTM training on WSJ0-2mix-shaped synth" if args.arch == "upit" else
+                  "utterance frames/sec RSH training on CHiME-5-shaped synth (each frame goes through num_spk passes)",
         "value": round(frames_per_step * args.steps / dt, 1),
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "uPIT %dx%d BLSTM, %d-spk, 512-pt STFT (257 bins), batch %d x %d frames per GPU, "
-                               "fwd + PIT-MSE + bwd + clip 0.25 + Adam, random-init weights"
-                               % (L, H, S, B, T),
+        "config": {"workload": ("RSH %dx%d BLSTM over [mix|attention], %d-spk (%d passes per step), " % (L, H, S, S)
+                                if args.arch == "rsh" else "uPIT %dx%d BLSTM, %d-spk, " % (L, H, S)) +
+                               "512-pt STFT (257 bins), batch %d x %d frames per GPU, fwd + %s + bwd + clip 0.25 + Adam, "
+                               "random-init weights" % (B, T, "greedy-assignment MSE" if args.arch == "rsh" else "PIT-MSE"),
                    "global_batch": B * world, "frames_per_step": frames_per_step,
                    "parallelism": "dp%d" % world if world > 1 else "single",
                    "mean_loss": round(final_loss, 6)},
@@ -207,7 +225,10 @@ def main():
         res["kernels"] = {k: {"launches_per_step": v[0] // args.steps, "ms_per_step": round(v[1] / args.steps, 3),
                               "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in prof.items()}
         # whole-step figure against the same roofline: 6 x MACs per frame
-        P = sum(2 * 4 * H * ((257 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257 * S
+        if args.arch == "rsh":      # per pass: I = 2F inputs, F outputs; num_spk passes per frame
+            P = S * (sum(2 * 4 * H * ((514 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257)
+        else:
+            P = sum(2 * 4 * H * ((257 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257 * S
         res["step_tflops"] = round(6.0 * P * frames_per_step / world / (dt / args.steps) / 1e12, 2)
         res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
     if args.aux and rank == 0:

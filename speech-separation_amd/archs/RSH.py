@@ -209,41 +209,36 @@ def compute_cv_loss(model, epoch, batch_sample, plotdir=""):
   return loss, norm
 
 
-# define training pass
-def compute_loss(model, epoch, batch_sample, plotdir=""):
-  dev = model.lin.weight.device
+def compute_loss_padded(model, groups, plotdir=""):
+  """compute_loss on sub-batches already resident on the GPU.  groups: list of (num_spk, combos (T,B,2F),
+  sources [(T,B,F)] * num_spk, lens int32 (B)), zero-padded time-major.  Same return as compute_loss."""
   F = model.feat_dim
   model.zero_grad()
   loss = 0
   norm = 0
-
-  for num_spk in range(batch_sample.max_spk):
-    if batch_sample.sub_batch_lens[num_spk] > 0:
-      batch = batch_sample.sub_batch_lens[num_spk]
-      combos, lens = _to_padded(batch_sample[num_spk]['combo'], dev)
-      # combos: (seq_length, batch, feat_dim*2)
-      model.hidden = model.init_hidden(batch)
-      sources = [_to_padded(batch_sample[num_spk]['source' + str(i + 1)], dev)[0] for i in range(num_spk)]
-      used = torch.zeros(num_spk, batch, dtype=torch.int32, device=dev)       # source_usage of archs/RSH.py:218
-      for dnn_pass in range(num_spk):
-        mask_out = model.forward_padded(combos, lens)
-        # mask_out: (seq_length, batch, feat_dim)
-        out, sel = _PassLossFn.apply(mask_out, combos, lens, used, *sources)
-        loss = loss + out[0]
-        norm = norm + out[1].detach()
-        if plotdir:
-          sys.path.append('tools')
-          import plot
-          os.system("mkdir -p " + plotdir)
-          c0 = combos[:, 0].detach().cpu().numpy()
-          prefix = plotdir + '/' + str(num_spk) + '-Spk_Pass-' + str(dnn_pass + 1) + '_'
-          if dnn_pass == 0:
-            plot.plot_spec(c0[:, 0:F], plotdir + '/' + str(num_spk) + '-Spk_Mix.png')
-          plot.plot_spec(c0, prefix + 'Input.png')
-          plot.plot_spec(mask_out[:, 0].detach().cpu().numpy(), prefix + 'Mask_Out.png')
-          plot.plot_spec((mask_out[:, 0] * combos[:, 0, :F]).detach().cpu().numpy(), prefix + 'Masked_Mix.png')
-          plot.plot_spec(sources[int(sel[0])][:, 0].cpu().numpy(), prefix + 'Chosen_Source.png')
-        combos = _AttFn.apply(combos, mask_out, True)
+  for num_spk, combos, sources, lens in groups:
+    batch = combos.shape[1]
+    model.hidden = model.init_hidden(batch)
+    used = torch.zeros(num_spk, batch, dtype=torch.int32, device=combos.device)   # source_usage of archs/RSH.py:218
+    for dnn_pass in range(num_spk):
+      mask_out = model.forward_padded(combos, lens)
+      # mask_out: (seq_length, batch, feat_dim)
+      out, sel = _PassLossFn.apply(mask_out, combos, lens, used, *sources)
+      loss = loss + out[0]
+      norm = norm + out[1].detach()
+      if plotdir:
+        sys.path.append('tools')
+        import plot
+        os.system("mkdir -p " + plotdir)
+        c0 = combos[:, 0].detach().cpu().numpy()
+        prefix = plotdir + '/' + str(num_spk) + '-Spk_Pass-' + str(dnn_pass + 1) + '_'
+        if dnn_pass == 0:
+          plot.plot_spec(c0[:, 0:F], plotdir + '/' + str(num_spk) + '-Spk_Mix.png')
+        plot.plot_spec(c0, prefix + 'Input.png')
+        plot.plot_spec(mask_out[:, 0].detach().cpu().numpy(), prefix + 'Mask_Out.png')
+        plot.plot_spec((mask_out[:, 0] * combos[:, 0, :F]).detach().cpu().numpy(), prefix + 'Masked_Mix.png')
+        plot.plot_spec(sources[int(sel[0])][:, 0].cpu().numpy(), prefix + 'Chosen_Source.png')
+      combos = _AttFn.apply(combos, mask_out, True)
 
   # data-parallel: the global frame count normalises every rank's loss (sepkern.dist)
   if skdist.is_parallel():
@@ -251,6 +246,19 @@ def compute_loss(model, epoch, batch_sample, plotdir=""):
     torch.distributed.all_reduce(gn)
     norm = gn[0]
   return loss / norm, norm
+
+
+# define training pass
+def compute_loss(model, epoch, batch_sample, plotdir=""):
+  dev = model.lin.weight.device
+  groups = []
+  for num_spk in range(batch_sample.max_spk):
+    if batch_sample.sub_batch_lens[num_spk] > 0:
+      combos, lens = _to_padded(batch_sample[num_spk]['combo'], dev)
+      # combos: (seq_length, batch, feat_dim*2)
+      sources = [_to_padded(batch_sample[num_spk]['source' + str(i + 1)], dev)[0] for i in range(num_spk)]
+      groups.append((num_spk, combos, sources, lens))
+  return compute_loss_padded(model, groups, plotdir)
 
 
 # define test pass
