@@ -131,6 +131,61 @@ class TestSet(Dataset):
     return {'mix': mix_mag_spec, 'name': os.path.basename(self.list[idx])}
 
 
+class WavTrainSet(Dataset):
+  """On-GPU input pipeline: reads <datadir>/wav.scp and yields the int16 PCM of the mixture
+  and its sources (found like steps/extract_feats.py:65 does, by globbing /mix/ -> /*/); the STFT that stage 1
+  of the recipe would have stored as npz is computed on the GPU inside compute_loss (sk_stft straight into the
+  padded (T,B,F) batch).  12x less host I/O than float32 spectrograms and no zlib in the loader."""
+
+  def __init__(self, datadir, location=""):
+    import glob
+    self.items = []
+    for line in open(datadir + "/wav.scp"):
+      reco_id, filename = line.rstrip('\n').split(' ')
+      self.items.append(sorted(glob.glob(filename.replace("/mix/", "/*/"))))
+    self.collator = WavCollator()
+
+  def __len__(self):
+    return len(self.items)
+
+  def __getitem__(self, idx):
+    import scipy.io.wavfile
+    out = {}
+    for i, f in enumerate(self.items[idx]):
+      fs, x = scipy.io.wavfile.read(f)
+      if x.dtype != np.int16 or x.ndim != 1:
+        raise ValueError("%s: only mono 16-bit PCM wav is supported" % f)
+      out['mix' if i == 0 else 'source' + str(i)] = x
+    if len(out) == 1:
+      out['source1'] = out['mix']
+    return out
+
+
+class WavCollator():
+  """Sorts by frame count (descending, as Collator does) and keeps the PCM as a list per key."""
+
+  def __call__(self, batch):
+    sort_inds = np.argsort(np.array([1 + len(d['mix']) // 128 for d in batch]))[::-1]
+    return {'pcm': {key: [torch.from_numpy(np.ascontiguousarray(batch[i][key])) for i in sort_inds] for key in batch[0]}}
+
+
+def _features_from_pcm(pcm, dev):
+  """{'mix': [int16 (N_b,)], 'source1': ...} -> mix (T,B,F), sources [(T,B,F)], lens: STFT magnitudes on the GPU."""
+  B = len(pcm['mix'])
+  F = 257
+  Ts = [1 + int(w.numel()) // 128 for w in pcm['mix']]
+  T = max(Ts)
+  keys = ['mix'] + sorted(k for k in pcm if k != 'mix')
+  feats = {}
+  for k in keys:
+    out = torch.zeros(T, B, F, device=dev)
+    ops.stft_batch([w.to(dev, non_blocking=True) for w in pcm[k]], out=out, out_offs=[b * F for b in range(B)],
+                   stride_t=[B * F] * B, stride_f=[1] * B)
+    feats[k] = out
+  lens = torch.tensor(Ts, dtype=torch.int32, device=dev)
+  return feats['mix'], [feats[k] for k in keys[1:]], lens
+
+
 class _PitFn(torch.autograd.Function):
   """out = [loss/norm, norm, sum_b min_p L/S] (reference archs/uPIT.py:181-197,206)."""
 
@@ -217,6 +272,9 @@ def compute_loss_padded(model, mix, sources, lens, plotdir=""):
 # define training pass
 def compute_loss(model, epoch, batch_sample, plotdir=""):
   dev = model.lin.weight.device
+  if 'pcm' in batch_sample:        # WavTrainSet batches: features are computed on the GPU
+    mix, sources, lens = _features_from_pcm(batch_sample['pcm'], dev)
+    return compute_loss_padded(model, mix, sources[:model.num_spk], lens, plotdir)
   mix, lens = _to_padded(batch_sample['mix'], dev)
   sources = [_to_padded(batch_sample['source' + str(i + 1)], dev)[0] for i in range(model.num_spk)]
   return compute_loss_padded(model, mix, sources, lens, plotdir)

@@ -46,6 +46,9 @@ def get_args():
   parser.add_argument("--torch-optimizer", action="store_true",
                       help="use torch clip_grad_norm_ + optim.Adam instead of the fused kernel")
   parser.add_argument("--num-workers", type=int, default=1)
+  parser.add_argument("--wav-input", action="store_true",
+                      help="read <data-dir>/wav.scp and compute the STFT features on the GPU inside the step "
+                           "(arch must provide WavTrainSet) instead of loading feats_train.scp npz files")
   parser.add_argument("--seed", type=int, default=None, help="seed for weights, shuffling and h0/c0")
   return parser.parse_args()
 
@@ -83,7 +86,10 @@ def main():
     os.makedirs(plot_dir, exist_ok=True)
 
   print("loading datset")
-  dataset = m.TrainSet(args.data_dir, args.train_copy_location)
+  if args.wav_input:
+    dataset = m.WavTrainSet(args.data_dir)
+  else:
+    dataset = m.TrainSet(args.data_dir, args.train_copy_location)
   collate = dataset.collator
   train_data = dataset if world == 1 else Subset(dataset, skdist.shard_indices(len(dataset), rank, world))
   gen = torch.Generator()
@@ -91,7 +97,7 @@ def main():
   dataloader = DataLoader(train_data, batch_size=args.batch_size, shuffle=True, collate_fn=collate,
                           num_workers=args.num_workers, generator=gen if args.seed is not None else None)
   if args.cv_data_dir:
-    cv_dataset = m.TrainSet(args.cv_data_dir)
+    cv_dataset = m.WavTrainSet(args.cv_data_dir) if args.wav_input else m.TrainSet(args.cv_data_dir)
     cv_dataloader = DataLoader(cv_dataset, batch_size=args.batch_size, collate_fn=cv_dataset.collator)
 
   print("initializing model")

@@ -59,6 +59,7 @@ def test_recipe_steps_end_to_end(tmp_path):
     # ---- stage 2: training (2x64 via the conf-file mechanism, strings as in steps/train_qsub.py:87-91)
     exp = os.path.join(root, "exp", "uPIT_syn")
     os.makedirs(os.path.join(exp, "train_stats"), exist_ok=True)
+    os.makedirs(os.path.join(root, "exp", "uPIT_wav", "train_stats"), exist_ok=True)
     shutil.copy(os.path.join(PKG, "archs", "uPIT.py"), os.path.join(exp, "arch.py"))     # run_train.sh:56
     with open(os.path.join(exp, "conf"), "w") as f:
         f.write("hidden_dim=64\nnum_layers=2\n")
@@ -74,6 +75,10 @@ def test_recipe_steps_end_to_end(tmp_path):
     assert open(os.path.join(exp, "train_stats", "cv_loss.txt")).read().split()[0] == "005"
     sd = torch.load(os.path.join(exp, "final.mdl"), map_location="cpu")
     assert list(sd.keys())[0] == "blstm.weight_ih_l0" and sd["blstm.weight_hh_l1_reverse"].shape == (256, 64)
+
+    out = run(os.path.join(STEPS, "train_qsub.py"), "uPIT", "0", data, os.path.join(root, "exp", "uPIT_wav"), "--model-config",
+              os.path.join(exp, "conf"), "--batch-size", "4", "--num-epochs", "2", "--seed", "1", "--wav-input")
+    assert "For epoch: 002 loss is:" in out
 
     # ---- stage 3: masks from the FROZEN arch copy, then reconstruction
     mdir = os.path.join(exp, "masks")
@@ -91,6 +96,44 @@ def test_recipe_steps_end_to_end(tmp_path):
             assert fs == 8000 and got.dtype == np.int16 and got.shape == ref.shape == (128 * (spec.shape[1] - 1),)
             d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
             assert d.max() <= 1 and (d > 0).mean() < 5e-3
+
+    # ---- stage 4: scoring (SI-SDR in the reference's results-file formats, run_eval.sh:88-93)
+    run(os.path.join(STEPS, "evaluate_sources.py"), data, exp)
+    st = open(os.path.join(exp, "results", "SDR_stats.txt")).read().splitlines()
+    assert [l.split("\t")[0] for l in st] == ["Mean:", "Std:", "Max:", "Min:"] and np.isfinite(float(st[0].split("\t")[1]))
+    sess = open(os.path.join(exp, "results", "session_SDRs.txt")).read().splitlines()
+    assert [l.split(' ')[0] for l in sess] == ids
+    src = open(os.path.join(exp, "results", "source_SDRs.txt")).readline().split(' ')
+    assert src[0] == ids[0] and len(src) == 3
+    assert os.path.isfile(os.path.join(exp, "results", "SDRi_stats.txt"))
+
+
+def test_wav_input_pipeline_equals_npz_pipeline(tmp_path):
+    """WavTrainSet (PCM in, STFT on the GPU inside the step) gives the same loss and gradients as
+    the npz feature path on the same utterances and the same (h0, c0)."""
+    sys.path.insert(0, os.path.join(PKG, "archs"))
+    import uPIT
+    from sepkern import synth
+    root = str(tmp_path)
+    wavroot, data = os.path.join(root, "wav8k"), os.path.join(root, "data", "syn")
+    ids = synth.write_wav_tree(wavroot, 5, num_spk=2, min_s=0.6, max_s=1.2)
+    synth.write_data_dir(data, wavroot, ids)
+    run(os.path.join(STEPS, "extract_feats.py"), data, "train", os.path.join(root, "feats"))
+    torch.manual_seed(4)
+    model = uPIT.SepDNN(0, hidden_dim="64", num_layers="2")
+    model.cuda()
+    model.train()
+    h = (torch.randn(4, 5, 64).cuda(), torch.randn(4, 5, 64).cuda())
+    out = []
+    for ds in (uPIT.TrainSet(data), uPIT.WavTrainSet(data)):
+        batch = ds.collator([ds[i] for i in range(len(ds))])
+        model.next_hidden = h
+        loss, norm = uPIT.compute_loss(model, 0, batch)
+        loss.backward()
+        out.append((float(loss), float(norm), model.flat_parameters()[1].clone()))
+    assert out[0][1] == out[1][1]
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-5)
+    np.testing.assert_allclose(out[1][2].cpu().numpy(), out[0][2].cpu().numpy(), rtol=2e-3, atol=2e-7)
 
 
 def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
