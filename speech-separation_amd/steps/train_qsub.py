@@ -128,6 +128,10 @@ def main():
   else:
     model.load_state_dict(torch.load(int_model_dir + str(args.start_epoch).zfill(3) + '.mdl',
                                      map_location=lambda storage, loc: storage.cuda()))
+    # beyond the reference (which restarts Adam's moments on resume, steps/train_qsub.py:107): optimizer state
+    opt_file = int_model_dir + str(args.start_epoch).zfill(3) + '.opt'
+    if os.path.isfile(opt_file):
+      optimizer.load_state_dict(torch.load(opt_file, map_location=lambda storage, loc: storage.cuda()))
     load_losses(loss_file, epoch_losses)
     if args.cv_data_dir:
       load_losses(cv_loss_file, epoch_cv_losses)
@@ -177,6 +181,7 @@ def main():
     if epoch % 5 == 4 and rank == 0:
       print("Saving model for epoch " + str(epoch + 1).zfill(3))
       torch.save(model.state_dict(), int_model_dir + str(epoch + 1).zfill(3) + '.mdl')
+      torch.save(optimizer.state_dict(), int_model_dir + str(epoch + 1).zfill(3) + '.opt')
       try:
         import plot
         os.makedirs(plot_dir + 'epoch' + str(epoch + 1).zfill(3), exist_ok=True)

@@ -107,6 +107,20 @@ def test_recipe_steps_end_to_end(tmp_path):
     assert src[0] == ids[0] and len(src) == 3
     assert os.path.isfile(os.path.join(exp, "results", "SDRi_stats.txt"))
 
+    # ---- oracle-mask upper bound through the same STFT -> mask -> iSTFT kernels (steps/evaluate_oracle.py)
+    run(os.path.join(STEPS, "evaluate_oracle.py"), data)
+    soft = float(open(os.path.join(data, "oracle_soft_mask_eval", "SDR_stats.txt")).readline().split("\t")[1])
+    run(os.path.join(STEPS, "evaluate_oracle.py"), data, "--hard-mask")
+    hard = float(open(os.path.join(data, "oracle_hard_mask_eval", "SDR_stats.txt")).readline().split("\t")[1])
+    trained = float(st[0].split("\t")[1])
+    assert soft > trained + 3 and hard > trained + 3 and soft > 5      # ideal masks bound a 5-epoch toy model from above
+
+    # ---- resume from epoch 5 with the optimizer state saved next to the checkpoint
+    assert os.path.isfile(os.path.join(exp, "intermediate_models", "005.opt"))
+    out = run(os.path.join(STEPS, "train_qsub.py"), "uPIT", "0", data, exp, "--model-config", os.path.join(exp, "conf"),
+              "--batch-size", "4", "--num-epochs", "6", "--start-epoch", "5", "--seed", "1")
+    assert "For epoch: 006 loss is:" in out
+
 
 def test_wav_input_pipeline_equals_npz_pipeline(tmp_path):
     """WavTrainSet (PCM in, STFT on the GPU inside the step) gives the same loss and gradients as
