@@ -40,5 +40,32 @@ def main():
                 print("   %-78s n=%4d avg=%12.1f KB%s" % (k, len(v), avg, extra))
 
 
+def sq_summary(d):
+    """MFMA-pipe busy fraction and effective clock per kernel from an SQ/GRBM PMC pass."""
+    f = find(d, "counter_collection.csv")
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(int)
+    dur = collections.defaultdict(float)
+    seen = set()
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:78]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            cnt[k] += 1
+            dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    print("\n# SQ/GRBM pass: clock = GRBM_GUI_ACTIVE / 8 XCDs / duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / cycles")
+    for k in sorted(agg, key=lambda k: -dur[k])[:6]:
+        c = agg[k]
+        cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if cyc <= 0:
+            continue
+        print("   %-78s n=%3d clock=%.2f GHz  MFMA busy=%.3f  MFMA flop=%.1f GF/launch" % (
+            k, cnt[k], cyc / dur[k], c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc,
+            c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512 / 1e9 / cnt[k]))
+
+
 if __name__ == "__main__":
     main()
+    if len(sys.argv) >= 6:
+        sq_summary(sys.argv[5])
