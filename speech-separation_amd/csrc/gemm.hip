@@ -7,15 +7,16 @@
 // rounding-order differences only.
 //
 // Tiling: 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of 32x32
-// (64 accumulator VGPRs); K step 32, LDS double-buffered, operands kept k-major in LDS so the
-// per-lane A/B fragment reads are conflict-free ds_read_b32 of 32 consecutive dwords.  BK = 32 gives
-// every wave 64 MFMAs (4096 cycles) between barriers, enough to cover a loaded HBM round trip with
-// the one-tile-ahead register prefetch.
+// (64 accumulator VGPRs); K step 16, LDS double-buffered, operands kept k-major in LDS so the
+// per-lane A/B fragment reads are conflict-free ds_read_b32 of 32 consecutive dwords.  BK = 16 keeps a
+// block at 33 KB of LDS and 142 registers, so THREE blocks (3 waves per SIMD) are resident per CU and fill
+// each other's barrier / staging gaps: measured 115 / 111 / 117 TFLOP/s on the large NT / NN / TN shapes
+// against 110 / 107 / 111 with BK = 32 (two blocks per CU).
 #include "sk_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int BM = 128, BN = 128, BK = 16;
 // LDS row stride (floats) of a k-major operand image [BK][LD]: 132 keeps float4 rows 16-byte aligned for
 // operands that are k-major in memory; 129 makes the 4x4 transposing stash of [dim][K] operands
 // conflict-free (bank = 4q + r + row).  Fragment reads (32 consecutive floats) are conflict-free for both.
