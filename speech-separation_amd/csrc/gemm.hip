@@ -96,7 +96,7 @@ __device__ __forceinline__ void stash(float (*S)[LD], int tid, const float4 (&r)
 }
 
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
   constexpr int LDA = TA ? LD_K : LD_T, LDB = TB ? LD_T : LD_K;
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];

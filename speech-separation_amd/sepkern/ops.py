@@ -81,11 +81,11 @@ _SLOTS = None
 
 def pick_splitk(M, N, K, batch=1):
     """Slices for a weight-gradient-shaped product (few output tiles, long K): minimise the
-    wave-quantisation loss over the resident block slots (3 blocks of 128x128 per CU) plus the
+    wave-quantisation loss over the resident block slots (4 blocks of 128x128 per CU) plus the
     cost of writing and re-reading the partial slabs."""
     global _SLOTS
     if _SLOTS is None:
-        _SLOTS = 3 * device_info()[0]
+        _SLOTS = 4 * device_info()[0]
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if tiles >= 4 * _SLOTS or K < 2048:
         return 1
