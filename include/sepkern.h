@@ -47,10 +47,12 @@ int sk_device_info(int* num_cu, int* lds_bytes);
  * Output element (t, f) of utterance u goes to out[out_offs[u] + t*stride_t[u] + f*stride_f[u]]
  * (units: elements; float32 magnitude when want_complex == 0, interleaved complex64 otherwise).
  * (stride_t = F, stride_f = 1) is the (T,F) training layout; (1, T_u) is the reference's
- * on-disk (F, T) layout.  max_frames >= max_u T_u sizes the grid.  n_fft must be 512. */
+ * on-disk (F, T) layout.  frame_major != 0 promises stride_f[u] == 1 for every utterance (the strides live on
+ * the device): frames are then stored straight from registers, coalesced, with no LDS staging.
+ * max_frames >= max_u T_u sizes the grid.  n_fft must be 512. */
 int sk_stft(const void* wav, int pcm16, const int64_t* wav_offs, const int32_t* nsamp, int nutt,
             int n_fft, int hop, int want_complex, void* out, const int64_t* out_offs,
-            const int64_t* stride_t, const int64_t* stride_f, int max_frames, sk_stream_t stream);
+            const int64_t* stride_t, const int64_t* stride_f, int frame_major, int max_frames, sk_stream_t stream);
 
 /* ---------------------------------------------------------------- mask-apply + iSTFT back end
  * Replaces np.multiply(mix_spec, mask) + librosa.core.istft(hop_length=128) + (*32767).astype(int16)

@@ -1,12 +1,15 @@
 // stft.hip -- framed STFT / mask-apply + iSTFT for n_fft = 512, gfx950.
 //
-// One wavefront owns one frame: the 512 real samples are packed into 256 complex points and
-// go through a 4-stage radix-4 Stockham FFT whose stages exchange data through LDS (each of the
-// 64 lanes does one radix-4 butterfly per stage), followed by the real-FFT split.  A workgroup
-// (4 waves) handles 16 consecutive frames of one utterance so that the 75 %-overlapping samples
-// are read from HBM once, coalesced, into LDS.  Both kernels are HBM-bound streaming kernels:
+// The 512 real samples of a frame are packed into 256 complex points; the 256-point FFT is computed by
+// SIXTEEN lanes, each holding 16 points: two in-register 16-point FFTs (radix 4 x 4) with ONE transpose
+// through LDS in between (256 = 16 x 16), then the real-FFT split, whose mirrored partner Z[256-k] lives
+// in lane (16-j)%16 of the same group and is fetched with a cross-lane shuffle.  A wavefront therefore
+// transforms 4 frames at once and a workgroup (4 waves) 16 consecutive frames of one utterance, whose
+// 75 %-overlapping samples are read from HBM once, coalesced, into LDS.  Compared with one-frame-per-wave
+// radix-4 stages (3 LDS exchanges) this is ~6x less LDS traffic and ~2x fewer twiddle multiplies.
+// Both kernels are streaming kernels (HBM roofline):
 //   STFT   reads 128 new samples and writes 257 bins per frame,
-//   iSTFT  reads 257 complex bins (+257 mask values) and writes 128 samples per frame.
+//   iSTFT  reads 257 complex bins (+257 mask values) and writes 128 samples per frame per source.
 //
 // Reference semantics restated: librosa.core.stft / istft as used at
 // steps/extract_feats.py:85-89,104-105 and steps/reconstruct_sources.py:39-42 (see oracle/stft.py).
@@ -18,159 +21,217 @@ namespace {
 constexpr int NFFT = 512;
 constexpr int NBIN = 257;
 constexpr int HOP = 128;
-constexpr int FPB = 16;  // frames per workgroup (STFT)
-constexpr int HPB = 16;  // hops of output per workgroup (iSTFT)
-constexpr int IFR = HPB + 3;  // frames an iSTFT workgroup must invert
+constexpr int FPB = 16;       // frames per workgroup (STFT and iSTFT): 4 waves x 4 frames
+constexpr int HPB = FPB - 3;  // hops of output per iSTFT workgroup (each output hop needs 4 frames)
+constexpr int XLD = 17;       // padded row of the 16 x 16 transpose (conflict-free column reads)
+constexpr int TPB = 5;        // consecutive 16-frame tiles per STFT workgroup (next tile's samples are prefetched)
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-// In-place radix-4 DFT of v[0..3] (forward, e^{-i...}).
-__device__ __forceinline__ void radix4(float2 (&v)[4]) {
-  const float2 a0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y);
-  const float2 a1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
-  const float2 a2 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y);
-  const float2 d = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
-  const float2 a3 = make_float2(d.y, -d.x);  // d * (-i)
-  v[0] = make_float2(a0.x + a2.x, a0.y + a2.y);
-  v[1] = make_float2(a1.x + a3.x, a1.y + a3.y);
-  v[2] = make_float2(a0.x - a2.x, a0.y - a2.y);
-  v[3] = make_float2(a1.x - a3.x, a1.y - a3.y);
+// A wave's LDS instructions execute in order, so data exchanged between the lanes of ONE wave needs no
+// hardware barrier -- only a compiler fence so that the ds_writes stay ahead of the ds_reads that follow.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 256-point complex forward FFT of one wave.  v holds z[lane + 64 r] on entry; on exit the
-// natural-order result is in `res` (Z[k], k = 0..255).  b0/b1 are the wave's two LDS buffers.
-// All four waves of the block call this together (it contains block barriers).
-__device__ __forceinline__ float2* fft256_wave(float2 (&v)[4], float2* b0, float2* b1, const float2* tw,
-                                               int lane) {
-  // stage 0: Ns = 1 (twiddles are 1), write b0[4 lane + r]
-  radix4(v);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) b0[4 * lane + r] = v[r];
-  __syncthreads();
-  // stage 1: Ns = 4
-  {
-    const int jm = lane & 3;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = cmul(b0[lane + 64 * r], tw[(2 * r * jm * 16) & 511]);
-    radix4(v);
-    const int j0 = (lane >> 2) * 16 + jm;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b1[j0 + 4 * r] = v[r];
-  }
-  __syncthreads();
-  // stage 2: Ns = 16
-  {
-    const int jm = lane & 15;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = cmul(b1[lane + 64 * r], tw[(2 * r * jm * 4) & 511]);
-    radix4(v);
-    const int j0 = (lane >> 4) * 64 + jm;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b0[j0 + 16 * r] = v[r];
-  }
-  __syncthreads();
-  // stage 3: Ns = 64
-  {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = cmul(b0[lane + 64 * r], tw[(2 * r * lane) & 511]);
-    radix4(v);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) b1[lane + 64 * r] = v[r];
-  }
-  __syncthreads();
-  return b1;
+// radix-4 DFT of (a, b, c, d) (forward, e^{-i...})
+__device__ __forceinline__ void radix4(float2& a, float2& b, float2& c, float2& d) {
+  const float2 s0 = make_float2(a.x + c.x, a.y + c.y), s1 = make_float2(a.x - c.x, a.y - c.y);
+  const float2 s2 = make_float2(b.x + d.x, b.y + d.y), df = make_float2(b.x - d.x, b.y - d.y);
+  const float2 s3 = make_float2(df.y, -df.x);  // df * (-i)
+  a = make_float2(s0.x + s2.x, s0.y + s2.y);
+  b = make_float2(s1.x + s3.x, s1.y + s3.y);
+  c = make_float2(s0.x - s2.x, s0.y - s2.y);
+  d = make_float2(s1.x - s3.x, s1.y - s3.y);
 }
 
+// In-register 16-point DFT, natural order in and out (16 = 4 x 4).
+__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+  // step A: for n2 = 0..3 a radix-4 over n1 of x[4 n1 + n2]  ->  t[k1][n2] kept in x[4 k1 + n2]
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) radix4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);
+  // twiddles W16^(n2 k1): (1,1)=W1 (1,2)=W2 (1,3)=W3 (2,1)=W2 (2,2)=W4 (2,3)=W6 (3,1)=W3 (3,2)=W6 (3,3)=W9
+  x[4 + 1] = cmul(x[4 + 1], make_float2(C1, -S1));
+  x[4 + 2] = cmul(x[4 + 2], make_float2(R2, -R2));
+  x[4 + 3] = cmul(x[4 + 3], make_float2(S1, -C1));
+  x[8 + 1] = cmul(x[8 + 1], make_float2(R2, -R2));
+  x[8 + 2] = make_float2(x[8 + 2].y, -x[8 + 2].x);  // * (-i)
+  x[8 + 3] = cmul(x[8 + 3], make_float2(-R2, -R2));
+  x[12 + 1] = cmul(x[12 + 1], make_float2(S1, -C1));
+  x[12 + 2] = cmul(x[12 + 2], make_float2(-R2, -R2));
+  x[12 + 3] = cmul(x[12 + 3], make_float2(-C1, S1));
+  // step B: for k1 = 0..3 a radix-4 over n2  ->  X[k1 + 4 k2] left in x[4 k1 + k2]
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) radix4(x[4 * k1 + 0], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+  // transpose the 4 x 4 register tile so that x[k] = X[k]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = a + 1; b < 4; ++b) {
+      const float2 tmp = x[4 * a + b];
+      x[4 * a + b] = x[4 * b + a];
+      x[4 * b + a] = tmp;
+    }
+}
+
+// 256-point forward FFT by the 16 lanes of one group (j = lane & 15).  On entry z[n1] = in[16 n1 + j];
+// on exit z[k2] = Z[j + 16 k2].  xch: this GROUP's 16 x XLD float2 transpose area in LDS; tw = e^{-2 pi i m/512}.
+__device__ __forceinline__ void fft256_g16(float2 (&z)[16], float2* xch, const float2* tw, int j) {
+  dft16(z);  // over n1: z[k1] = A[k1][n2 = j]
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], tw[(2 * j * k1) & 511]);  // W256^(j k1)
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) xch[k1 * XLD + j] = z[k1];
+  wave_sync();
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) z[n2] = xch[j * XLD + n2];  // lane j now plays k1 = j
+  wave_sync();
+  dft16(z);  // over n2: z[k2] = Z[j + 16 k2]
+}
+
+// BINMAJOR == false: every utterance of the launch is written frame-major (stride_f == 1): lanes store their
+// bins straight from registers.  BINMAJOR == true: arbitrary strides (the reference's on-disk (257, T)
+// layout): results are staged in LDS and written with consecutive threads on consecutive frames.
+template <bool BINMAJOR>
 __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav, int pcm16,
                                                    const int64_t* __restrict__ wav_offs,
                                                    const int32_t* __restrict__ nsamp, int want_complex,
                                                    void* __restrict__ out, const int64_t* __restrict__ out_offs,
                                                    const int64_t* __restrict__ stride_t,
                                                    const int64_t* __restrict__ stride_f) {
-  __shared__ float smp[NFFT + (FPB - 1) * HOP];
+  __shared__ __attribute__((aligned(16))) float smp[NFFT + (FPB - 1) * HOP];
+  __shared__ __attribute__((aligned(16))) float win[NFFT];
   __shared__ float2 tw[NFFT];
-  __shared__ float2 fbuf[4][2][256];
-  __shared__ float2 ost[FPB][NBIN];
+  __shared__ float2 xch[16][16 * XLD];  // one transpose area per 16-lane group
+  __shared__ float2 ost[BINMAJOR ? FPB : 1][BINMAJOR ? NBIN : 1];
 
   const int u = blockIdx.y;
   const int N = nsamp[u];
   const int T = 1 + N / HOP;
-  const int t0 = blockIdx.x * FPB;
-  if (t0 >= T) return;
-  const int nfr = min(FPB, T - t0);
+  const int tile0 = blockIdx.x * TPB;  // this block transforms tiles tile0 .. tile0+TPB-1 (FPB frames each)
+  if (tile0 * FPB >= T) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-  for (int i = tid; i < NFFT; i += 256) tw[i] = g_tw512[i];
-  // reflect-padded samples [t0*HOP, t0*HOP + 512 + (nfr-1)*HOP) of the padded signal
-  const int span = NFFT + (nfr - 1) * HOP;
   const int64_t woff = wav_offs[u];
-  for (int i = tid; i < span; i += 256) {
-    int src = t0 * HOP + i - NFFT / 2;
-    if (src < 0) src = -src;
-    if (src >= N) src = 2 * (N - 1) - src;
-    src = max(0, min(src, N - 1));
-    float v;
-    if (pcm16)
-      v = (float)((const int16_t*)wav)[woff + src] * (1.0f / 32768.0f);
-    else
-      v = ((const float*)wav)[woff + src];
-    smp[i] = v;
-  }
-  __syncthreads();
-
-  for (int it = 0; it < FPB / 4; ++it) {
-    const int fr = it * 4 + wave;
-    const bool active = fr < nfr;
-    float2 v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = lane + 64 * r;
-      if (active) {
-        const float2 w = *reinterpret_cast<const float2*>(&g_hann512[2 * n]);
-        v[r] = make_float2(smp[fr * HOP + 2 * n] * w.x, smp[fr * HOP + 2 * n + 1] * w.y);
-      } else {
-        v[r] = make_float2(0.f, 0.f);
-      }
-    }
-    const float2* Z = fft256_wave(v, fbuf[wave][0], fbuf[wave][1], tw, lane);
-    if (active) {
-      // real-FFT split: X[k] = Xe + W^k Xo, Xe = (Z[k] + conj Z[256-k])/2, Xo = -i (Z[k] - conj Z[256-k])/2
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = lane + 64 * q;
-        const float2 zk = Z[k];
-        const float2 zc = Z[(256 - k) & 255];
-        const float2 xe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
-        const float2 xo = make_float2(0.5f * dd.y, -0.5f * dd.x);
-        const float2 t = cmul(tw[k], xo);
-        ost[fr][k] = make_float2(xe.x + t.x, xe.y + t.y);
-      }
-      if (lane == 0) ost[fr][256] = make_float2(Z[0].x - Z[0].y, 0.f);
-    }
-    __syncthreads();
-  }
-
   const int64_t ooff = out_offs[u];
   const int64_t st = stride_t[u], sf = stride_f[u];
-  const int total = nfr * NBIN;
-  for (int i = tid; i < total; i += 256) {
-    int fr, k;
-    if (st == 1) {  // bin-major (F,T): consecutive threads -> consecutive frames
-      k = i / nfr;
-      fr = i - k * nfr;
-    } else {  // frame-major: consecutive threads -> consecutive bins
-      fr = i / NBIN;
-      k = i - fr * NBIN;
+  constexpr int SPAN = NFFT + (FPB - 1) * HOP, SPT = (SPAN + 255) / 256;  // samples per tile / per thread
+
+  // reflect-padded samples [t0*HOP, t0*HOP + SPAN) of the padded signal (zeros past the last frame of the utterance)
+  auto fetch = [&](int t0, float (&r)[SPT]) {
+    const int nfr = min(FPB, T - t0);
+    const int span = NFFT + (nfr - 1) * HOP;
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+      const int i = tid + 256 * q;
+      int src = t0 * HOP + i - NFFT / 2;
+      if (src < 0) src = -src;
+      if (src >= N) src = 2 * (N - 1) - src;
+      src = max(0, min(src, N - 1));
+      float v = pcm16 ? (float)((const int16_t*)wav)[woff + src] * (1.0f / 32768.0f) : ((const float*)wav)[woff + src];
+      r[q] = (i < span) ? v : 0.f;
     }
-    const float2 x = ost[fr][k];
-    const int64_t o = ooff + (int64_t)(t0 + fr) * st + (int64_t)k * sf;
-    if (want_complex)
-      ((float2*)out)[o] = x;
-    else
-      ((float*)out)[o] = sqrtf(x.x * x.x + x.y * x.y);
+  };
+  auto stash = [&](const float (&r)[SPT]) {
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+      const int i = tid + 256 * q;
+      if (i < SPAN) smp[i] = r[q];
+    }
+  };
+
+  for (int i = tid; i < NFFT; i += 256) {
+    tw[i] = g_tw512[i];
+    win[i] = g_hann512[i];
+  }
+  float pre[SPT];
+  fetch(tile0 * FPB, pre);
+  stash(pre);
+  __syncthreads();
+
+  const int j = lane & 15, g = lane >> 4;
+  const int fr = 4 * wave + g;  // this group's frame within a tile
+  const int partner = (lane & 48) | ((16 - j) & 15);
+  for (int ti = 0; ti < TPB; ++ti) {
+    const int t0 = (tile0 + ti) * FPB;
+    if (t0 >= T) break;  // block-uniform
+    const int nfr = min(FPB, T - t0);
+    const bool more = ti + 1 < TPB && t0 + FPB < T;
+    if (more) fetch(t0 + FPB, pre);  // next tile's samples travel while this tile is transformed
+    const bool active = fr < nfr;
+    float2 z[16];
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {  // packed point n = 16 n1 + j  <->  samples 2n, 2n+1
+      const float2 sm = *reinterpret_cast<const float2*>(&smp[fr * HOP + 32 * n1 + 2 * j]);
+      const float2 w = *reinterpret_cast<const float2*>(&win[32 * n1 + 2 * j]);
+      z[n1] = make_float2(sm.x * w.x, sm.y * w.y);
+    }
+    fft256_g16(z, xch[4 * wave + g], tw, j);
+
+    // real-FFT split: X[k] = Xe + W^k Xo, Xe = (Z[k] + conj Z[256-k])/2, Xo = -i (Z[k] - conj Z[256-k])/2,
+    // k = j + 16 k2.  Z[256-k] is register 15-k2 of lane (16-j)%16 of this group (register (16-k2)%16 of lane 0
+    // itself when j == 0).
+    const int64_t fo = ooff + (int64_t)(t0 + fr) * st;
+    const float z0x = z[0].x, z0y = z[0].y;
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      float2 zc;
+      zc.x = __shfl(z[15 - k2].x, partner, 64);
+      zc.y = __shfl(z[15 - k2].y, partner, 64);
+      if (j == 0) zc = z[(16 - k2) & 15];
+      const float2 zk = z[k2];
+      const int k = j + 16 * k2;
+      const float2 xe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+      const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
+      const float2 xo = make_float2(0.5f * dd.y, -0.5f * dd.x);
+      const float2 t = cmul(tw[k], xo);
+      const float2 x = make_float2(xe.x + t.x, xe.y + t.y);
+      if (BINMAJOR) {
+        if (active) ost[fr][k] = x;
+      } else if (active) {
+        if (want_complex)
+          ((float2*)out)[fo + k] = x;
+        else
+          ((float*)out)[fo + k] = sqrtf(x.x * x.x + x.y * x.y);
+      }
+    }
+    if (j == 0 && active) {  // k = 256: Re Z[0] - Im Z[0]
+      const float2 x = make_float2(z0x - z0y, 0.f);
+      if (BINMAJOR)
+        ost[fr][256] = x;
+      else if (want_complex)
+        ((float2*)out)[fo + 256] = x;
+      else
+        ((float*)out)[fo + 256] = fabsf(x.x);
+    }
+    __syncthreads();  // every wave is done with smp (and ost is complete)
+    if (BINMAJOR) {
+      const int total = nfr * NBIN;
+      for (int i = tid; i < total; i += 256) {
+        int f2, k;
+        if (st == 1) {  // bin-major (F,T): consecutive threads -> consecutive frames
+          k = i / nfr;
+          f2 = i - k * nfr;
+        } else {  // frame-major: consecutive threads -> consecutive bins
+          f2 = i / NBIN;
+          k = i - f2 * NBIN;
+        }
+        const float2 x = ost[f2][k];
+        const int64_t o = ooff + (int64_t)(t0 + f2) * st + (int64_t)k * sf;
+        if (want_complex)
+          ((float2*)out)[o] = x;
+        else
+          ((float*)out)[o] = sqrtf(x.x * x.x + x.y * x.y);
+      }
+    }
+    if (more) {
+      stash(pre);
+      __syncthreads();
+    }
   }
 }
 
@@ -180,10 +241,11 @@ __global__ __launch_bounds__(256) void istft_kernel(
     const int64_t* __restrict__ mask_st, const int64_t* __restrict__ mask_sf, const int32_t* __restrict__ nframes,
     int S, float* __restrict__ wav_out, int16_t* __restrict__ pcm_out, const int64_t* __restrict__ out_offs) {
   // rows[fr] holds the masked spectrum of frame fr (257 complex) and is then overwritten by its
-  // windowed time-domain frame (512 floats); only the owning wave touches a row in between.
-  __shared__ float2 rows[IFR][NBIN + 1];
+  // windowed time-domain frame (512 floats); only the owning 16-lane group touches a row in between.
+  __shared__ __attribute__((aligned(16))) float2 rows[FPB][NBIN + 1];
+  __shared__ __attribute__((aligned(16))) float win[NFFT];
   __shared__ float2 tw[NFFT];
-  __shared__ float2 fbuf[4][2][256];
+  __shared__ float2 xch[16][16 * XLD];
 
   const int us = blockIdx.y;
   const int u = us / S;
@@ -194,18 +256,20 @@ __global__ __launch_bounds__(256) void istft_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tbase = c * HPB - 1;  // first frame that can touch this chunk (may be -1)
 
-  for (int i = tid; i < NFFT; i += 256) tw[i] = g_tw512[i];
-
-  // ---- masked spectra of frames tbase .. tbase+IFR-1 into LDS
+  for (int i = tid; i < NFFT; i += 256) {
+    tw[i] = g_tw512[i];
+    win[i] = g_hann512[i];
+  }
+  // ---- masked spectra of frames tbase .. tbase+FPB-1 into LDS
   {
     const int64_t mo = mix_offs[u], mst = mix_st[u], msf = mix_sf[u];
     const int64_t ko = mask ? mask_offs[us] : 0, kst = mask ? mask_st[u] : 0, ksf = mask ? mask_sf[u] : 0;
-    const int total = IFR * NBIN;
+    const int total = FPB * NBIN;
     for (int i = tid; i < total; i += 256) {
       int fr, k;
       if (mst == 1) {
-        k = i / IFR;
-        fr = i - k * IFR;
+        k = i / FPB;
+        fr = i - k * FPB;
       } else {
         fr = i / NBIN;
         k = i - fr * NBIN;
@@ -225,48 +289,40 @@ __global__ __launch_bounds__(256) void istft_kernel(
   }
   __syncthreads();
 
-  // ---- inverse real FFT of every frame, windowed, left in rows[fr] as 512 floats
-  for (int it = 0; it < (IFR + 3) / 4; ++it) {
-    const int fr = it * 4 + wave;
-    const bool active = fr < IFR;
-    float2 v[4];
+  // ---- inverse real FFT of the 16 frames (one per 16-lane group), windowed, left in rows[fr] as 512 floats
+  {
+    const int j = lane & 15, g = lane >> 4;
+    const int fr = 4 * wave + g;
+    float2 z[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = lane + 64 * r;
-      if (active) {
-        float2 a = rows[fr][k];
-        float2 b = rows[fr][256 - k];
-        if (k == 0) {  // irfft ignores Im X[0] and Im X[256]
-          a.y = 0.f;
-          b.y = 0.f;
-        }
-        b.y = -b.y;  // conj(X[256-k])
-        const float2 xe = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-        const float2 hd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-        const float2 wk = make_float2(tw[k].x, -tw[k].y);  // conj(W^k)
-        const float2 xo = cmul(hd, wk);
-        // Z = Xe + i Xo ; feed conj(Z) to the forward FFT
-        v[r] = make_float2(xe.x - xo.y, -(xe.y + xo.x));
-      } else {
-        v[r] = make_float2(0.f, 0.f);
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int k = 16 * n1 + j;
+      float2 a = rows[fr][k];
+      float2 b = rows[fr][256 - k];
+      if (k == 0) {  // irfft ignores Im X[0] and Im X[256]
+        a.y = 0.f;
+        b.y = 0.f;
       }
+      b.y = -b.y;  // conj(X[256-k])
+      const float2 xe = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+      const float2 hd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+      const float2 wk = make_float2(tw[k].x, -tw[k].y);  // conj(W^k)
+      const float2 xo = cmul(hd, wk);
+      // Z = Xe + i Xo ; feed conj(Z) to the forward FFT
+      z[n1] = make_float2(xe.x - xo.y, -(xe.y + xo.x));
     }
-    // all reads of rows[fr] above are done by this wave before it overwrites the row below
-    const float2* Y = fft256_wave(v, fbuf[wave][0], fbuf[wave][1], tw, lane);
-    if (active) {
-      float* tf = reinterpret_cast<float*>(&rows[fr][0]);
+    wave_sync();  // all reads of rows[fr] are done before the row is overwritten below
+    fft256_g16(z, xch[4 * wave + g], tw, j);
+    float* tf = reinterpret_cast<float*>(&rows[fr][0]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = lane + 64 * r;
-        const float2 y = Y[n];
-        const float2 w = *reinterpret_cast<const float2*>(&g_hann512[2 * n]);
-        // z[n] = conj(Y[n]) / 256 ; x[2n] = Re z, x[2n+1] = Im z
-        *reinterpret_cast<float2*>(&tf[2 * n]) =
-            make_float2(w.x * (y.x * (1.0f / 256.0f)), w.y * (-y.y * (1.0f / 256.0f)));
-      }
+    for (int k2 = 0; k2 < 16; ++k2) {  // z[k2] = Y[n], n = j + 16 k2; x[2n] = Re Y / 256, x[2n+1] = -Im Y / 256
+      const int n = j + 16 * k2;
+      const float2 w = *reinterpret_cast<const float2*>(&win[2 * n]);
+      *reinterpret_cast<float2*>(&tf[2 * n]) =
+          make_float2(w.x * (z[k2].x * (1.0f / 256.0f)), w.y * (-z[k2].y * (1.0f / 256.0f)));
     }
-    __syncthreads();
   }
+  __syncthreads();  // every frame of the chunk is in LDS
 
   // ---- overlap-add in increasing frame order, window-sum-square normalisation, trim, convert
   const int64_t oo = out_offs[us];
@@ -277,13 +333,13 @@ __global__ __launch_bounds__(256) void istft_kernel(
     const int hp = p >> 7;
     float acc = 0.f, wss = 0.f;
 #pragma unroll
-    for (int j = 3; j >= 0; --j) {
-      const int t = hp - j;
+    for (int q = 3; q >= 0; --q) {
+      const int t = hp - q;
       if (t >= 0 && t < T) {
         const int m = p - t * HOP;
         const float* tf = reinterpret_cast<const float*>(&rows[t - tbase][0]);
         acc += tf[m];
-        const float w = g_hann512[m];
+        const float w = win[m];
         wss += w * w;
       }
     }
@@ -300,13 +356,17 @@ __global__ __launch_bounds__(256) void istft_kernel(
 
 extern "C" int sk_stft(const void* wav, int pcm16, const int64_t* wav_offs, const int32_t* nsamp, int nutt, int n_fft,
                        int hop, int want_complex, void* out, const int64_t* out_offs, const int64_t* stride_t,
-                       const int64_t* stride_f, int max_frames, sk_stream_t stream) {
+                       const int64_t* stride_f, int frame_major, int max_frames, sk_stream_t stream) {
   SK_CHECK_ARG(n_fft == NFFT && hop == HOP, "sk_stft: only n_fft=512, hop=128 are built (got %d, %d)", n_fft, hop);
   SK_CHECK_ARG(wav && wav_offs && nsamp && out && out_offs && stride_t && stride_f, "sk_stft: null pointer");
   SK_CHECK_ARG(nutt > 0 && nutt <= 65535 && max_frames > 0, "sk_stft: bad nutt/max_frames");
-  dim3 grid((unsigned)sk_cdiv(max_frames, FPB), (unsigned)nutt);
-  hipLaunchKernelGGL(stft_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, pcm16, wav_offs, nsamp, want_complex,
-                     out, out_offs, stride_t, stride_f);
+  dim3 grid((unsigned)sk_cdiv(max_frames, FPB * TPB), (unsigned)nutt);
+  if (frame_major)
+    hipLaunchKernelGGL(stft_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, pcm16, wav_offs, nsamp,
+                       want_complex, out, out_offs, stride_t, stride_f);
+  else
+    hipLaunchKernelGGL(stft_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, pcm16, wav_offs, nsamp,
+                       want_complex, out, out_offs, stride_t, stride_f);
   SK_CHECK_LAUNCH("sk_stft");
   return SK_OK;
 }

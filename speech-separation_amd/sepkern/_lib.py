@@ -22,7 +22,7 @@ PROTOTYPES = {
     "sk_version": (_i, []),
     "sk_last_error": (C.c_char_p, []),
     "sk_device_info": (_i, [C.POINTER(_i), C.POINTER(_i)]),
-    "sk_stft": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p]),
+    "sk_stft": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
     "sk_mask_istft": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
     "sk_gemm_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p]),
     "sk_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),

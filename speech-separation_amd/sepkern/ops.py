@@ -160,8 +160,9 @@ def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, s
     # descriptor arrays must outlive the (asynchronous) launch call: keep references until it returns
     d_woffs, d_ns = _i64(woffs, dev), torch.tensor(ns, dtype=torch.int32, device=dev)
     d_ooffs, d_st, d_sf = _i64(out_offs, dev), _i64(stride_t, dev), _i64(stride_f, dev)
+    frame_major = all(int(v) == 1 for v in stride_f)
     _lib.call("sk_stft", _ptr(cat), int(pcm16), _ptr(d_woffs), _ptr(d_ns), len(wavs), 512, 128, int(want_complex),
-              _ptr(out), _ptr(d_ooffs), _ptr(d_st), _ptr(d_sf), max(Ts), _stream())
+              _ptr(out), _ptr(d_ooffs), _ptr(d_st), _ptr(d_sf), int(frame_major), max(Ts), _stream())
     return ret if ret is not None else out
 
 

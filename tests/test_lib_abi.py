@@ -41,7 +41,7 @@ def test_argument_errors_are_reported_not_thrown():
     from sepkern import _lib
     lib = _lib.load()
     # n_fft other than 512 is rejected before anything touches the GPU
-    rc = lib.sk_stft(None, 0, None, None, 1, 256, 64, 0, None, None, None, None, 1, None)
+    rc = lib.sk_stft(None, 0, None, None, 1, 256, 64, 0, None, None, None, None, 0, 1, None)
     assert rc == -1
     assert b"n_fft" in lib.sk_last_error()
     assert lib.sk_lstm_workspace_bytes(400, 32, 896) > 0
