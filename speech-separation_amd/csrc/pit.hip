@@ -11,7 +11,8 @@
 namespace {
 
 constexpr int MAXS = 4;
-constexpr int TCH = 8;  // frames per block in the pairwise pass
+constexpr int TCH = 16;  // frames per block in the pairwise pass
+constexpr int RB = 4;    // (frame, utterance) rows per block in the backward pass
 
 struct SrcPtrs {
   const float* p[MAXS];
@@ -28,22 +29,22 @@ __global__ __launch_bounds__(256) void pit_pair_kernel(const float* __restrict__
   for (int s = 0; s < S; ++s)
 #pragma unroll
     for (int r = 0; r < S; ++r) acc[s][r] = 0.f;
-  const int tend = min(T, (ch + 1) * TCH);
-  for (int t = ch * TCH; t < tend; ++t) {
-    const int64_t row = (int64_t)t * B + b;
-    for (int f = threadIdx.x; f < F; f += 256) {
-      const float mx = mix[row * F + f];
-      float sv[S];
+  // the chunk's frames x bins as one flat range, so that F = 257 does not leave a nearly empty second sweep
+  const int t0 = ch * TCH, nel = (min(T, t0 + TCH) - t0) * F;
+  for (int i = threadIdx.x; i < nel; i += 256) {
+    const int dt = i / F, f = i - dt * F;
+    const int64_t row = (int64_t)(t0 + dt) * B + b;
+    const float mx = mix[row * F + f];
+    float sv[S];
 #pragma unroll
-      for (int r = 0; r < S; ++r) sv[r] = src.p[r][row * F + f];
+    for (int r = 0; r < S; ++r) sv[r] = src.p[r][row * F + f];
 #pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const float mm = mask[row * (int64_t)(S * F) + s * F + f] * mx;
+    for (int s = 0; s < S; ++s) {
+      const float mm = mask[row * (int64_t)(S * F) + s * F + f] * mx;
 #pragma unroll
-        for (int r = 0; r < S; ++r) {
-          const float d = mm - sv[r];
-          acc[s][r] += d * d;
-        }
+      for (int r = 0; r < S; ++r) {
+        const float d = mm - sv[r];
+        acc[s][r] += d * d;
       }
     }
   }
@@ -121,17 +122,21 @@ __global__ __launch_bounds__(256) void pit_bwd_kernel(const float* __restrict__ 
                                                       SrcPtrs src, const int32_t* __restrict__ best_perm,
                                                       const float* __restrict__ out, const float* __restrict__ gscale,
                                                       int T, int B, int F, float* __restrict__ dmask) {
-  const int64_t row = blockIdx.x;  // t*B + b
-  const int b = (int)(row % B);
-  int perm[MAXS];
-  nth_perm(best_perm[b], S, perm);
+  __shared__ int perm[RB][MAXS];
+  const int64_t row0 = (int64_t)blockIdx.x * RB, nrows = (int64_t)T * B;  // row = t*B + b
+  if (threadIdx.x < RB && row0 + threadIdx.x < nrows)
+    nth_perm(best_perm[(int)((row0 + threadIdx.x) % B)], S, perm[threadIdx.x]);
+  __syncthreads();
   const float k = gscale[0] * 2.0f / ((float)S * out[1]);
-  for (int f = threadIdx.x; f < F; f += 256) {
+  const int nel = (int)min((int64_t)RB, nrows - row0) * F;
+  for (int i = threadIdx.x; i < nel; i += 256) {
+    const int dr = i / F, f = i - dr * F;
+    const int64_t row = row0 + dr;
     const float mx = mix[row * F + f];
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       const int64_t o = row * (int64_t)(S * F) + s * F + f;
-      const float sv = src.p[perm[s]][row * F + f];
+      const float sv = src.p[perm[dr][s]][row * F + f];
       dmask[o] = k * (mask[o] * mx - sv) * mx;
     }
   }
@@ -177,7 +182,7 @@ extern "C" int sk_pit_mse_bwd(const float* mask, const float* mix, const float* 
   SK_CHECK_ARG(T > 0 && B > 0 && F > 0, "sk_pit_mse_bwd: bad sizes");
   SrcPtrs sp;
   for (int s = 0; s < MAXS; ++s) sp.p[s] = s < S ? src_host[s] : nullptr;
-  dim3 grid((unsigned)((int64_t)T * B));
+  dim3 grid((unsigned)sk_cdiv((int64_t)T * B, RB));
   hipStream_t st = (hipStream_t)stream;
   switch (S) {
     case 1: hipLaunchKernelGGL(pit_bwd_kernel<1>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;

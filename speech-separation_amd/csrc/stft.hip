@@ -22,7 +22,6 @@ constexpr int NFFT = 512;
 constexpr int NBIN = 257;
 constexpr int HOP = 128;
 constexpr int FPB = 16;       // frames per workgroup (STFT and iSTFT): 4 waves x 4 frames
-constexpr int HPB = FPB - 3;  // hops of output per iSTFT workgroup (each output hop needs 4 frames)
 constexpr int XLD = 17;       // padded row of the 16 x 16 transpose (conflict-free column reads)
 constexpr int TPB = 5;        // consecutive 16-frame tiles per STFT workgroup (next tile's samples are prefetched)
 
@@ -121,14 +120,35 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
   const int64_t st = stride_t[u], sf = stride_f[u];
   constexpr int SPAN = NFFT + (FPB - 1) * HOP, SPT = (SPAN + 255) / 256;  // samples per tile / per thread
 
-  // reflect-padded samples [t0*HOP, t0*HOP + SPAN) of the padded signal (zeros past the last frame of the utterance)
+  // reflect-padded samples [t0*HOP, t0*HOP + SPAN) of the padded signal (zeros past the last frame of the
+  // utterance).  Tiles whose whole span lies inside the utterance (all but the first and the last one or two)
+  // take a block-uniform path without the reflect/clamp arithmetic.
   auto fetch = [&](int t0, float (&r)[SPT]) {
     const int nfr = min(FPB, T - t0);
     const int span = NFFT + (nfr - 1) * HOP;
+    const int first = t0 * HOP - NFFT / 2;
+    if (first >= 0 && first + SPAN <= N) {
+      if (pcm16) {
+        const int16_t* w = (const int16_t*)wav + woff + first;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+          const int i = tid + 256 * q;
+          r[q] = (i < SPAN) ? (float)w[i] * (1.0f / 32768.0f) : 0.f;
+        }
+      } else {
+        const float* w = (const float*)wav + woff + first;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+          const int i = tid + 256 * q;
+          r[q] = (i < SPAN) ? w[i] : 0.f;
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < SPT; ++q) {
       const int i = tid + 256 * q;
-      int src = t0 * HOP + i - NFFT / 2;
+      int src = first + i;
       if (src < 0) src = -src;
       if (src >= N) src = 2 * (N - 1) - src;
       src = max(0, min(src, N - 1));
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
         if (want_complex)
           ((float2*)out)[fo + k] = x;
         else
-          ((float*)out)[fo + k] = sqrtf(x.x * x.x + x.y * x.y);
+          ((float*)out)[fo + k] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
       }
     }
     if (j == 0 && active) {  // k = 256: Re Z[0] - Im Z[0]
@@ -225,7 +245,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
         if (want_complex)
           ((float2*)out)[o] = x;
         else
-          ((float*)out)[o] = sqrtf(x.x * x.x + x.y * x.y);
+          ((float*)out)[o] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
       }
     }
     if (more) {
@@ -235,119 +255,133 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
   }
 }
 
-__global__ __launch_bounds__(256) void istft_kernel(
+constexpr int RING = FPB + 3;  // row slots of the iSTFT ring: one tile of frames + the 3 frames before it
+constexpr int RLD = 16 * XLD;  // float2 per slot: holds a 257-bin spectrum, the FFT's transpose area, 512 samples
+
+// Masked spectra of frames [tfirst, tfirst + COUNT) into their ring slots (zeros outside [0, T)).
+template <int COUNT>
+__device__ __forceinline__ void istft_load(float2 (*rows)[RLD], int tfirst, int T, const float2* __restrict__ mix,
+                                           int64_t mo, int64_t mst, int64_t msf, const float* __restrict__ mask,
+                                           int64_t ko, int64_t kst, int64_t ksf) {
+  for (int i = threadIdx.x; i < COUNT * NBIN; i += 256) {
+    int fr, k;
+    if (mst == 1) {  // bin-major (257, T): consecutive threads -> consecutive frames
+      k = i / COUNT;
+      fr = i - k * COUNT;
+    } else {
+      fr = i / NBIN;
+      k = i - fr * NBIN;
+    }
+    const int t = tfirst + fr;
+    float2 x = make_float2(0.f, 0.f);
+    if (t >= 0 && t < T) {
+      x = mix[mo + (int64_t)t * mst + (int64_t)k * msf];
+      if (mask) {
+        const float m = mask[ko + (int64_t)t * kst + (int64_t)k * ksf];
+        x.x *= m;
+        x.y *= m;
+      }
+    }
+    rows[(t + 3) % RING][k] = x;
+  }
+}
+
+// Inverse real FFT of frame t by one 16-lane group; the windowed 512 samples replace the spectrum in the slot.
+__device__ __forceinline__ void istft_frame(float2* row, const float2* tw, const float* win, int j) {
+  float2 z[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const int k = 16 * n1 + j;
+    float2 a = row[k];
+    float2 b = row[256 - k];
+    if (k == 0) {  // irfft ignores Im X[0] and Im X[256]
+      a.y = 0.f;
+      b.y = 0.f;
+    }
+    b.y = -b.y;  // conj(X[256-k])
+    const float2 xe = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+    const float2 hd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+    const float2 wk = make_float2(tw[k].x, -tw[k].y);  // conj(W^k)
+    const float2 xo = cmul(hd, wk);
+    // Z = Xe + i Xo ; feed conj(Z) to the forward FFT
+    z[n1] = make_float2(xe.x - xo.y, -(xe.y + xo.x));
+  }
+  wave_sync();  // the spectrum is in registers: the slot now serves as the transpose area, then as the output
+  fft256_g16(z, row, tw, j);
+  float* tf = reinterpret_cast<float*>(row);
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) {  // z[k2] = Y[n], n = j + 16 k2; x[2n] = Re Y / 256, x[2n+1] = -Im Y / 256
+    const int n = j + 16 * k2;
+    const float2 w = *reinterpret_cast<const float2*>(&win[2 * n]);
+    *reinterpret_cast<float2*>(&tf[2 * n]) =
+        make_float2(w.x * (z[k2].x * (1.0f / 256.0f)), w.y * (-z[k2].y * (1.0f / 256.0f)));
+  }
+}
+
+// One workgroup reconstructs `tpb` consecutive 16-hop tiles of one (utterance, source): every frame is read
+// and transformed once; the 3 frames that overlap into the next tile stay in the LDS ring.
+__global__ __launch_bounds__(256, 3) void istft_kernel(
     const float2* __restrict__ mix, const int64_t* __restrict__ mix_offs, const int64_t* __restrict__ mix_st,
     const int64_t* __restrict__ mix_sf, const float* __restrict__ mask, const int64_t* __restrict__ mask_offs,
     const int64_t* __restrict__ mask_st, const int64_t* __restrict__ mask_sf, const int32_t* __restrict__ nframes,
-    int S, float* __restrict__ wav_out, int16_t* __restrict__ pcm_out, const int64_t* __restrict__ out_offs) {
-  // rows[fr] holds the masked spectrum of frame fr (257 complex) and is then overwritten by its
-  // windowed time-domain frame (512 floats); only the owning 16-lane group touches a row in between.
-  __shared__ __attribute__((aligned(16))) float2 rows[FPB][NBIN + 1];
+    int S, float* __restrict__ wav_out, int16_t* __restrict__ pcm_out, const int64_t* __restrict__ out_offs, int tpb) {
+  __shared__ __attribute__((aligned(16))) float2 rows[RING][RLD];
   __shared__ __attribute__((aligned(16))) float win[NFFT];
   __shared__ float2 tw[NFFT];
-  __shared__ float2 xch[16][16 * XLD];
 
   const int us = blockIdx.y;
   const int u = us / S;
   const int T = nframes[u];
   const int nout = HOP * (T - 1);
-  const int c = blockIdx.x;
-  if (c * HPB * HOP >= nout) return;
+  const int ntiles = T / FPB + 1;  // hops 0 .. T carry output samples
+  const int tile0 = blockIdx.x * tpb;
+  if (tile0 >= ntiles) return;
+  const int tile1 = min(ntiles, tile0 + tpb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tbase = c * HPB - 1;  // first frame that can touch this chunk (may be -1)
+  const int j = lane & 15, fr = 4 * wave + (lane >> 4);
+  const int64_t mo = mix_offs[u], mst = mix_st[u], msf = mix_sf[u];
+  const int64_t ko = mask ? mask_offs[us] : 0, kst = mask ? mask_st[u] : 0, ksf = mask ? mask_sf[u] : 0;
+  const int64_t oo = out_offs[us];
 
   for (int i = tid; i < NFFT; i += 256) {
     tw[i] = g_tw512[i];
     win[i] = g_hann512[i];
   }
-  // ---- masked spectra of frames tbase .. tbase+FPB-1 into LDS
-  {
-    const int64_t mo = mix_offs[u], mst = mix_st[u], msf = mix_sf[u];
-    const int64_t ko = mask ? mask_offs[us] : 0, kst = mask ? mask_st[u] : 0, ksf = mask ? mask_sf[u] : 0;
-    const int total = FPB * NBIN;
-    for (int i = tid; i < total; i += 256) {
-      int fr, k;
-      if (mst == 1) {
-        k = i / FPB;
-        fr = i - k * FPB;
-      } else {
-        fr = i / NBIN;
-        k = i - fr * NBIN;
-      }
-      const int t = tbase + fr;
-      float2 x = make_float2(0.f, 0.f);
-      if (t >= 0 && t < T) {
-        x = mix[mo + (int64_t)t * mst + (int64_t)k * msf];
-        if (mask) {
-          const float m = mask[ko + (int64_t)t * kst + (int64_t)k * ksf];
-          x.x *= m;
-          x.y *= m;
+  if (tile0 > 0) {  // the 3 frames before this block's first tile
+    const int tf = tile0 * FPB - 3;
+    istft_load<3>(rows, tf, T, mix, mo, mst, msf, mask, ko, kst, ksf);
+    __syncthreads();
+    if (fr < 3) istft_frame(rows[(tf + fr + 3) % RING], tw, win, j);
+  }
+  for (int tile = tile0; tile < tile1; ++tile) {
+    const int t0 = tile * FPB;
+    __syncthreads();  // the previous tile's overlap-add is done with the slots about to be refilled
+    istft_load<FPB>(rows, t0, T, mix, mo, mst, msf, mask, ko, kst, ksf);
+    __syncthreads();
+    istft_frame(rows[(t0 + fr + 3) % RING], tw, win, j);
+    __syncthreads();
+    // overlap-add in increasing frame order, window-sum-square normalisation, trim, convert
+    for (int i = tid; i < FPB * HOP; i += 256) {
+      const int hp = t0 + (i >> 7), m0 = i & (HOP - 1);
+      const int n = hp * HOP + m0 - NFFT / 2;
+      if (n < 0 || n >= nout) continue;
+      float acc = 0.f, wss = 0.f;
+#pragma unroll
+      for (int q = 3; q >= 0; --q) {
+        const int t = hp - q;
+        if (t >= 0 && t < T) {
+          const int m = q * HOP + m0;
+          acc += reinterpret_cast<const float*>(rows[(t + 3) % RING])[m];
+          const float w = win[m];
+          wss += w * w;
         }
       }
-      rows[fr][k] = x;
-    }
-  }
-  __syncthreads();
-
-  // ---- inverse real FFT of the 16 frames (one per 16-lane group), windowed, left in rows[fr] as 512 floats
-  {
-    const int j = lane & 15, g = lane >> 4;
-    const int fr = 4 * wave + g;
-    float2 z[16];
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-      const int k = 16 * n1 + j;
-      float2 a = rows[fr][k];
-      float2 b = rows[fr][256 - k];
-      if (k == 0) {  // irfft ignores Im X[0] and Im X[256]
-        a.y = 0.f;
-        b.y = 0.f;
+      if (wss > 1.17549435e-38f) acc /= wss;
+      if (wav_out) wav_out[oo + n] = acc;
+      if (pcm_out) {
+        const float sv = acc * 32767.0f;
+        pcm_out[oo + n] = (int16_t)(long long)sv;  // truncation toward zero, wrap on overflow
       }
-      b.y = -b.y;  // conj(X[256-k])
-      const float2 xe = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-      const float2 hd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-      const float2 wk = make_float2(tw[k].x, -tw[k].y);  // conj(W^k)
-      const float2 xo = cmul(hd, wk);
-      // Z = Xe + i Xo ; feed conj(Z) to the forward FFT
-      z[n1] = make_float2(xe.x - xo.y, -(xe.y + xo.x));
-    }
-    wave_sync();  // all reads of rows[fr] are done before the row is overwritten below
-    fft256_g16(z, xch[4 * wave + g], tw, j);
-    float* tf = reinterpret_cast<float*>(&rows[fr][0]);
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) {  // z[k2] = Y[n], n = j + 16 k2; x[2n] = Re Y / 256, x[2n+1] = -Im Y / 256
-      const int n = j + 16 * k2;
-      const float2 w = *reinterpret_cast<const float2*>(&win[2 * n]);
-      *reinterpret_cast<float2*>(&tf[2 * n]) =
-          make_float2(w.x * (z[k2].x * (1.0f / 256.0f)), w.y * (-z[k2].y * (1.0f / 256.0f)));
-    }
-  }
-  __syncthreads();  // every frame of the chunk is in LDS
-
-  // ---- overlap-add in increasing frame order, window-sum-square normalisation, trim, convert
-  const int64_t oo = out_offs[us];
-  for (int i = tid; i < HPB * HOP; i += 256) {
-    const int n = c * HPB * HOP + i;
-    if (n >= nout) break;
-    const int p = n + NFFT / 2;
-    const int hp = p >> 7;
-    float acc = 0.f, wss = 0.f;
-#pragma unroll
-    for (int q = 3; q >= 0; --q) {
-      const int t = hp - q;
-      if (t >= 0 && t < T) {
-        const int m = p - t * HOP;
-        const float* tf = reinterpret_cast<const float*>(&rows[t - tbase][0]);
-        acc += tf[m];
-        const float w = win[m];
-        wss += w * w;
-      }
-    }
-    if (wss > 1.17549435e-38f) acc /= wss;
-    if (wav_out) wav_out[oo + n] = acc;
-    if (pcm_out) {
-      const float sv = acc * 32767.0f;
-      pcm_out[oo + n] = (int16_t)(long long)sv;  // truncation toward zero, wrap on overflow
     }
   }
 }
@@ -381,9 +415,14 @@ extern "C" int sk_mask_istft(const void* mix_c64, const int64_t* mix_offs, const
   SK_CHECK_ARG(!mask || (mask_offs && mask_st && mask_sf), "sk_mask_istft: mask given without its strides");
   SK_CHECK_ARG(wav_out || pcm_out, "sk_mask_istft: no output buffer");
   SK_CHECK_ARG(nutt > 0 && S > 0 && (int64_t)nutt * S <= 65535 && max_frames > 1, "sk_mask_istft: bad sizes");
-  dim3 grid((unsigned)sk_cdiv((int64_t)HOP * (max_frames - 1), HPB * HOP), (unsigned)(nutt * S));
+  // tiles of 16 hops per (utterance, source); a workgroup walks `tpb` of them so that every frame is transformed
+  // once, as long as that still leaves a few workgroups per CU
+  const int ntiles = max_frames / FPB + 1;
+  const int64_t total = (int64_t)ntiles * nutt * S;
+  const int tpb = (int)std::min<int64_t>(std::max<int64_t>(total / 2048, 2), ntiles);
+  dim3 grid((unsigned)sk_cdiv(ntiles, tpb), (unsigned)(nutt * S));
   hipLaunchKernelGGL(istft_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float2*)mix_c64, mix_offs, mix_st,
-                     mix_sf, mask, mask_offs, mask_st, mask_sf, nframes, S, wav_out, pcm_out, out_offs);
+                     mix_sf, mask, mask_offs, mask_st, mask_sf, nframes, S, wav_out, pcm_out, out_offs, tpb);
   SK_CHECK_LAUNCH("sk_mask_istft");
   return SK_OK;
 }
