@@ -85,6 +85,14 @@ int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bi
                        int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
                        int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws,
                        sk_stream_t stream);
+/* Same contract, bf16 matrix-core inputs (BASELINE configs[3]: "bf16"): A and B stay fp32 in memory and are
+ * rounded to bf16 (round-to-nearest-even) on the way into the matrix cores; products are exact and are
+ * accumulated in fp32; C, bias, slabs are fp32.  Equals an fp32 GEMM of the bf16-rounded operands up to
+ * summation order. */
+int sk_gemm_bf16_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                        int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
+                        int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws,
+                        sk_stream_t stream);
 
 /* ---------------------------------------------------------------- BLSTM recurrence
  * One bidirectional LSTM layer's time recurrence (the part of nn.LSTM, reference

@@ -191,6 +191,187 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// bf16-input variant (BASELINE configs[3]: "bf16 MFMA inputs, fp32 accumulate").  Operands stay fp32 in
+// HBM -- no second copy of weights or activations exists -- and are rounded to bf16 (RNE) on their way
+// into LDS; the matrix cores run v_mfma_f32_32x32x16_bf16 with fp32 accumulators, and the epilogue, the
+// split-K slabs and their fixed-order reduction are the fp32 kernel's.  Same 128x128 block / 2x2 waves /
+// 64x64 per wave; K step 32.  Both operands are kept [tile row][32 k] in LDS (64 B per row), which is the
+// fragment shape of the bf16 MFMA (lane: row l&31, eight consecutive k at 8*(l>>5)); a k-major operand
+// (transA / !transB) is transposed in registers by the thread that fetched its 4 k x 4 row patch.
+// LDS image swizzle (no padding): row r, 16-byte chunk c  ->  256 B * (r>>2) + 64 B * ((r&3) ^ ((r>>4)&3))
+// + 16 B * (c ^ ((r>>2)&3)): fragment reads (16 rows x one chunk) and row-wise writes are conflict-free,
+// patch-transposed writes are 2-way.
+namespace bf {
+
+constexpr int BK = 32;
+constexpr int PIECES = BK * BM / 4 / 256;  // 4 float4 per thread per operand tile
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int lds_off(int r, int c) {  // byte offset of chunk c of row r
+  return ((r >> 2) << 8) + ((((r & 3) ^ ((r >> 4) & 3))) << 6) + ((c ^ ((r >> 2) & 3)) << 4);
+}
+
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+  bf16x4 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  v[2] = (__bf16)c;
+  v[3] = (__bf16)d;
+  return v;
+}
+
+// KMAJOR == false: operand stored [tile dim][K]: piece i = row idx/8, k (idx%8)*4 .. +3, idx = tid + 256 i
+// KMAJOR == true : operand stored [K][tile dim]: piece i = k 4*(tid>>5) + i, rows (tid&31)*4 .. +3
+template <bool KMAJOR>
+__device__ __forceinline__ void fetch(const float* __restrict__ P, int ld, int dim0, int dimLimit, int k0, int K,
+                                      bool fast, int tid, float4 (&r)[PIECES]) {
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) {
+    int row, col, rowLimit, colLimit;  // element (row, col..col+3) of the stored matrix
+    if (KMAJOR) {
+      row = k0 + 4 * (tid >> 5) + i;
+      col = dim0 + (tid & 31) * 4;
+      rowLimit = K;
+      colLimit = dimLimit;
+    } else {
+      const int idx = tid + 256 * i;
+      row = dim0 + (idx >> 3);
+      col = k0 + (idx & 7) * 4;
+      rowLimit = dimLimit;
+      colLimit = K;
+    }
+    if (fast) {
+      r[i] = *reinterpret_cast<const float4*>(P + (int64_t)row * ld + col);
+    } else {
+      const bool rok = row < rowLimit;
+      const float* q = P + (int64_t)min(row, rowLimit - 1) * ld;
+      const int cmax = colLimit - 1;
+      const float v0 = q[min(col + 0, cmax)], v1 = q[min(col + 1, cmax)];
+      const float v2 = q[min(col + 2, cmax)], v3 = q[min(col + 3, cmax)];
+      r[i].x = (rok && col + 0 < colLimit) ? v0 : 0.f;
+      r[i].y = (rok && col + 1 < colLimit) ? v1 : 0.f;
+      r[i].z = (rok && col + 2 < colLimit) ? v2 : 0.f;
+      r[i].w = (rok && col + 3 < colLimit) ? v3 : 0.f;
+    }
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void stash(char* S, int tid, const float4 (&r)[PIECES]) {
+  if (KMAJOR) {
+    const int kq = tid >> 5, r0 = (tid & 31) * 4;  // k = 4 kq .. +3 -> chunk kq>>1, half kq&1
+    *reinterpret_cast<bf16x4*>(S + lds_off(r0 + 0, kq >> 1) + (kq & 1) * 8) = pack4(r[0].x, r[1].x, r[2].x, r[3].x);
+    *reinterpret_cast<bf16x4*>(S + lds_off(r0 + 1, kq >> 1) + (kq & 1) * 8) = pack4(r[0].y, r[1].y, r[2].y, r[3].y);
+    *reinterpret_cast<bf16x4*>(S + lds_off(r0 + 2, kq >> 1) + (kq & 1) * 8) = pack4(r[0].z, r[1].z, r[2].z, r[3].z);
+    *reinterpret_cast<bf16x4*>(S + lds_off(r0 + 3, kq >> 1) + (kq & 1) * 8) = pack4(r[0].w, r[1].w, r[2].w, r[3].w);
+  } else {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;
+      *reinterpret_cast<bf16x4*>(S + lds_off(row, q >> 1) + (q & 1) * 8) = pack4(r[i].x, r[i].y, r[i].z, r[i].w);
+    }
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs g) {
+  constexpr int TILE = BM * BK * 2;  // bytes of one operand image
+  __shared__ __attribute__((aligned(256))) char As[2][TILE];
+  __shared__ __attribute__((aligned(256))) char Bs[2][TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
+    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+  }
+  const int m0 = (tile / g.tilesN) * BM, n0 = (tile % g.tilesN) * BN;
+  const bool fullA = g.vecA && (m0 + BM <= g.M), fullB = g.vecB && (n0 + BN <= g.N);
+  const int z = blockIdx.z, ks = blockIdx.y;
+  const float* A = g.A + z * g.sA;
+  const float* B = g.B + z * g.sB;
+  const bool partial = g.splitk > 1;
+  float* C = partial ? g.slabs + ((int64_t)z * g.splitk + ks) * g.M * g.N : g.C + z * g.sC;
+  const int ldc = partial ? g.N : g.ldc;
+  const float* bias = (g.bias && !partial) ? g.bias + z * g.sbias : nullptr;
+  const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);  // kchunk is a multiple of BK
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  float4 ra[PIECES], rb[PIECES];
+  fetch<TA>(A, g.lda, m0, g.M, kbeg, kend, fullA && kbeg + BK <= kend, tid, ra);
+  fetch<!TB>(B, g.ldb, n0, g.N, kbeg, kend, fullB && kbeg + BK <= kend, tid, rb);
+  stash<TA>(As[0], tid, ra);
+  stash<!TB>(Bs[0], tid, rb);
+  __syncthreads();
+
+  const int kh = lane >> 5, l31 = lane & 31;
+  // fragment byte offsets: k step s uses chunk 2 s + kh; the swizzle makes step 1 = step 0 ^ 32
+  const int oa0 = lds_off(wm * 64 + l31, kh), oa1 = lds_off(wm * 64 + 32 + l31, kh);
+  const int ob0 = lds_off(wn * 64 + l31, kh), ob1 = lds_off(wn * 64 + 32 + l31, kh);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) {
+      const int k0 = kbeg + (kt + 1) * BK;
+      const bool kfull = k0 + BK <= kend;  // block-uniform
+      fetch<TA>(A, g.lda, m0, g.M, k0, kend, fullA && kfull, tid, ra);
+      fetch<!TB>(B, g.ldb, n0, g.N, k0, kend, fullB && kfull, tid, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(As[cur] + (oa0 ^ (s << 5)));
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(As[cur] + (oa1 ^ (s << 5)));
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bs[cur] + (ob0 ^ (s << 5)));
+      const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bs[cur] + (ob1 ^ (s << 5)));
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (more) {
+      stash<TA>(As[cur ^ 1], tid, ra);
+      stash<!TB>(Bs[cur ^ 1], tid, rb);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < g.M) {
+          float* cp = C + (int64_t)row * ldc + col;
+          float v = acc[i][j][r] + bv;
+          if (!partial) {
+            if (g.accumulate) v += *cp;
+            if (g.act == 1) v = sk_sigmoid(v);
+          }
+          *cp = v;
+        }
+      }
+    }
+}
+
+}  // namespace bf
+
 // C = act(sum_ks slabs[z][ks] + bias (+ C)), slices added in fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   const int z = blockIdx.z;
@@ -245,14 +426,17 @@ extern "C" int sk_gemm_f32(const float* A, const float* B, float* C, const float
                             sbias, 1, nullptr, stream);
 }
 
-extern "C" int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
-                           int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA,
-                           int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
-  SK_CHECK_ARG(A && B && C, "sk_gemm_f32: null pointer");
-  SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm_f32: bad splitk %d / missing workspace", splitk);
-  SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm_f32: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
-  SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm_f32: leading dimension too small");
-  SK_CHECK_ARG(act == 0 || act == 1, "sk_gemm_f32: unknown activation %d", act);
+namespace {
+
+int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
+                int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
+  SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
+  SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
+  SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
+  SK_CHECK_ARG(act == 0 || act == 1, "sk_gemm: unknown activation %d", act);
+  const int bk = bf16 ? bf::BK : BK;
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -261,23 +445,34 @@ extern "C" int sk_gemm_f32_splitk(const float* A, const float* B, float* C, cons
   g.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
   g.tilesN = (int)sk_cdiv(N, BN);
   g.sA = sA; g.sB = sB; g.sC = sC; g.sbias = sbias;
-  g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), BK) * BK);
+  g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), bk) * bk);
   splitk = (int)sk_cdiv(K, g.kchunk);  // slices that actually hold work
   g.splitk = splitk;
   g.slabs = (float*)ws;
   const int64_t tiles = sk_cdiv(M, BM) * g.tilesN;
-  SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm_f32: too many tiles");
+  SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm: too many tiles");
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
-  if (!transA && !transB)
-    hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
-  else if (!transA && transB)
-    hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
-  else if (transA && !transB)
-    hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
-  else
-    hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
-  SK_CHECK_LAUNCH("sk_gemm_f32");
+  if (bf16) {
+    if (!transA && !transB)
+      hipLaunchKernelGGL((bf::gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, g);
+    else if (!transA && transB)
+      hipLaunchKernelGGL((bf::gemm_bf16_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else if (transA && !transB)
+      hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, g);
+  } else {
+    if (!transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
+    else if (!transA && transB)
+      hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else if (transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
+  }
+  SK_CHECK_LAUNCH("sk_gemm");
   if (splitk > 1) {
     const int64_t quads = sk_cdiv((int64_t)M * N, 4);
     const unsigned nb = (unsigned)(sk_cdiv(quads, 256) > 2048 ? 2048 : sk_cdiv(quads, 256));
@@ -285,4 +480,20 @@ extern "C" int sk_gemm_f32_splitk(const float* A, const float* B, float* C, cons
     SK_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return SK_OK;
+}
+
+}  // namespace
+
+extern "C" int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                           int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA,
+                           int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
+  return gemm_launch(false, A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, accumulate, act, batch, sA, sB, sC,
+                     sbias, splitk, ws, stream);
+}
+
+extern "C" int sk_gemm_bf16_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
+                           int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA,
+                           int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
+  return gemm_launch(true, A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, accumulate, act, batch, sA, sB, sC,
+                     sbias, splitk, ws, stream);
 }

@@ -103,10 +103,11 @@ def pick_splitk(M, N, K, batch=1):
 
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, accumulate=False, act=0,
-         batch=1, sA=0, sB=0, sC=0, sbias=0, splitk=1, ws_tag="gemm"):
+         batch=1, sA=0, sB=0, sC=0, sbias=0, splitk=1, ws_tag="gemm", bf16=False):
     """Cout[M,N] = act(opA(A) opB(B) + bias (+ Cout)).  A/B/Cout are tensors whose data_ptr() is the
     first element of the operand (views are fine: leading dimensions are explicit).  splitk > 1 (or 0 =
-    choose) splits K into deterministic partial slabs -- for weight gradients."""
+    choose) splits K into deterministic partial slabs -- for weight gradients.  bf16=True rounds A and B to
+    bf16 on the way into the matrix cores (fp32 accumulate; everything in memory stays fp32)."""
     for t in (A, B, Cout, bias):
         _chk(t)
     if splitk == 0:
@@ -114,8 +115,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     ws = None
     if splitk > 1:
         ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
-    with _timed("gemm_f32_kernel", 2.0 * M * N * K * batch):
-        _lib.call("sk_gemm_f32_splitk", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA),
+    with _timed("gemm_bf16_kernel" if bf16 else "gemm_f32_kernel", 2.0 * M * N * K * batch):
+        _lib.call("sk_gemm_bf16_splitk" if bf16 else "sk_gemm_f32_splitk", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA),
                   int(transB), int(accumulate), int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws), _stream())
 
 

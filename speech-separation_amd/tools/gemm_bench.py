@@ -24,12 +24,13 @@ SHAPES = [  # name, M, N, K, transA, transB, batch, splitk
 
 
 def main():
+    bf16 = "--bf16" in sys.argv
     for name, M, N, K, tA, tB, batch, sk in SHAPES:
         A = torch.randn((K, M * batch) if tA else (M, K), device="cuda")
         B = torch.randn((N, K) if tB else (K, N * batch), device="cuda")
         C = torch.empty(batch, M, N, device="cuda")
         lda, ldb = A.shape[1], B.shape[1]
-        kw = dict(transA=tA, transB=tB, batch=batch, sA=M if batch > 1 else 0, sB=N if batch > 1 else 0, sC=M * N, splitk=sk)
+        kw = dict(transA=tA, transB=tB, batch=batch, sA=M if batch > 1 else 0, sB=N if batch > 1 else 0, sC=M * N, splitk=sk, bf16=bf16)
         used = ops.pick_splitk(M, N, K, batch) if sk == 0 else sk
         for _ in range(2):
             ops.gemm(A, B, C, M, N, K, lda, ldb, N, **kw)

@@ -46,6 +46,43 @@ def test_gemm_matches_fp64(ops, M, N, K, tA, tB):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,tA,tB", [
+    (300, 200, 257, False, True), (256, 256, 64, False, False), (256, 256, 64, True, False), (256, 256, 64, False, True),
+    (256, 256, 64, True, True), (130, 514, 96, False, True), (1000, 72, 1, False, False), (129, 131, 300, True, False),
+    (64, 1792, 514, False, False), (257, 384, 1000, True, False),
+])
+def test_gemm_bf16_equals_fp32_product_of_rounded_operands(ops, M, N, K, tA, tB):
+    """bf16 x bf16 products are exact in fp32, so the bf16-input kernel must agree with an fp64 product of the
+    bf16-ROUNDED operands to fp32 summation error -- the same tolerance as the fp32 kernel (BASELINE configs[3])."""
+    g = torch.Generator().manual_seed(M * 11 + N)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    Ar, Br = A.bfloat16().double(), B.bfloat16().double()        # torch rounds to nearest even, like v_cvt_pk_bf16_f32
+    ref = (Ar.t() if tA else Ar) @ (Br.t() if tB else Br) + bias.double()
+    C = torch.full((M, N), float("nan")).cuda()
+    ops.gemm(dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N, transA=tA, transB=tB, bias=dev(bias), bf16=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
+
+
+def test_gemm_bf16_splitk_batch_accumulate(ops):
+    g = torch.Generator().manual_seed(77)
+    K, M, N = 3000, 140, 257
+    A, B = torch.randn(K, 2 * M, generator=g), torch.randn(K, 2 * N, generator=g)
+    bias, C0 = torch.randn(N, generator=g), torch.randn(2, M, N, generator=g)
+    Ar, Br = A.bfloat16().double(), B.bfloat16().double()
+    ref = torch.stack([Ar[:, d * M:(d + 1) * M].t() @ Br[:, d * N:(d + 1) * N] for d in range(2)]) + bias.double() + C0.double()
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        ops.gemm(dev(A), dev(B), C, M, N, K, 2 * M, 2 * N, N, transA=True, bias=dev(bias), accumulate=True, batch=2,
+                 sA=M, sB=N, sC=M * N, splitk=3, bf16=True)
+        outs.append(C.cpu())
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_accumulate_sigmoid_batch_and_ld(ops):
     g = torch.Generator().manual_seed(5)
     # batch of 2 TN products out of strided storage: A (K, 2*M) and B (K, 2*N), like dW_hh

@@ -19,7 +19,7 @@ def declared_symbols():
 
 def test_header_declares_the_hot_path():
     syms = declared_symbols()
-    for need in ("sk_stft", "sk_mask_istft", "sk_gemm_f32", "sk_lstm_fwd", "sk_lstm_bwd", "sk_bn_stats",
+    for need in ("sk_stft", "sk_mask_istft", "sk_gemm_f32", "sk_gemm_bf16_splitk", "sk_lstm_fwd", "sk_lstm_bwd", "sk_bn_stats",
                  "sk_pit_mse_fwd", "sk_pit_mse_bwd", "sk_clip_adam", "sk_last_error", "sk_version"):
         assert need in syms
 
