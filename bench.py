@@ -28,6 +28,7 @@ for p in (ROOT, PKG, os.path.join(PKG, "archs")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* at 64 FLOP/clk/SIMD, 256 CUs, 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 
@@ -50,6 +51,9 @@ def parse():
     ap.add_argument("--num-spk", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--frames", type=int, default=400)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: BASELINE configs[3] arithmetic (bf16 matrix-core inputs for the non-recurrent GEMMs, "
+                         "fp32 accumulate); the headline metric is quoted on f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--aux", action="store_true", help="also time the STFT / iSTFT kernels (extra JSON fields)")
@@ -139,13 +143,14 @@ def main():
         arch_mod = uPIT
 
     H, L, S, B, T = args.hidden, args.layers, args.num_spk, args.batch, args.frames
+    DT = "bf16" if args.dtype == "bf16" else "fp32"
     torch.manual_seed(0)                                  # identical initial weights on every rank
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # SepDNN prints its conf keys like the reference does
         if args.arch == "rsh":
-            model = arch_mod.SepDNN(local, hidden_dim=str(H), num_layers=str(L))
+            model = arch_mod.SepDNN(local, hidden_dim=str(H), num_layers=str(L), dtype=DT)
         else:
-            model = uPIT.SepDNN(local, num_spk=str(S), hidden_dim=str(H), num_layers=str(L))
+            model = uPIT.SepDNN(local, num_spk=str(S), hidden_dim=str(H), num_layers=str(L), dtype=DT)
     model.cuda()
     model.train()
     model.hidden_generator = torch.Generator(device="cuda")
@@ -206,7 +211,7 @@ def main():
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * dt / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("RSH %dx%d BLSTM over [mix|attention], %d-spk (%d passes per step), " % (L, H, S, S)
                                 if args.arch == "rsh" else "uPIT %dx%d BLSTM, %d-spk, " % (L, H, S)) +
                                "512-pt STFT (257 bins), batch %d x %d frames per GPU, fwd + %s + bwd + clip 0.25 + Adam, "
@@ -216,10 +221,12 @@ def main():
                    "mean_loss": round(final_loss, 6)},
     }
     if prof:
-        n, ms, fl = prof["gemm_f32_kernel"]
+        kname = "gemm_bf16_kernel" if args.dtype == "bf16" else "gemm_f32_kernel"
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        n, ms, fl = prof[kname]
         ach = fl / (ms * 1e-3) / 1e12
-        res["roofline"] = {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": round(ach, 2),
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+        res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
+                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                            "traffic": None, "launches_per_step": n // args.steps,
                            "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms / args.steps, 3)}
         res["kernels"] = {k: {"launches_per_step": v[0] // args.steps, "ms_per_step": round(v[1] / args.steps, 3),
@@ -230,7 +237,7 @@ def main():
         else:
             P = sum(2 * 4 * H * ((257 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257 * S
         res["step_tflops"] = round(6.0 * P * frames_per_step / world / (dt / args.steps) / 1e12, 2)
-        res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+        res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)  # vs the fp32 peak
     if args.aux and rank == 0:
         res["aux"] = aux_kernels(torch, ops, pcms, mix, T, B, S)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

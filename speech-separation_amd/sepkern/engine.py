@@ -64,7 +64,13 @@ class ParamLayout:
 class Engine:
     """Forward / backward of the network on one device."""
 
-    def __init__(self, in_dim, out_dim, hidden, layers, device):
+    def __init__(self, in_dim, out_dim, hidden, layers, device, precision="fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise SepkernError("precision must be 'fp32' or 'bf16' (got %r)" % (precision,))
+        # bf16: the matrix products outside the time recurrence (input projections, Linear, their dgrad and
+        # wgrad: 72 % of the step's FLOPs) round their operands to bf16 on the way into the matrix cores and
+        # accumulate in fp32; parameters, activations, gradients, Adam and the recurrence stay fp32.
+        self.precision, self.bf16 = precision, precision == "bf16"
         if hidden % 4 != 0 or hidden > 1024:
             raise SepkernError("hidden_dim must be a multiple of 4 and <= 1024 (got %d)" % hidden)
         self.I, self.O, self.H, self.L = in_dim, out_dim, hidden, layers
@@ -126,7 +132,7 @@ class Engine:
             bsum = torch.empty(8 * H, device=dev)
             ops.colsum(self.flat[off_ih:], 2, 8 * H, 8 * H, bsum)
             gx = torch.empty(T, B, 2, 4 * H, device=dev)
-            ops.gemm(inp, wih, gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum)
+            ops.gemm(inp, wih, gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum, bf16=self.bf16)
             y = torch.empty(T, B, 2 * H, device=dev)
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
             ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
@@ -147,7 +153,7 @@ class Engine:
         ops.bn_apply(y2d, mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
         mask = torch.empty(T, B, O, device=dev)
         ops.gemm(xbn, self.p("lin.weight"), mask, R, O, 2 * H, 2 * H, 2 * H, O, transB=True,
-                 bias=self.p("lin.bias"), act=1)
+                 bias=self.p("lin.bias"), act=1, bf16=self.bf16)
         ctx = None
         if save:
             ctx = dict(saved=saved, mean=mean, var=var, xbn=xbn, mask=mask, lens=lens, h0=h0, c0=c0,
@@ -178,10 +184,10 @@ class Engine:
         dz = torch.empty_like(dmask)
         ops.sigmoid_bwd(dmask, ctx["mask"], dz)
         ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), O, 2 * H, R, O, 2 * H, 2 * H, transA=True, accumulate=acc,
-                 splitk=0)
+                 splitk=0, bf16=self.bf16)
         ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc)
         dxbn = torch.empty(R, 2 * H, device=dev)
-        ops.gemm(dz, self.p("lin.weight"), dxbn, R, 2 * H, O, O, 2 * H, 2 * H)
+        ops.gemm(dz, self.p("lin.weight"), dxbn, R, 2 * H, O, O, 2 * H, 2 * H, bf16=self.bf16)
         del dz
         y_top = ctx["saved"][-1][3].view(R, 2 * H)
         dy = torch.empty(R, 2 * H, device=dev)
@@ -213,7 +219,7 @@ class Engine:
                               dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, I, device=dev)
-                ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy_next, R, I, 8 * H, 8 * H, I, I)
+                ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy_next, R, I, 8 * H, 8 * H, I, I, bf16=self.bf16)
                 if l == 0:
                     dx = dy_next.view(T, B, I)
             stream = self.side if (overlap and l > 0) else main
@@ -225,10 +231,10 @@ class Engine:
                 ops.lstm_hprev(y, h0[2 * l:2 * l + 2], lens, hprev, T, B, H)
                 # dW_hh[d] = dgx[:, d]^T hprev[:, d]   (two directions as a batch of 2)
                 ops.gemm(dgx, hprev, self.g("weight_hh_l%d" % l), 4 * H, H, R, 8 * H, 2 * H, H, transA=True,
-                         accumulate=acc, batch=2, sA=4 * H, sB=H, sC=4 * H * H, splitk=0, ws_tag="gemm_" + tag)
+                         accumulate=acc, batch=2, sA=4 * H, sB=H, sC=4 * H * H, splitk=0, ws_tag="gemm_" + tag, bf16=self.bf16)
                 # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
                 ops.gemm(dgx, inp, self.g("weight_ih_l%d" % l), 8 * H, I, R, 8 * H, I, I, transA=True, accumulate=acc,
-                         splitk=0, ws_tag="gemm_" + tag)
+                         splitk=0, ws_tag="gemm_" + tag, bf16=self.bf16)
                 db = torch.empty(8 * H, device=dev)
                 ops.colsum(dgx, R, 8 * H, 8 * H, db, ws_tag="bn_" + tag)
                 put("bias_ih_l%d" % l, db.view(2, 4 * H))

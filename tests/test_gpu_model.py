@@ -183,6 +183,56 @@ def test_configs_match_oracle(arch, H, L, S, B, T):
     assert np.abs(mask - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("H,L,S,B,T", [(600, 2, 3, 5, 30), (896, 3, 3, 4, 12)])
+def test_bf16_config_matches_bf16_oracle_and_fp32_within_tolerance(arch, H, L, S, B, T):
+    """BASELINE configs[3] (3 speakers, bf16 matrix-core inputs): the HIP path against a CPU computation of the
+    SAME arithmetic (oracle/upit_bf16.py: operands of every non-recurrent product rounded to bf16, fp32
+    accumulate) at a tight tolerance, and against the fp32 oracle at the stated bf16 tolerance (2e-2 abs on
+    masks)."""
+    from oracle import upit_bf16 as OB
+    torch.manual_seed(H + L + 1)
+    rng = np.random.default_rng(H + 1)
+    model = arch.SepDNN(0, num_spk=str(S), hidden_dim=str(H), num_layers=str(L), dtype="bf16")
+    model.cuda()
+    model.train()
+    orc = _oracle_like(model, H, L, S)
+    orc.train()
+    lens = sorted([int(v) for v in rng.integers(max(2, T // 2), T + 1, B)])
+    lens[-1] = T
+    samples = []
+    for n in lens:
+        d = {"mix": np.abs(rng.standard_normal((n, 257))).astype(np.float32)}
+        for s in range(S):
+            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((n, 257))).astype(np.float32) * 0.6
+        samples.append(d)
+    batch = arch.Collator("mix")(samples)
+    h0, c0 = torch.randn(2 * L, B, H), torch.randn(2 * L, B, H)
+    lo, no, aux = OB.compute_loss(orc, OU.collate(samples), (h0, c0))
+    lo.backward()
+    model.next_hidden = (h0.cuda(), c0.cuda())
+    loss, norm = arch.compute_loss(model, 0, batch)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(lo), rtol=2e-4)
+    assert float(norm) == float(no)
+    og = dict(orc.named_parameters())
+    for k, p in model.named_parameters():
+        ref = og[k].grad
+        err = float((p.grad.cpu().double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
+        assert err < 3e-3, (k, err)        # an fp32 rounding-order difference can flip a bf16 rounding (2^-9 rel)
+    model.next_hidden = (h0.cuda(), c0.cuda())
+    model.hidden = model.init_hidden(B)
+    with torch.no_grad():
+        mask = model(batch["mix"]).cpu().numpy()
+    ref = aux["mask_out"].detach().numpy()
+    assert np.abs(mask - ref).max() <= 2e-3
+    # against the fp32 oracle: the bf16 tolerance
+    orc32 = _oracle_like(model, H, L, S)
+    orc32.train()
+    l32, _, a32 = OU.compute_loss(orc32, OU.collate(samples), (h0, c0))
+    assert np.abs(mask - a32["mask_out"].detach().numpy()).max() <= 2e-2
+    assert abs(float(loss) - float(l32)) <= 1e-2 * abs(float(l32))
+
+
 def test_end_to_end_si_sdr_parity(arch):
     """wav -> STFT -> masks -> mask-apply + iSTFT -> int16 wav, GPU path vs oracle path, SI-SDR +-0.1 dB."""
     from sepkern import ops, synth

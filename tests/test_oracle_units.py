@@ -126,3 +126,44 @@ def test_si_sdr_known_values():
     noise -= noise.dot(ref) / ref.dot(ref) * ref
     est = ref + noise * np.sqrt(ref.dot(ref) / noise.dot(noise)) * 0.1
     np.testing.assert_allclose(O.si_sdr(est, ref), 20.0, atol=0.05)
+
+
+def test_bf16_oracle_without_rounding_is_the_fp32_oracle(monkeypatch):
+    """oracle/upit_bf16.py restates the step with bf16-rounded GEMM operands (BASELINE configs[3]); with the
+    rounding switched off it must reproduce the golden-pinned fp32 oracle (loss, masks, every gradient)."""
+    from oracle import upit_bf16 as OB
+    torch.manual_seed(3)
+    rng = np.random.default_rng(3)
+    S, H, L = 3, 24, 2
+    model = O.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
+    model.train()
+    samples = []
+    for n in (9, 14, 11, 14):
+        d = {"mix": np.abs(rng.standard_normal((n, 257))).astype(np.float32)}
+        for s in range(S):
+            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((n, 257))).astype(np.float32) * 0.5
+        samples.append(d)
+    batch = O.collate(samples)
+    hidden = (torch.randn(2 * L, 4, H), torch.randn(2 * L, 4, H))
+    l0, n0, a0 = O.compute_loss(model, batch, hidden)
+    l0.backward()
+    g0 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    rm = model.bn.running_mean.clone()
+    model.bn.running_mean.zero_()
+    model.bn.running_var.fill_(1.0)
+    monkeypatch.setattr(OB, "rnd", lambda x: x)
+    l1, n1, a1 = OB.compute_loss(model, batch, hidden)
+    l1.backward()
+    assert float(n0) == float(n1)
+    np.testing.assert_allclose(float(l1), float(l0), rtol=1e-6)
+    np.testing.assert_allclose(a1["mask_out"].detach().numpy(), a0["mask_out"].detach().numpy(), atol=2e-6)
+    assert torch.equal(a1["indices"], a0["indices"])
+    np.testing.assert_allclose(model.bn.running_mean.numpy(), rm.numpy(), atol=1e-6)
+    for k, p in model.named_parameters():
+        err = float((p.grad - g0[k]).norm() / (g0[k].norm() + 1e-30))
+        assert err < 2e-5, (k, err)
+    # and with the rounding on it is a different (but close) computation
+    monkeypatch.undo()
+    l2, _, a2 = OB.compute_loss(model, batch, hidden)
+    assert 0 < abs(float(l2) - float(l0)) < 2e-2 * abs(float(l0))
+    assert np.abs(a2["mask_out"].detach().numpy() - a0["mask_out"].detach().numpy()).max() < 3e-2
