@@ -227,7 +227,7 @@ def main():
         ach = fl / (ms * 1e-3) / 1e12
         res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
                            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                           "traffic": None, "launches_per_step": n // args.steps,
+                           "traffic": pmc_traffic(kname), "launches_per_step": n // args.steps,
                            "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms / args.steps, 3)}
         res["kernels"] = {k: {"launches_per_step": v[0] // args.steps, "ms_per_step": round(v[1] / args.steps, 3),
                               "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in prof.items()}
@@ -248,6 +248,18 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same bench, gfx950 read correction applied) -- the
+    counters cannot be collected from inside this process, so the figure is the one measured by those runs,
+    or None when the file holds nothing for this kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def aux_kernels(torch, ops, pcms, mix, T, B, S):

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the PMC passes collected by profiles/collect.sh.
+
+    python profiles/pmc_traffic.py <tag>     # reads gpurun_out/prof_<tag>_{f32,bf16}_{FETCH_SIZE,WRITE_SIZE}
+
+Per-launch averages over every launch of a kernel in the run.  Counters are KB; FETCH_SIZE is doubled
+(MI355X_MICROARCH.md, HBM: gfx950 tallies 128-B read requests at 64 B), WRITE_SIZE is used as read.  Both
+count the L2s' memory-side requests, so Infinity-Cache hits are included.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+KEYS = ("gemm_f32_kernel", "gemm_bf16_kernel", "lstm_fwd_kernel", "lstm_bwd_kernel", "clip_adam", "pit_pair",
+        "pit_bwd", "bn_apply", "bn_bwd", "splitk_reduce", "colred", "sumsq")
+
+
+def main():
+    tag = sys.argv[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    acc = collections.defaultdict(lambda: {"FETCH_SIZE": [], "WRITE_SIZE": []})
+    for dt in ("f32", "bf16"):
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            files = glob.glob(os.path.join(root, "gpurun_out", "prof_%s_%s_%s" % (tag, dt, c), "**", "*counter_collection.csv"),
+                              recursive=True)
+            for r in csv.DictReader(open(files[0])):
+                for k in KEYS:
+                    if k in r["Kernel_Name"] and (dt == "f32" or k == "gemm_bf16_kernel"):
+                        acc[k][c].append(float(r["Counter_Value"]))
+    res = {}
+    for k, e in acc.items():
+        f = sum(e["FETCH_SIZE"]) / max(1, len(e["FETCH_SIZE"])) * 1024
+        w = sum(e["WRITE_SIZE"]) / max(1, len(e["WRITE_SIZE"])) * 1024
+        res[k] = {"launches": len(e["FETCH_SIZE"]), "fetch_bytes_raw": round(f), "fetch_bytes_x2": round(2 * f),
+                  "write_bytes": round(w), "hbm_bytes": round(2 * f + w)}
+    doc = {"_comment": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, profiles/collect.sh) "
+                       "over `python3 bench.py [--dtype bf16] --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events` on one "
+                       "MI355X; per-launch averages; FETCH_SIZE doubled per MI355X_MICROARCH.md; memory-side requests of "
+                       "the L2s (Infinity-Cache hits included).", "tag": tag, "kernels": res}
+    json.dump(doc, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    for k, v in sorted(res.items()):
+        print("%-18s n=%3d  fetch x2 %8.1f MB  write %8.1f MB" % (k, v["launches"], v["fetch_bytes_x2"] / 1e6, v["write_bytes"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int GROUP_M = 8;  // tile rows per L2 working-set group (see the kernels' tile order)
 // LDS row stride (floats) of a k-major operand image [BK][LD]: 132 keeps float4 rows 16-byte aligned for
 // operands that are k-major in memory; 129 makes the 4x4 transposing stash of [dim][K] operands
 // conflict-free (bank = 4q + r + row).  Fragment reads (32 consecutive floats) are conflict-free for both.
@@ -110,7 +111,17 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
     const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
     tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
   }
-  const int m0 = (tile / g.tilesN) * BM, n0 = (tile % g.tilesN) * BN;
+  // within a run, walk groups of GROUP_M tile rows column by column: the ~128 tiles an XCD has in flight
+  // then cover about GROUP_M x 16 tiles and share 8 A panels and 16 B panels in its 4 MB L2, instead of
+  // 2-3 A panels and every B panel of the matrix
+  int m0, n0;
+  {
+    const int tilesM = gridDim.x / g.tilesN, per = GROUP_M * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GROUP_M;
+    const int gsz = min(GROUP_M, tilesM - first);
+    m0 = (first + rem2 % gsz) * BM;
+    n0 = (rem2 / gsz) * BN;
+  }
   const bool fullA = g.vecA && (m0 + BM <= g.M), fullB = g.vecB && (n0 + BN <= g.N);
   const int z = blockIdx.z, ks = blockIdx.y;
   const float* A = g.A + z * g.sA;
@@ -288,7 +299,17 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs g) {
     const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
     tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
   }
-  const int m0 = (tile / g.tilesN) * BM, n0 = (tile % g.tilesN) * BN;
+  // within a run, walk groups of GROUP_M tile rows column by column: the ~128 tiles an XCD has in flight
+  // then cover about GROUP_M x 16 tiles and share 8 A panels and 16 B panels in its 4 MB L2, instead of
+  // 2-3 A panels and every B panel of the matrix
+  int m0, n0;
+  {
+    const int tilesM = gridDim.x / g.tilesN, per = GROUP_M * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GROUP_M;
+    const int gsz = min(GROUP_M, tilesM - first);
+    m0 = (first + rem2 % gsz) * BM;
+    n0 = (rem2 / gsz) * BN;
+  }
   const bool fullA = g.vecA && (m0 + BM <= g.M), fullB = g.vecB && (n0 + BN <= g.N);
   const int z = blockIdx.z, ks = blockIdx.y;
   const float* A = g.A + z * g.sA;
