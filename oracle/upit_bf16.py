@@ -6,12 +6,13 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  The reference itself has no reduc
 can be checked against a CPU computation of the SAME arithmetic (tight tolerance) and, separately, against
 the fp32 oracle (oracle/upit.py, loose "bf16" tolerance):
 
-  * every matrix product outside the time recurrence -- the LSTM input projections x W_ih^T
+  * every matrix product -- the LSTM input projections x W_ih^T and the recurrence h_{t-1} W_hh^T
     (archs/uPIT.py:132), nn.Linear (archs/uPIT.py:141), and in their backward passes the data gradients
-    dY W and the weight gradients dY^T X, including dW_hh = dG^T h_prev -- rounds BOTH operands to bf16
-    (round to nearest even) and accumulates the exact products in fp32;
-  * the recurrence h_{t-1} W_hh^T and its backward dG W_hh, the cell non-linearities, BatchNorm, the
-    PIT-MSE loss, gradient clipping and Adam are fp32, as are all tensors in memory.
+    dY W (incl. dG W_hh through time) and the weight gradients dY^T X (incl. dW_hh = dG^T h_prev) -- rounds
+    BOTH operands to bf16 (round to nearest even) and accumulates the exact products in fp32;
+  * the cell non-linearities and cell state, BatchNorm, the PIT-MSE loss, gradient clipping and Adam are
+    fp32, as are all tensors in memory (h_t itself is kept and emitted in fp32; only the copy that enters
+    the next step's product is rounded).
 """
 import torch
 from torch.nn.utils.rnn import pad_packed_sequence
@@ -40,18 +41,7 @@ class _Bf16Linear(torch.autograd.Function):
         return dyr @ wr, dyr.t() @ ar
 
 
-class _Recurrent(torch.autograd.Function):
-    """g = h w^T in fp32 ;  dh = dg w in fp32 ;  dw = rnd(dg)^T rnd(h) (a weight gradient: bf16 inputs)."""
-
-    @staticmethod
-    def forward(ctx, h, w):
-        ctx.save_for_backward(h, w)
-        return h @ w.t()
-
-    @staticmethod
-    def backward(ctx, dg):
-        h, w = ctx.saved_tensors
-        return dg @ w, rnd(dg).t() @ rnd(h)
+_Recurrent = _Bf16Linear          # g = rnd(h) rnd(w)^T ;  dh = rnd(dg) rnd(w) ;  dw = rnd(dg)^T rnd(h)
 
 
 def blstm_padded(x, lens, weights, h0, c0):
@@ -61,6 +51,7 @@ def blstm_padded(x, lens, weights, h0, c0):
     H = h0.shape[2]
     lens = torch.as_tensor(lens)
     inp = x
+    hn, cn = [], []
     for l in range(len(weights)):
         outs = []
         for d in range(2):
@@ -79,8 +70,10 @@ def blstm_padded(x, lens, weights, h0, c0):
                 h = torch.where(valid, h_new, h)
                 ys[t] = torch.where(valid, h_new, torch.zeros_like(h_new))
             outs.append(torch.stack(ys))
+            hn.append(h)
+            cn.append(c)
         inp = torch.cat(outs, dim=2)
-    return inp
+    return inp, torch.stack(hn), torch.stack(cn)
 
 
 def _weights(model):
@@ -95,7 +88,7 @@ def forward(model, packed_mix, hidden):
     """SepDNN.forward (archs/uPIT.py:129-147) -> mask (B, T_max, F*S)."""
     x, lens = pad_packed_sequence(packed_mix)                    # (T, B, F)
     T, B, _ = x.shape
-    y = blstm_padded(x, lens, _weights(model), hidden[0], hidden[1])           # (T, B, 2H), zeros past len
+    y, _, _ = blstm_padded(x, lens, _weights(model), hidden[0], hidden[1])     # (T, B, 2H), zeros past len
     y = model.bn(y.permute(1, 2, 0).contiguous()).permute(0, 2, 1)            # BatchNorm1d over (B, 2H, T)
     z = _Bf16Linear.apply(y.reshape(B * T, -1), model.lin.weight).view(B, T, -1) + model.lin.bias
     return torch.sigmoid(z)

@@ -32,6 +32,22 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// bf16 variant (mode bit 16; BASELINE configs[3]): W_hh and the exchanged operand (h_t forward, dG_t backward)
+// are rounded to bf16 on their way into v_mfma_f32_16x16x32_bf16, fp32 accumulate; cell state, gates and all
+// stored tensors stay fp32.  The exchange image is then the bf16 B-operand image [k/32][4 k-octets][16 rows][8]
+// (still 1 KB per chunk, now 32 k deep), the register slice of W halves, and a step's MFMA phase shrinks 16x.
+__device__ __forceinline__ bf16x8 pack8(const float4& a, const float4& b) {
+  bf16x8 v;
+  v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+  v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+  return v;
+}
+// element offset (bf16 units) of k, row b in the bf16 image
+__device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((((k >> 3) & 3) * 16 + b) << 3) + (k & 7); }
 
 constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 constexpr int NTHREADS = 512;
@@ -46,17 +62,17 @@ struct WsLayout {
   int KS, NBG;
 };
 
-inline int pick_ks(int H) {
+inline int pick_ks(int H, bool bf = false) {
   const int need = (H + 15) / 16;
-  const int opts[4] = {20, 38, 56, 64};
+  const int opts[4] = {20, bf ? 40 : 38, 56, 64};  // bf16: 32-k chunks split over 8 waves need KS % 4 == 0
   for (int i = 0; i < 4; ++i)
     if (opts[i] >= need) return opts[i];
   return 0;
 }
 
-inline WsLayout ws_layout(int B, int H) {
+inline WsLayout ws_layout(int B, int H, bool bf = false) {
   WsLayout w;
-  w.KS = pick_ks(H);
+  w.KS = pick_ks(H, bf);
   w.NBG = (B + 15) / 16;
   const size_t Hp = 16 * (size_t)w.KS;
   w.ctrl = 0;
@@ -165,9 +181,12 @@ __device__ __forceinline__ void wait_vmcnt() {
 // h_t is in flight to the other workgroups the next group computes.
 constexpr int GMAX = 8;
 
-template <int KS>
+template <int KS, bool BF>
 __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
-  constexpr int HP = 16 * KS, NQ = KS / 2;
+  constexpr int HP = 16 * KS;
+  constexpr int NCH = BF ? HP / 32 : KS;  // 1 KB chunks of the h image (16 k each in fp32, 32 k in bf16)
+  constexpr int NQ = NCH / 2;             // chunks per wave (one K half)
+  static_assert(NCH % 2 == 0, "image chunks must split into two K halves");
   __shared__ __attribute__((aligned(16))) float hs[16 * HP];  // B-operand image of h_{s-1}: [k/4][16 rows][4]
   __shared__ __attribute__((aligned(16))) float red[4][64][4];
   __shared__ float st_c[GMAX][256], st_h[GMAX][256];          // per-group cell state of the owner lanes
@@ -180,7 +199,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
 
   // ---- W_hh slice -> registers.  MFMA A operand: lane l supplies A[i = l&15][k = l>>4];
   //      row i = 4*unit_local + gate; k of (chunk q, r) = 16 (kh*NQ + q) + 4 (l>>4) + r.
-  float wreg[4 * NQ];
+  //      bf16: lane l supplies A[i = l&15][k = 32 chunk + 8 (l>>4) + 0..7] as 8 bf16.
+  float wreg[BF ? 1 : 4 * NQ];
+  bf16x8 wb[BF ? NQ : 1];
   {
     const int i = lane & 15, kq = lane >> 4;
     const int unit_i = ug * 16 + 4 * mt + (i >> 2), g_i = i & 3;
@@ -188,13 +209,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
     const float* wrow = a.whh + ((size_t)dir * 4 * H + (size_t)g_i * H + unit_i) * H;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int k = 16 * (kh * NQ + q) + 4 * kq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rowok && k < H) v = *reinterpret_cast<const float4*>(wrow + k);
-      wreg[4 * q + 0] = v.x;
-      wreg[4 * q + 1] = v.y;
-      wreg[4 * q + 2] = v.z;
-      wreg[4 * q + 3] = v.w;
+      if (BF) {
+        const int k = 32 * (kh * NQ + q) + 8 * kq;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (rowok && k < H) v0 = *reinterpret_cast<const float4*>(wrow + k);
+        if (rowok && k + 4 < H) v1 = *reinterpret_cast<const float4*>(wrow + k + 4);
+        wb[q] = pack8(v0, v1);
+      } else {
+        const int k = 16 * (kh * NQ + q) + 4 * kq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rowok && k < H) v = *reinterpret_cast<const float4*>(wrow + k);
+        wreg[4 * q + 0] = v.x;
+        wreg[4 * q + 1] = v.y;
+        wreg[4 * q + 2] = v.z;
+        wreg[4 * q + 3] = v.w;
+      }
     }
   }
 
@@ -203,7 +232,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
   const bool owner = kh == 0;  // this wave carries cells
   const int oi = mt * 64 + lane;
   const size_t xblk = (size_t)16 * HP;  // floats per (parity, dir, batch group) exchange block
-  const int xoff = ((ug * 4 + mt) * 16 + bl) * 4 + u_l;  // image position of (k = unit, row = bl)
+  const int xoff = ((ug * 4 + mt) * 16 + bl) * 4 + u_l;  // fp32 image position of (k = unit, row = bl)
+  const size_t hst = (size_t)2 * NBG * 16 * HP;           // second state array (bf16: exact h between step launches)
 
   if (owner) {
     for (int gi = 0; gi < G; ++gi) {
@@ -215,7 +245,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
           h = a.h0[((size_t)dir * B + b) * H + unit];
         } else {
           c = a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
-          h = __hip_atomic_load(a.xbuf + ((size_t)(((a.s_begin - 1) & 1) * 2 + dir) * NBG + bg) * xblk + xoff, SK_RLX, SK_AGENT);
+          if (BF)
+            h = a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
+          else
+            h = __hip_atomic_load(a.xbuf + ((size_t)(((a.s_begin - 1) & 1) * 2 + dir) * NBG + bg) * xblk + xoff, SK_RLX, SK_AGENT);
         }
       }
       st_c[gi][oi] = c;
@@ -258,16 +291,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
       SK_STAMP(0);
       // 3. h_{s-1} image (16 rows x HP) -> LDS
       if (s == 0) {
-        for (int i = tid; i < 16 * (HP / 4); i += NTHREADS) {
-          const int bb = i & 15, c = i >> 4;  // row, k/4
-          const int brow = bg * 16 + bb;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (brow < B && 4 * c < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)dir * B + brow) * H + 4 * c);
-          *reinterpret_cast<float4*>(&hs[(c * 16 + bb) * 4]) = v;
+        if (BF) {
+          for (int i = tid; i < 16 * (HP / 8); i += NTHREADS) {
+            const int bb = i & 15, c8 = i >> 4;  // row, k/8
+            const int brow = bg * 16 + bb, k = 8 * c8;
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            const float* hp0 = a.h0 + ((size_t)dir * B + brow) * H + k;
+            if (brow < B && k < H) v0 = *reinterpret_cast<const float4*>(hp0);
+            if (brow < B && k + 4 < H) v1 = *reinterpret_cast<const float4*>(hp0 + 4);
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(hs) + bf_img(k, bb)) = pack8(v0, v1);
+          }
+        } else {
+          for (int i = tid; i < 16 * (HP / 4); i += NTHREADS) {
+            const int bb = i & 15, c = i >> 4;  // row, k/4
+            const int brow = bg * 16 + bb;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (brow < B && 4 * c < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)dir * B + brow) * H + 4 * c);
+            *reinterpret_cast<float4*>(&hs[(c * 16 + bb) * 4]) = v;
+          }
         }
       } else {
         const float* src = ((s - 1) & 1) ? xb1 : xb0;
-        for (int p = w; p < KS; p += 8) dma_piece(src + p * 256, hs + p * 256, lane);
+        for (int p = w; p < NCH; p += 8) dma_piece(src + p * 256, hs + p * 256, lane);
         wait_vmcnt<0>();
       }
       __syncthreads();
@@ -278,11 +323,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
         const float* hp = &hs[(kh * NQ) * 256 + lane * 4];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          const float4 hb = *reinterpret_cast<const float4*>(hp + q * 256);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], hb.x, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], hb.y, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], hb.z, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], hb.w, acc1, 0, 0, 0);
+          if (BF) {
+            const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hp + q * 256);
+            if (q & 1)
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q], hb, acc1, 0, 0, 0);
+            else
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q], hb, acc0, 0, 0, 0);
+          } else {
+            const float4 hb = *reinterpret_cast<const float4*>(hp + q * 256);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], hb.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], hb.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], hb.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], hb.w, acc1, 0, 0, 0);
+          }
         }
       }
       f32x4 acc = acc0 + acc1;
@@ -310,7 +363,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
           st_h[gi][oi] = h_reg;
         }
         // 6. publish h_s first (write-through) ...
-        __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
+        if (BF) {
+          // the 4 units of this wave's tile for batch row bl sit in lanes bl, 16+bl, 32+bl, 48+bl: lane bl
+          // gathers them and stores 4 bf16 = 8 bytes at k = unit0 .. unit0+3 of the image
+          const float hv = cellok ? h_reg : 0.f;
+          const float h1 = __shfl(hv, bl + 16, 64), h2 = __shfl(hv, bl + 32, 64), h3 = __shfl(hv, bl + 48, 64);
+          if (lane < 16) {
+            bf16x4 pk;
+            pk[0] = (__bf16)hv; pk[1] = (__bf16)h1; pk[2] = (__bf16)h2; pk[3] = (__bf16)h3;
+            float* xdst = (s & 1) ? xb1 : xb0;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs,
+                                                  (unsigned)(bf_img(ug * 16 + 4 * mt, bl) * 2), 0, 16 /* sc1 */);
+          }
+        } else {
+          __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
+        }
         SK_STAMP(4);
         wait_vmcnt<0>();
         SK_STAMP(5);
@@ -349,6 +417,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
         if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = st_c[gi][oi];
       } else {
         a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_c[gi][oi];
+        if (BF) a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_h[gi][oi];
       }
     }
   }
@@ -359,66 +428,81 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
 // Transposed MFMA: D[m = out unit][n = batch] = sum_k' A[m][k'] B[k'][n]; wave w takes the k' chunks
 // [w*NQ, (w+1)*NQ) (an eighth of K = 4H), streamed through its own 2-deep ring of DMA sub-blocks;
 // the 8 partial tiles are summed through LDS.
-template <int KS>
+template <int KS, bool BF>
 struct BwdCfg {
-  static constexpr int NQ = KS / 2;                       // 1 KB chunks per wave
+  static constexpr int NQ = BF ? KS / 4 : KS / 2;         // 1 KB chunks per wave (16 k' each in fp32, 32 in bf16)
   static constexpr int NSB = 4;                           // sub-blocks per step
   static constexpr int SB = (NQ + NSB - 1) / NSB;         // chunks per sub-block (last may be short)
   static constexpr int cnt(int sb) { return (sb * SB >= NQ) ? 0 : ((sb + 1) * SB <= NQ ? SB : NQ - sb * SB); }
 };
 
-template <int KS, int SBI>
+template <int KS, bool BF, int SBI>
 __device__ __forceinline__ void bwd_issue(const float* xsrc, float* ring, int w, int lane) {
-  using C = BwdCfg<KS>;
+  using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
   float* dst = ring + (SBI & 1) * C::SB * 256;
 #pragma unroll
   for (int j = 0; j < n; ++j) dma_piece(xsrc + (size_t)(w * C::NQ + SBI * C::SB + j) * 256, dst + j * 256, lane);
 }
 
-template <int KS, int SBI>
-__device__ __forceinline__ void bwd_consume(const float (&wreg)[4 * (KS / 2)], const float* ring, int lane, f32x4& acc0,
+// Register slice of W_hh^T of one wave: fp32 4 floats per chunk, bf16 8 bf16 (4 VGPRs) per chunk.
+template <int KS, bool BF>
+struct BwdW {
+  float f[BF ? 1 : 4 * BwdCfg<KS, BF>::NQ];
+  bf16x8 b[BF ? BwdCfg<KS, BF>::NQ : 1];
+};
+
+template <int KS, bool BF, int SBI>
+__device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* ring, int lane, f32x4& acc0,
                                             f32x4& acc1) {
-  using C = BwdCfg<KS>;
+  using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
   const float* src = ring + (SBI & 1) * C::SB * 256 + lane * 4;
 #pragma unroll
   for (int j = 0; j < n; ++j) {
     const int q = SBI * C::SB + j;
-    const float4 db = *reinterpret_cast<const float4*>(src + j * 256);  // dG[b = lane&15][k' = 16 cc + 4 (lane>>4) + 0..3]
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 0], db.x, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 1], db.y, acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 2], db.z, acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[4 * q + 3], db.w, acc1, 0, 0, 0);
+    if (BF) {
+      const bf16x8 db = *reinterpret_cast<const bf16x8*>(src + j * 256);  // dG[b = lane&15][k' = 32 cc + 8 (lane>>4) + 0..7]
+      if (q & 1)
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.b[q], db, acc1, 0, 0, 0);
+      else
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.b[q], db, acc0, 0, 0, 0);
+    } else {
+      const float4 db = *reinterpret_cast<const float4*>(src + j * 256);  // dG[b = lane&15][k' = 16 cc + 4 (lane>>4) + 0..3]
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 0], db.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 1], db.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 2], db.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 3], db.w, acc1, 0, 0, 0);
+    }
   }
 }
 
 // Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
-template <int KS>
-__device__ __forceinline__ float bwd_matmul(const float (&wreg)[4 * (KS / 2)], const float* xsrc, float* ring,
+template <int KS, bool BF>
+__device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xsrc, float* ring,
                                             float (*red)[16][17], int w, int lane) {
-  using C = BwdCfg<KS>;
+  using C = BwdCfg<KS, BF>;
   static_assert(C::NSB == 4, "the sub-block schedule below is written for 4 sub-blocks");
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   // The counted waits below assume the DMAs are the YOUNGEST vector-memory operations of this wave:
   // nothing may be scheduled into this region (the cell loads of the step were issued before it).
   __builtin_amdgcn_sched_barrier(0);
-  bwd_issue<KS, 0>(xsrc, ring, w, lane);
-  bwd_issue<KS, 1>(xsrc, ring, w, lane);
+  bwd_issue<KS, BF, 0>(xsrc, ring, w, lane);
+  bwd_issue<KS, BF, 1>(xsrc, ring, w, lane);
   wait_vmcnt<C::cnt(1)>();  // sub-block 0 landed (the newer C::cnt(1) DMAs may still be in flight)
-  bwd_consume<KS, 0>(wreg, ring, lane, acc0, acc1);
+  bwd_consume<KS, BF, 0>(wreg, ring, lane, acc0, acc1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of ring buffer 0 returned before it is refilled
   __builtin_amdgcn_sched_barrier(0);
-  bwd_issue<KS, 2>(xsrc, ring, w, lane);
+  bwd_issue<KS, BF, 2>(xsrc, ring, w, lane);
   wait_vmcnt<C::cnt(2)>();  // sub-block 1 landed
-  bwd_consume<KS, 1>(wreg, ring, lane, acc0, acc1);
+  bwd_consume<KS, BF, 1>(wreg, ring, lane, acc0, acc1);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  bwd_issue<KS, 3>(xsrc, ring, w, lane);
+  bwd_issue<KS, BF, 3>(xsrc, ring, w, lane);
   wait_vmcnt<C::cnt(3)>();  // sub-block 2 landed
-  bwd_consume<KS, 2>(wreg, ring, lane, acc0, acc1);
+  bwd_consume<KS, BF, 2>(wreg, ring, lane, acc0, acc1);
   wait_vmcnt<0>();
-  bwd_consume<KS, 3>(wreg, ring, lane, acc0, acc1);
+  bwd_consume<KS, BF, 3>(wreg, ring, lane, acc0, acc1);
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll
@@ -432,9 +516,9 @@ __device__ __forceinline__ float bwd_matmul(const float (&wreg)[4 * (KS / 2)], c
   return v;
 }
 
-template <int KS>
+template <int KS, bool BF>
 __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
-  using C = BwdCfg<KS>;
+  using C = BwdCfg<KS, BF>;
   constexpr int HP = 16 * KS, NQ = C::NQ;
   __shared__ __attribute__((aligned(16))) float ring_all[8][2 * C::SB * 256];
   __shared__ float red[8][16][17];
@@ -447,17 +531,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   float* const ring = &ring_all[w][0];
 
   // ---- W_hh^T slice -> registers: A[m = out unit i][k'] = W_hh[gate r * H + unit_k][ug*16 + i]
-  float wreg[4 * NQ];
+  //      bf16: chunk cc holds k' = 32 cc + 8 (l>>4) + j, i.e. unit_k = 8 cc + 2 (l>>4) + (j>>2), gate j&3.
+  BwdW<KS, BF> wreg;
   {
     const int i = lane & 15, kq = lane >> 4;
     const int uout = ug * 16 + i;
     const float* wbase = a.whh + (size_t)dir * 4 * H * H + uout;
 #pragma unroll
     for (int s = 0; s < NQ; ++s) {
-      const int unit_k = 4 * (w * NQ + s) + kq;
-      const bool ok = uout < H && unit_k < H;
+      if (BF) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) wreg[4 * s + r] = ok ? wbase[((size_t)r * H + unit_k) * H] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+          const int unit_k = 8 * (w * NQ + s) + 2 * kq + (j >> 2);
+          const bool ok = uout < H && unit_k < H;
+          wreg.b[s][j] = (__bf16)(ok ? wbase[((size_t)(j & 3) * H + unit_k) * H] : 0.f);
+        }
+      } else {
+        const int unit_k = 4 * (w * NQ + s) + kq;
+        const bool ok = uout < H && unit_k < H;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wreg.f[4 * s + r] = ok ? wbase[((size_t)r * H + unit_k) * H] : 0.f;
+      }
     }
   }
 
@@ -466,7 +560,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   const bool owner = w < 4;
   const int oi = (w & 3) * 64 + lane;
   const size_t xblk = (size_t)HP * 64;  // floats per (parity, dir, batch group) exchange block
-  const size_t xoff = ((size_t)unit * 16 + bl) * 4;  // image position of k' = 4*unit + 0..3, row bl
+  // image position of k' = 4*unit + 0..3, row bl: fp32 floats / bf16 elements (chunk unit>>3, octet (unit&7)>>1)
+  const size_t xoff = BF ? (size_t)bf_img(4 * unit, bl) : ((size_t)unit * 16 + bl) * 4;
   const size_t st2 = (size_t)2 * NBG * 16 * HP;
 
   // carry = gradient wrt h that passes straight through a frozen (padded) step
@@ -532,7 +627,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
           break;
         }
         SK_STAMP(0);
-        dh_rec = bwd_matmul<KS>(wreg, ((s - 1) & 1) ? xb1 : xb0, ring, red, w, lane);
+        dh_rec = bwd_matmul<KS, BF>(wreg, ((s - 1) & 1) ? xb1 : xb0, ring, red, w, lane);
         SK_STAMP(2);
       }
       // 3. cell backward (owner waves)
@@ -560,7 +655,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
         float* xdst = (s & 1) ? xb1 : xb0;
         __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
         SK_STAMP(4);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
+        if (BF) {
+          bf16x4 pk;
+          pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, (unsigned)(xoff * 2), 0, 16 /* sc1 */);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
+        }
         wait_vmcnt<0>();
         SK_STAMP(5);
       }
@@ -595,7 +696,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       }
       __syncthreads();
       if (s_abort) return;
-      float dh_rec = bwd_matmul<KS>(wreg, ((T - 1) & 1) ? xb1 : xb0, ring, red, w, lane);
+      float dh_rec = bwd_matmul<KS, BF>(wreg, ((T - 1) & 1) ? xb1 : xb0, ring, red, w, lane);
       if (cellok) {
         dh_rec += st_carry[gi][oi];
         if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
@@ -631,31 +732,43 @@ __global__ __launch_bounds__(256) void hprev_kernel(const float* __restrict__ y,
   }
 }
 
-template <int KS>
+template <int KS, bool BF>
 int launch_fwd(const FwdArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_fwd_kernel<KS>, grid, dim3(NTHREADS), 0, st, a);
+  hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF>), grid, dim3(NTHREADS), 0, st, a);
   return 0;
 }
-template <int KS>
+template <int KS, bool BF>
 int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL(lstm_bwd_kernel<KS>, grid, dim3(NTHREADS), 0, st, a);
+  hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF>), grid, dim3(NTHREADS), 0, st, a);
   return 0;
 }
 
-int dispatch_fwd(int KS, const FwdArgs& a, dim3 grid, hipStream_t st) {
+int dispatch_fwd(int KS, bool bf, const FwdArgs& a, dim3 grid, hipStream_t st) {
+  if (bf) switch (KS) {
+      case 20: return launch_fwd<20, true>(a, grid, st);
+      case 40: return launch_fwd<40, true>(a, grid, st);
+      case 56: return launch_fwd<56, true>(a, grid, st);
+      default: return launch_fwd<64, true>(a, grid, st);
+    }
   switch (KS) {
-    case 20: return launch_fwd<20>(a, grid, st);
-    case 38: return launch_fwd<38>(a, grid, st);
-    case 56: return launch_fwd<56>(a, grid, st);
-    default: return launch_fwd<64>(a, grid, st);
+    case 20: return launch_fwd<20, false>(a, grid, st);
+    case 38: return launch_fwd<38, false>(a, grid, st);
+    case 56: return launch_fwd<56, false>(a, grid, st);
+    default: return launch_fwd<64, false>(a, grid, st);
   }
 }
-int dispatch_bwd(int KS, const BwdArgs& a, dim3 grid, hipStream_t st) {
+int dispatch_bwd(int KS, bool bf, const BwdArgs& a, dim3 grid, hipStream_t st) {
+  if (bf) switch (KS) {
+      case 20: return launch_bwd<20, true>(a, grid, st);
+      case 40: return launch_bwd<40, true>(a, grid, st);
+      case 56: return launch_bwd<56, true>(a, grid, st);
+      default: return launch_bwd<64, true>(a, grid, st);
+    }
   switch (KS) {
-    case 20: return launch_bwd<20>(a, grid, st);
-    case 38: return launch_bwd<38>(a, grid, st);
-    case 56: return launch_bwd<56>(a, grid, st);
-    default: return launch_bwd<64>(a, grid, st);
+    case 20: return launch_bwd<20, false>(a, grid, st);
+    case 38: return launch_bwd<38, false>(a, grid, st);
+    case 56: return launch_bwd<56, false>(a, grid, st);
+    default: return launch_bwd<64, false>(a, grid, st);
   }
 }
 
@@ -682,7 +795,8 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && (mode >> 8) <= GMAX, "%s: unknown mode %d", fn, mode);
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 17) == 0,
+               "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
 
@@ -691,7 +805,8 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
 extern "C" size_t sk_lstm_workspace_bytes(int T, int B, int H) {
   (void)T;
   if (B <= 0 || H <= 0 || pick_ks(H) == 0) return 0;
-  return ws_layout(B, H).total;
+  const size_t a = ws_layout(B, H, false).total, b = ws_layout(B, H, true).total;  // either precision
+  return a > b ? a : b;
 }
 
 extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
@@ -702,9 +817,10 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   SK_CHECK_ARG(((uintptr_t)h0 % 16) == 0, "sk_lstm_fwd: h0 must be 16-byte aligned");
   int rc = check_common("sk_lstm_fwd", T, B, H, whh, mode);
   if (rc) return rc;
-  const int gmin = mode >> 8;  // bits 8..: minimum batch groups per workgroup (frees CUs for concurrent kernels)
+  const int gmin = (mode >> 8) & 0xff;  // bits 8..15: minimum batch groups per workgroup (frees CUs for concurrent kernels)
+  const bool bf = (mode >> 16) & 1;     // bit 16: bf16 matrix-core inputs
   mode &= 0xff;
-  const WsLayout L = ws_layout(B, H);
+  const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
   FwdArgs a;
@@ -722,11 +838,11 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));  // status word + flags
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T;
-    dispatch_fwd(L.KS, a, grid, st);
+    dispatch_fwd(L.KS, bf, a, grid, st);
   } else {
     for (int s = 0; s < T; ++s) {
       a.s_begin = s; a.s_end = s + 1;
-      dispatch_fwd(L.KS, a, grid, st);
+      dispatch_fwd(L.KS, bf, a, grid, st);
     }
   }
   SK_CHECK_LAUNCH("sk_lstm_fwd");
@@ -745,9 +861,10 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
   if (rc) return rc;
-  const int gmin = mode >> 8;
+  const int gmin = (mode >> 8) & 0xff;
+  const bool bf = (mode >> 16) & 1;
   mode &= 0xff;
-  const WsLayout L = ws_layout(B, H);
+  const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
   BwdArgs a;
@@ -766,16 +883,16 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;
-    dispatch_bwd(L.KS, a, grid, st);
+    dispatch_bwd(L.KS, bf, a, grid, st);
   } else {
     a.final_mm = 0;  // a step launch never waits on other workgroups
     for (int s = 0; s < T; ++s) {
       a.s_begin = s; a.s_end = s + 1;
-      dispatch_bwd(L.KS, a, grid, st);
+      dispatch_bwd(L.KS, bf, a, grid, st);
     }
     if (want_d0) {
       a.s_begin = T; a.s_end = T; a.final_mm = 1;
-      dispatch_bwd(L.KS, a, grid, st);
+      dispatch_bwd(L.KS, bf, a, grid, st);
     }
   }
   SK_CHECK_LAUNCH("sk_lstm_bwd");

@@ -67,9 +67,9 @@ class Engine:
     def __init__(self, in_dim, out_dim, hidden, layers, device, precision="fp32"):
         if precision not in ("fp32", "bf16"):
             raise SepkernError("precision must be 'fp32' or 'bf16' (got %r)" % (precision,))
-        # bf16: the matrix products outside the time recurrence (input projections, Linear, their dgrad and
-        # wgrad: 72 % of the step's FLOPs) round their operands to bf16 on the way into the matrix cores and
-        # accumulate in fp32; parameters, activations, gradients, Adam and the recurrence stay fp32.
+        # bf16: EVERY matrix product (input projections, Linear, the recurrence h W_hh^T, their data and weight
+        # gradients) rounds both operands to bf16 on the way into the matrix cores and accumulates in fp32;
+        # parameters, activations, cell state, gradients, BatchNorm, the loss and Adam stay fp32.
         self.precision, self.bf16 = precision, precision == "bf16"
         if hidden % 4 != 0 or hidden > 1024:
             raise SepkernError("hidden_dim must be a multiple of 4 and <= 1024 (got %d)" % hidden)
@@ -137,7 +137,7 @@ class Engine:
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
             ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
                               hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
-                              T, B, H, self.lstm_mode)
+                              T, B, H, self.lstm_mode, bf16=self.bf16)
             saved.append((inp, gx, cs, y))
             inp, I = y, 2 * H
         self._check_status(ws)
@@ -216,7 +216,8 @@ class Engine:
             sl = slice(2 * l, 2 * l + 2)
             ws = ops.lstm_bwd(dy, whh, gates, cs, c0[sl], lens, dgx, dh0[sl] if want_dstate else None,
                               dc0[sl] if want_dstate else None, T, B, H, mode,
-                              dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None)
+                              dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None,
+                              bf16=self.bf16)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, I, device=dev)
                 ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy_next, R, I, 8 * H, 8 * H, I, I, bf16=self.bf16)

@@ -351,16 +351,19 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
-def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0):
+def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False):
+    """bf16=True: W_hh and h_{t-1} enter the matrix cores rounded to bf16 (fp32 accumulate, fp32 state)."""
     ws = lstm_ws(T, B, H)
+    mode = int(mode) | (0x10000 if bf16 else 0)
     with _timed("lstm_fwd_kernel", 2.0 * T * B * 2 * 4 * H * H):
         _lib.call("sk_lstm_fwd", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(y), _ptr(gates), _ptr(cs),
                   _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, _stream())
     return ws
 
 
-def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=None, dcn=None):
+def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=None, dcn=None, bf16=False):
     ws = lstm_ws(T, B, H)
+    mode = int(mode) | (0x10000 if bf16 else 0)
     with _timed("lstm_bwd_kernel", 2.0 * T * B * 2 * 4 * H * H):
         _lib.call("sk_lstm_bwd_state", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
                   _ptr(lens), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(ws), T, B, H, mode, _stream())

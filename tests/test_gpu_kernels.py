@@ -343,3 +343,56 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
         np.testing.assert_allclose((dgx[:, d].t() @ hp[:, d]).numpy(), w_hh_g.numpy(), rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(dgx[:, d].sum(0).numpy(), b_ih_g.numpy(), rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(b_hh_g.numpy(), b_ih_g.numpy())
+
+
+@pytest.mark.parametrize("mode", [2, 1])
+@pytest.mark.parametrize("T,B,H,I,lens", [
+    (5, 3, 8, 6, [5, 3, 1]),
+    (7, 20, 300, 33, [7] * 5 + [6] * 5 + [4] * 5 + [1] * 5),
+    (6, 32, 600, 40, [6] * 16 + [5] * 8 + [2] * 8),              # H=600: 40 unit groups in bf16 (38 in fp32)
+    (4, 32, 896, 24, [4] * 20 + [3] * 12),
+    (4, 40, 1024, 16, [4] * 17 + [3] * 20 + [1] * 3),
+])
+def test_lstm_layer_bf16_matches_bf16_oracle(ops, mode, T, B, H, I, lens):
+    """The recurrence with bf16 matrix-core inputs (mode bit 16; BASELINE configs[3]) against the CPU computation of
+    the same arithmetic (oracle/upit_bf16.py: W_hh, h_{t-1} and dG_t rounded to bf16 inside the products)."""
+    from oracle import upit_bf16 as OB
+    w, x, h0, c0 = _layer_case(T, B, H, I, lens, seed=T * 100 + H + 1)
+    wr = [[tuple(t.clone().requires_grad_(True) for t in w[0][d]) for d in range(2)]]
+    h0r, c0r = h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    y_ref, hn_ref, cn_ref = OB.blstm_padded(x, lens, wr, h0r, c0r)
+    gd = torch.Generator().manual_seed(2)
+    dy = torch.randn(T, B, 2 * H, generator=gd)
+    dhn, dcn = torch.randn(2, B, H, generator=gd), torch.randn(2, B, H, generator=gd)
+    ((y_ref * dy).sum() + (hn_ref * dhn).sum() + (cn_ref * dcn).sum()).backward()
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+    wih = torch.stack([w[0][d][0] for d in range(2)]).cuda()
+    whh = torch.stack([w[0][d][1] for d in range(2)]).cuda()
+    bsum = torch.stack([w[0][d][2] + w[0][d][3] for d in range(2)]).reshape(-1).cuda()
+    R = T * B
+    gx = torch.empty(T, B, 2, 4 * H).cuda()
+    ops.gemm(dev(x), wih, gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum, bf16=True)
+    y = torch.full((T, B, 2 * H), float("nan")).cuda()
+    cs = torch.empty(T, B, 2, H).cuda()
+    hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
+    ws = ops.lstm_fwd(gx, whh, dev(h0), dev(c0), lens_d, y, gx, cs, hn, cn, T, B, H, mode, bf16=True)
+    ops.lstm_status(ws)
+    # a rounding-order difference in fp32 can flip a bf16 rounding of one h (2^-9 relative on one term of H)
+    tol = dict(rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(hn.cpu().numpy(), hn_ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(cn.cpu().numpy(), cn_ref.detach().numpy(), **tol)
+    dh0, dc0 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
+    ws = ops.lstm_bwd(dev(dy), whh, gx, cs, dev(c0), lens_d, gx, dh0, dc0, T, B, H, mode, dhn=dev(dhn), dcn=dev(dcn),
+                      bf16=True)
+    ops.lstm_status(ws)
+
+    def close(a, ref, what):
+        err = float((a.double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
+        assert err < 3e-3, (what, err)
+    close(dh0.cpu(), h0r.grad, "dh0")
+    close(dc0.cpu(), c0r.grad, "dc0")
+    dgx = gx.cpu().view(R, 2, 4 * H)
+    assert torch.isfinite(dgx).all()
+    for d in range(2):
+        close(dgx[:, d].sum(0), wr[0][d][2].grad, "db dir %d" % d)     # column sums of dG = bias gradient
