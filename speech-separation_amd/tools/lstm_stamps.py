@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 from sepkern import ops  # noqa: E402
 
 T, B, H = 400, 32, 896
-NAMES_F = ["wait flags+barrier", "DMA h + barrier", "MFMA", "LDS reduce barrier", "cell + h store", "drain vmcnt(0)",
+NAMES_F = ["-", "hand-off wait (consumer waves: flags, DMA) + barrier", "MFMA", "LDS reduce barrier", "cell + h store", "drain vmcnt(0)",
            "barrier+flag+bulk stores", "gx prefetch issue"]
 NAMES_B = ["wait flags+barrier", "-", "matmul (DMA ring+MFMA+reduce)", "-", "cell backward", "dG store + drain",
            "barrier+flag+dgx stores", "saved-activation loads issue"]
@@ -21,6 +21,7 @@ def stamps(ws):
 
 
 def main():
+    bf = "--bf16" in sys.argv
     torch.manual_seed(0)
     gx = torch.randn(T, B, 2, 4 * H, device="cuda") * 0.5
     whh = torch.randn(2, 4 * H, H, device="cuda") / 30
@@ -29,11 +30,11 @@ def main():
     y, cs = torch.empty(T, B, 2 * H, device="cuda"), torch.empty(T, B, 2, H, device="cuda")
     for rep in range(2):
         g = gx.clone()
-        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, None, None, T, B, H, 1)
+        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, None, None, T, B, H, 1, bf16=bf)
         ops.lstm_status(ws)
         sf = stamps(ws)
         dy = torch.randn(T, B, 2 * H, device="cuda")
-        ws = ops.lstm_bwd(dy, whh, g, cs, c0, lens, g, None, None, T, B, H, 1)
+        ws = ops.lstm_bwd(dy, whh, g, cs, c0, lens, g, None, None, T, B, H, 1, bf16=bf)
         ops.lstm_status(ws)
         sb = stamps(ws)
     print("forward  (us per step, workgroup 0):")
