@@ -220,7 +220,8 @@ class Engine:
                               bf16=self.bf16)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, I, device=dev)
-                ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy_next, R, I, 8 * H, 8 * H, I, I, bf16=self.bf16)
+                ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy_next, R, I, 8 * H, 8 * H, I, I, splitk=0,
+                         ws_tag="gemm_dgrad", bf16=self.bf16)
                 if l == 0:
                     dx = dy_next.view(T, B, I)
             stream = self.side if (overlap and l > 0) else main
