@@ -467,7 +467,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
 template <int KS, bool BF>
 struct BwdCfg {
   static constexpr int NQ = BF ? KS / 4 : KS / 2;         // 1 KB chunks per wave (16 k' each in fp32, 32 in bf16)
-  static constexpr int NSB = 4;                           // sub-blocks per step
+  static constexpr int NSB = BF ? 4 : 8;                  // sub-blocks per step (ring = 2 sub-blocks per wave; fp32: 8 keeps
+                                                          // the workgroup at 91 KB of LDS, bf16 measured faster with 4)
   static constexpr int SB = (NQ + NSB - 1) / NSB;         // chunks per sub-block (last may be short)
   static constexpr int cnt(int sb) { return (sb * SB >= NQ) ? 0 : ((sb + 1) * SB <= NQ ? SB : NQ - sb * SB); }
 };
@@ -513,32 +514,37 @@ __device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* 
   }
 }
 
+// Sub-block I of the 2-deep ring: wait until it has landed (only the C::cnt(I+1) DMAs of the next sub-block may
+// still be in flight), multiply, and refill its buffer with sub-block I+2.
+template <int KS, bool BF, int I>
+__device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* xsrc, float* ring, int w, int lane,
+                                         f32x4& acc0, f32x4& acc1) {
+  using C = BwdCfg<KS, BF>;
+  if constexpr (I < C::NSB) {
+    wait_vmcnt<C::cnt(I + 1)>();
+    bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
+    if constexpr (I + 2 < C::NSB) {
+      if constexpr (C::cnt(I + 2) > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this ring buffer returned before it is refilled
+        __builtin_amdgcn_sched_barrier(0);
+        bwd_issue<KS, BF, I + 2>(xsrc, ring, w, lane);
+      }
+    }
+    bwd_ring<KS, BF, I + 1>(wreg, xsrc, ring, w, lane, acc0, acc1);
+  }
+}
+
 // Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
 template <int KS, bool BF>
 __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xsrc, float* ring,
                                             float (*red)[16][17], int w, int lane) {
-  using C = BwdCfg<KS, BF>;
-  static_assert(C::NSB == 4, "the sub-block schedule below is written for 4 sub-blocks");
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   // The counted waits below assume the DMAs are the YOUNGEST vector-memory operations of this wave:
   // nothing may be scheduled into this region (the cell loads of the step were issued before it).
   __builtin_amdgcn_sched_barrier(0);
   bwd_issue<KS, BF, 0>(xsrc, ring, w, lane);
   bwd_issue<KS, BF, 1>(xsrc, ring, w, lane);
-  wait_vmcnt<C::cnt(1)>();  // sub-block 0 landed (the newer C::cnt(1) DMAs may still be in flight)
-  bwd_consume<KS, BF, 0>(wreg, ring, lane, acc0, acc1);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of ring buffer 0 returned before it is refilled
-  __builtin_amdgcn_sched_barrier(0);
-  bwd_issue<KS, BF, 2>(xsrc, ring, w, lane);
-  wait_vmcnt<C::cnt(2)>();  // sub-block 1 landed
-  bwd_consume<KS, BF, 1>(wreg, ring, lane, acc0, acc1);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  bwd_issue<KS, BF, 3>(xsrc, ring, w, lane);
-  wait_vmcnt<C::cnt(3)>();  // sub-block 2 landed
-  bwd_consume<KS, BF, 2>(wreg, ring, lane, acc0, acc1);
-  wait_vmcnt<0>();
-  bwd_consume<KS, BF, 3>(wreg, ring, lane, acc0, acc1);
+  bwd_ring<KS, BF, 0>(wreg, xsrc, ring, w, lane, acc0, acc1);
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll

@@ -86,7 +86,8 @@ class Engine:
         # l-1's recurrence (shrunk to half the CUs by carrying 2 batch groups per workgroup) runs on the main
         # stream.  Measured on MI355X at 3x896, 32x400: 44.27 vs 44.85 ms/step (+1.3 %) -- the recurrence's
         # hand-off chain slows from 9.5 to 15.6 ms/step when GEMMs load the L2/fabric, eating the overlap.
-        self.overlap = os.environ.get("SEPKERN_OVERLAP", "0") == "1"
+        self.overlap_mode = int(os.environ.get("SEPKERN_OVERLAP", "0"))
+        self.overlap = self.overlap_mode in (1, 2)
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
         self._calls = 0
@@ -211,8 +212,10 @@ class Engine:
             I = I0 if l == 0 else 2 * H
             whh = self.p("weight_hh_l%d" % l)
             dgx = gates                                  # overwritten in place, cell by cell
-            # with weight-gradient GEMMs in flight on the side stream, carry 2 batch groups per workgroup
-            mode = self.lstm_mode | ((2 << 8) if (overlap and l < L - 1) else 0)
+            # with weight-gradient GEMMs in flight on the side stream: SEPKERN_OVERLAP=1 carries 2 batch groups per
+            # workgroup (the recurrence on half the CUs, GEMMs on the rest); =2 leaves the recurrence as it is and
+            # lets GEMM blocks co-reside on its CUs (it leaves 124 VGPRs per SIMD lane and 69 KB of LDS free)
+            mode = self.lstm_mode | ((2 << 8) if (overlap and self.overlap_mode == 1 and l < L - 1) else 0)
             sl = slice(2 * l, 2 * l + 2)
             ws = ops.lstm_bwd(dy, whh, gates, cs, c0[sl], lens, dgx, dh0[sl] if want_dstate else None,
                               dc0[sl] if want_dstate else None, T, B, H, mode,
