@@ -82,11 +82,14 @@ class Engine:
         self.running_var = torch.ones(2 * hidden, device=device)
         self.eps, self.momentum = 1e-5, 0.1
         self.lstm_mode = int(os.environ.get("SEPKERN_LSTM_MODE", "0"))
-        # Experiment (off by default): run the weight-gradient GEMMs of layer l on a side stream while layer
-        # l-1's recurrence (shrunk to half the CUs by carrying 2 batch groups per workgroup) runs on the main
-        # stream.  Measured on MI355X at 3x896, 32x400: 44.27 vs 44.85 ms/step (+1.3 %) -- the recurrence's
-        # hand-off chain slows from 9.5 to 15.6 ms/step when GEMMs load the L2/fabric, eating the overlap.
-        self.overlap_mode = int(os.environ.get("SEPKERN_OVERLAP", "0"))
+        # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one.
+        # SEPKERN_OVERLAP=2 (default): the recurrence keeps its one-workgroup-per-CU grid and the GEMM blocks
+        # become CO-RESIDENT on its CUs -- a persistent workgroup leaves >=124 VGPRs per SIMD lane and >=69 KB of
+        # LDS free, and the matrix pipe idle during its hand-offs -- : 42.9 -> 40.5 ms/step at 3x896, 32x400 (the
+        # co-scheduled GEMMs run at ~1/3 of their stand-alone rate, the recurrence 25 % slower, net +6 %).
+        # =1: recurrence on half the CUs (2 batch groups per workgroup), GEMMs on the rest: +1.3 % only, the
+        # hand-off chain slows from 9.5 to 15.6 ms/step under the GEMMs' L2/fabric load.  =0: no overlap.
+        self.overlap_mode = int(os.environ.get("SEPKERN_OVERLAP", "2"))
         self.overlap = self.overlap_mode in (1, 2)
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate

@@ -30,7 +30,9 @@ class _timed:
     def __exit__(self, *exc):
         if PROF is not None:
             self.e1.record()
-            PROF.setdefault(self.cls, []).append((self.e0, self.e1, self.flops))
+            # launches on a side stream are co-scheduled with other kernels: their durations are kept apart
+            side = torch.cuda.current_stream() != torch.cuda.default_stream()
+            PROF.setdefault(self.cls + ("@side" if side else ""), []).append((self.e0, self.e1, self.flops))
         return False
 
 
