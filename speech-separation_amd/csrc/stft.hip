@@ -197,36 +197,36 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
     // itself when j == 0).
     const int64_t fo = ooff + (int64_t)(t0 + fr) * st;
     const float z0x = z[0].x, z0y = z[0].y;
+    if (active) {  // uniform over the 16-lane group, which is all the shuffles below reach
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) {
-      float2 zc;
-      zc.x = __shfl(z[15 - k2].x, partner, 64);
-      zc.y = __shfl(z[15 - k2].y, partner, 64);
-      if (j == 0) zc = z[(16 - k2) & 15];
-      const float2 zk = z[k2];
-      const int k = j + 16 * k2;
-      const float2 xe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-      const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
-      const float2 xo = make_float2(0.5f * dd.y, -0.5f * dd.x);
-      const float2 t = cmul(tw[k], xo);
-      const float2 x = make_float2(xe.x + t.x, xe.y + t.y);
-      if (BINMAJOR) {
-        if (active) ost[fr][k] = x;
-      } else if (active) {
-        if (want_complex)
+      for (int k2 = 0; k2 < 16; ++k2) {
+        float2 zc;
+        zc.x = __shfl(z[15 - k2].x, partner, 64);
+        zc.y = __shfl(z[15 - k2].y, partner, 64);
+        if (j == 0) zc = z[(16 - k2) & 15];
+        const float2 zk = z[k2];
+        const int k = j + 16 * k2;
+        const float2 xe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
+        const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
+        const float2 xo = make_float2(0.5f * dd.y, -0.5f * dd.x);
+        const float2 t = cmul(tw[k], xo);
+        const float2 x = make_float2(xe.x + t.x, xe.y + t.y);
+        if (BINMAJOR)
+          ost[fr][k] = x;
+        else if (want_complex)
           ((float2*)out)[fo + k] = x;
         else
           ((float*)out)[fo + k] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
       }
-    }
-    if (j == 0 && active) {  // k = 256: Re Z[0] - Im Z[0]
-      const float2 x = make_float2(z0x - z0y, 0.f);
-      if (BINMAJOR)
-        ost[fr][256] = x;
-      else if (want_complex)
-        ((float2*)out)[fo + 256] = x;
-      else
-        ((float*)out)[fo + 256] = fabsf(x.x);
+      if (j == 0) {  // k = 256: Re Z[0] - Im Z[0]
+        const float2 x = make_float2(z0x - z0y, 0.f);
+        if (BINMAJOR)
+          ost[fr][256] = x;
+        else if (want_complex)
+          ((float2*)out)[fo + 256] = x;
+        else
+          ((float*)out)[fo + 256] = fabsf(x.x);
+      }
     }
     __syncthreads();  // every wave is done with smp (and ost is complete)
     if (BINMAJOR) {

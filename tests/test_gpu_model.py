@@ -275,3 +275,42 @@ def test_end_to_end_si_sdr_parity(arch):
         for s in range(S):
             d = np.abs(est_g[s] - est_o[s])
             assert d.max() <= 2.0                                    # int16 LSBs
+
+
+def test_coscheduled_backward_is_bitwise_the_serial_backward(arch):
+    """The engine issues the weight-gradient GEMMs of layer l on a side stream so that they run co-resident with
+    layer l-1's recurrence.  That is scheduling only: gradients must be bit-identical to the
+    serial order, run after run (a missing dependency would show up as a difference here)."""
+    H, L, S, B, T = 896, 3, 2, 32, 40
+    torch.manual_seed(11)
+    rng = np.random.default_rng(11)
+    model = arch.SepDNN(0, num_spk=str(S), hidden_dim=str(H), num_layers=str(L))
+    model.cuda()
+    model.train()
+    lens = sorted([int(v) for v in rng.integers(T // 2, T + 1, B)])
+    lens[-1] = T
+    samples = []
+    for n in lens:
+        d = {"mix": np.abs(rng.standard_normal((n, 257))).astype(np.float32)}
+        for s in range(S):
+            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((n, 257))).astype(np.float32) * 0.6
+        samples.append(d)
+    batch = arch.Collator("mix")(samples)
+    h0, c0 = torch.randn(2 * L, B, H).cuda(), torch.randn(2 * L, B, H).cuda()
+
+    def grads(overlap):
+        model._engine.overlap = overlap
+        model.next_hidden = (h0, c0)
+        loss, _ = arch.compute_loss(model, 0, batch)
+        loss.backward()
+        torch.cuda.synchronize()
+        return model._engine.grad.clone(), float(loss)
+
+    model.next_hidden = (h0, c0)
+    arch.compute_loss(model, 0, batch)[0].backward()          # builds the engine
+    assert model._engine.overlap, "co-scheduling is expected to be on by default"
+    g_ser, l_ser = grads(False)
+    for _ in range(3):
+        g_co, l_co = grads(True)
+        assert l_co == l_ser
+        assert torch.equal(g_co, g_ser)
