@@ -96,10 +96,10 @@ __device__ __forceinline__ void fft256_g16(float2 (&z)[16], float2* xch, const f
 // BINMAJOR == false: every utterance of the launch is written frame-major (stride_f == 1): lanes store their
 // bins straight from registers.  BINMAJOR == true: arbitrary strides (the reference's on-disk (257, T)
 // layout): results are staged in LDS and written with consecutive threads on consecutive frames.
-template <bool BINMAJOR>
+template <bool BINMAJOR, bool CPLX>
 __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav, int pcm16,
                                                    const int64_t* __restrict__ wav_offs,
-                                                   const int32_t* __restrict__ nsamp, int want_complex,
+                                                   const int32_t* __restrict__ nsamp,
                                                    void* __restrict__ out, const int64_t* __restrict__ out_offs,
                                                    const int64_t* __restrict__ stride_t,
                                                    const int64_t* __restrict__ stride_f) {
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
     // real-FFT split: X[k] = Xe + W^k Xo, Xe = (Z[k] + conj Z[256-k])/2, Xo = -i (Z[k] - conj Z[256-k])/2,
     // k = j + 16 k2.  Z[256-k] is register 15-k2 of lane (16-j)%16 of this group (register (16-k2)%16 of lane 0
     // itself when j == 0).
-    const int64_t fo = ooff + (int64_t)(t0 + fr) * st;
+    // frame-major output row of this group's frame; lane j writes bins j, j+16, ... at constant offsets
+    float* const orow = (float*)out + (CPLX ? 2 : 1) * (ooff + (int64_t)(t0 + fr) * st) + (CPLX ? 2 : 1) * j;
     const float z0x = z[0].x, z0y = z[0].y;
     if (active) {  // uniform over the 16-lane group, which is all the shuffles below reach
 #pragma unroll
@@ -213,19 +214,19 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
         const float2 x = make_float2(xe.x + t.x, xe.y + t.y);
         if (BINMAJOR)
           ost[fr][k] = x;
-        else if (want_complex)
-          ((float2*)out)[fo + k] = x;
+        else if (CPLX)
+          *reinterpret_cast<float2*>(orow + 32 * k2) = x;
         else
-          ((float*)out)[fo + k] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
+          orow[16 * k2] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
       }
       if (j == 0) {  // k = 256: Re Z[0] - Im Z[0]
         const float2 x = make_float2(z0x - z0y, 0.f);
         if (BINMAJOR)
           ost[fr][256] = x;
-        else if (want_complex)
-          ((float2*)out)[fo + 256] = x;
+        else if (CPLX)
+          *reinterpret_cast<float2*>(orow + 512) = x;
         else
-          ((float*)out)[fo + 256] = fabsf(x.x);
+          orow[256] = fabsf(x.x);
       }
     }
     __syncthreads();  // every wave is done with smp (and ost is complete)
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
         }
         const float2 x = ost[f2][k];
         const int64_t o = ooff + (int64_t)(t0 + f2) * st + (int64_t)k * sf;
-        if (want_complex)
+        if (CPLX)
           ((float2*)out)[o] = x;
         else
           ((float*)out)[o] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
@@ -395,12 +396,15 @@ extern "C" int sk_stft(const void* wav, int pcm16, const int64_t* wav_offs, cons
   SK_CHECK_ARG(wav && wav_offs && nsamp && out && out_offs && stride_t && stride_f, "sk_stft: null pointer");
   SK_CHECK_ARG(nutt > 0 && nutt <= 65535 && max_frames > 0, "sk_stft: bad nutt/max_frames");
   dim3 grid((unsigned)sk_cdiv(max_frames, FPB * TPB), (unsigned)nutt);
-  if (frame_major)
-    hipLaunchKernelGGL(stft_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, pcm16, wav_offs, nsamp,
-                       want_complex, out, out_offs, stride_t, stride_f);
-  else
-    hipLaunchKernelGGL(stft_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, pcm16, wav_offs, nsamp,
-                       want_complex, out, out_offs, stride_t, stride_f);
+#define SK_STFT_LAUNCH(BM, CX)                                                                                 \
+  hipLaunchKernelGGL((stft_kernel<BM, CX>), grid, dim3(256), 0, (hipStream_t)stream, wav, pcm16, wav_offs, nsamp, \
+                     out, out_offs, stride_t, stride_f)
+  if (frame_major) {
+    if (want_complex) SK_STFT_LAUNCH(false, true); else SK_STFT_LAUNCH(false, false);
+  } else {
+    if (want_complex) SK_STFT_LAUNCH(true, true); else SK_STFT_LAUNCH(true, false);
+  }
+#undef SK_STFT_LAUNCH
   SK_CHECK_LAUNCH("sk_stft");
   return SK_OK;
 }
