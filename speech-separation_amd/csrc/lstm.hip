@@ -470,6 +470,7 @@ struct BwdCfg {
   static constexpr int NSB = BF ? 4 : 8;                  // sub-blocks per step (ring = 2 sub-blocks per wave; fp32: 8 keeps
                                                           // the workgroup at 91 KB of LDS, bf16 measured faster with 4)
   static constexpr int SB = (NQ + NSB - 1) / NSB;         // chunks per sub-block (last may be short)
+  static constexpr int DEPTH = BF ? 2 : 3;                // sub-blocks in flight per wave (ring slots)
   static constexpr int cnt(int sb) { return (sb * SB >= NQ) ? 0 : ((sb + 1) * SB <= NQ ? SB : NQ - sb * SB); }
 };
 
@@ -477,7 +478,7 @@ template <int KS, bool BF, int SBI>
 __device__ __forceinline__ void bwd_issue(const float* xsrc, float* ring, int w, int lane) {
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
-  float* dst = ring + (SBI & 1) * C::SB * 256;
+  float* dst = ring + (SBI % C::DEPTH) * C::SB * 256;
 #pragma unroll
   for (int j = 0; j < n; ++j) dma_piece(xsrc + (size_t)(w * C::NQ + SBI * C::SB + j) * 256, dst + j * 256, lane);
 }
@@ -494,7 +495,7 @@ __device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* 
                                             f32x4& acc1) {
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
-  const float* src = ring + (SBI & 1) * C::SB * 256 + lane * 4;
+  const float* src = ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4;
 #pragma unroll
   for (int j = 0; j < n; ++j) {
     const int q = SBI * C::SB + j;
@@ -514,20 +515,21 @@ __device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* 
   }
 }
 
-// Sub-block I of the 2-deep ring: wait until it has landed (only the C::cnt(I+1) DMAs of the next sub-block may
-// still be in flight), multiply, and refill its buffer with sub-block I+2.
+// Sub-block I of the DEPTH-deep ring: wait until it has landed (only the DMAs of the next DEPTH-1 sub-blocks may
+// still be in flight), multiply, and refill its slot with sub-block I+DEPTH.
 template <int KS, bool BF, int I>
 __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* xsrc, float* ring, int w, int lane,
                                          f32x4& acc0, f32x4& acc1) {
   using C = BwdCfg<KS, BF>;
   if constexpr (I < C::NSB) {
-    wait_vmcnt<C::cnt(I + 1)>();
+    constexpr int younger = C::cnt(I + 1) + (C::DEPTH > 2 ? C::cnt(I + 2) : 0);
+    wait_vmcnt<younger>();
     bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
-    if constexpr (I + 2 < C::NSB) {
-      if constexpr (C::cnt(I + 2) > 0) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this ring buffer returned before it is refilled
+    if constexpr (I + C::DEPTH < C::NSB) {
+      if constexpr (C::cnt(I + C::DEPTH) > 0) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this ring slot returned before it is refilled
         __builtin_amdgcn_sched_barrier(0);
-        bwd_issue<KS, BF, I + 2>(xsrc, ring, w, lane);
+        bwd_issue<KS, BF, I + C::DEPTH>(xsrc, ring, w, lane);
       }
     }
     bwd_ring<KS, BF, I + 1>(wreg, xsrc, ring, w, lane, acc0, acc1);
@@ -544,6 +546,7 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
   __builtin_amdgcn_sched_barrier(0);
   bwd_issue<KS, BF, 0>(xsrc, ring, w, lane);
   bwd_issue<KS, BF, 1>(xsrc, ring, w, lane);
+  if constexpr (BwdCfg<KS, BF>::DEPTH > 2) bwd_issue<KS, BF, 2>(xsrc, ring, w, lane);
   bwd_ring<KS, BF, 0>(wreg, xsrc, ring, w, lane, acc0, acc1);
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
@@ -562,7 +565,7 @@ template <int KS, bool BF>
 __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   using C = BwdCfg<KS, BF>;
   constexpr int HP = 16 * KS, NQ = C::NQ;
-  __shared__ __attribute__((aligned(16))) float ring_all[8][2 * C::SB * 256];
+  __shared__ __attribute__((aligned(16))) float ring_all[8][C::DEPTH * C::SB * 256];
   __shared__ float red[8][16][17];
   __shared__ float st_carry[GMAX][256], st_dc[GMAX][256];  // per-group recurrent state of the owner lanes
   __shared__ int s_abort;
