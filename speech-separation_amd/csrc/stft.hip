@@ -25,9 +25,18 @@ constexpr int FPB = 16;       // frames per workgroup (STFT and iSTFT): 4 waves 
 constexpr int XLD = 17;       // padded row of the 16 x 16 transpose (conflict-free column reads)
 constexpr int TPB = 5;        // consecutive 16-frame tiles per STFT workgroup (next tile's samples are prefetched)
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// Complex numbers are 2-vectors so that additions, scalings and the two halves of a complex product map onto
+// the packed fp32 VALU ops (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32, swizzles and signs in their modifiers).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f cmul(v2f a, v2f b) {  // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+  const v2f bs = {-b.y, b.x};
+  return a.xx * b + a.yy * bs;
 }
+__device__ __forceinline__ v2f mul_mi(v2f a) { return (v2f){a.y, -a.x}; }  // a * (-i)
+__device__ __forceinline__ v2f conj(v2f a) { return (v2f){a.x, -a.y}; }
+__device__ __forceinline__ v2f ld2(const float2* p) { return *reinterpret_cast<const v2f*>(p); }
+__device__ __forceinline__ void st2(float2* p, v2f v) { *reinterpret_cast<v2f*>(p) = v; }
 
 // A wave's LDS instructions execute in order, so data exchanged between the lanes of ONE wave needs no
 // hardware barrier -- only a compiler fence so that the ds_writes stay ahead of the ds_reads that follow.
@@ -38,32 +47,30 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 // radix-4 DFT of (a, b, c, d) (forward, e^{-i...})
-__device__ __forceinline__ void radix4(float2& a, float2& b, float2& c, float2& d) {
-  const float2 s0 = make_float2(a.x + c.x, a.y + c.y), s1 = make_float2(a.x - c.x, a.y - c.y);
-  const float2 s2 = make_float2(b.x + d.x, b.y + d.y), df = make_float2(b.x - d.x, b.y - d.y);
-  const float2 s3 = make_float2(df.y, -df.x);  // df * (-i)
-  a = make_float2(s0.x + s2.x, s0.y + s2.y);
-  b = make_float2(s1.x + s3.x, s1.y + s3.y);
-  c = make_float2(s0.x - s2.x, s0.y - s2.y);
-  d = make_float2(s1.x - s3.x, s1.y - s3.y);
+__device__ __forceinline__ void radix4(v2f& a, v2f& b, v2f& c, v2f& d) {
+  const v2f s0 = a + c, s1 = a - c, s2 = b + d, s3 = mul_mi(b - d);
+  a = s0 + s2;
+  b = s1 + s3;
+  c = s0 - s2;
+  d = s1 - s3;
 }
 
 // In-register 16-point DFT, natural order in and out (16 = 4 x 4).
-__device__ __forceinline__ void dft16(float2 (&x)[16]) {
+__device__ __forceinline__ void dft16(v2f (&x)[16]) {
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
   // step A: for n2 = 0..3 a radix-4 over n1 of x[4 n1 + n2]  ->  t[k1][n2] kept in x[4 k1 + n2]
 #pragma unroll
   for (int n2 = 0; n2 < 4; ++n2) radix4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);
   // twiddles W16^(n2 k1): (1,1)=W1 (1,2)=W2 (1,3)=W3 (2,1)=W2 (2,2)=W4 (2,3)=W6 (3,1)=W3 (3,2)=W6 (3,3)=W9
-  x[4 + 1] = cmul(x[4 + 1], make_float2(C1, -S1));
-  x[4 + 2] = cmul(x[4 + 2], make_float2(R2, -R2));
-  x[4 + 3] = cmul(x[4 + 3], make_float2(S1, -C1));
-  x[8 + 1] = cmul(x[8 + 1], make_float2(R2, -R2));
-  x[8 + 2] = make_float2(x[8 + 2].y, -x[8 + 2].x);  // * (-i)
-  x[8 + 3] = cmul(x[8 + 3], make_float2(-R2, -R2));
-  x[12 + 1] = cmul(x[12 + 1], make_float2(S1, -C1));
-  x[12 + 2] = cmul(x[12 + 2], make_float2(-R2, -R2));
-  x[12 + 3] = cmul(x[12 + 3], make_float2(-C1, S1));
+  x[4 + 1] = cmul(x[4 + 1], (v2f){C1, -S1});
+  x[4 + 2] = cmul(x[4 + 2], (v2f){R2, -R2});
+  x[4 + 3] = cmul(x[4 + 3], (v2f){S1, -C1});
+  x[8 + 1] = cmul(x[8 + 1], (v2f){R2, -R2});
+  x[8 + 2] = mul_mi(x[8 + 2]);
+  x[8 + 3] = cmul(x[8 + 3], (v2f){-R2, -R2});
+  x[12 + 1] = cmul(x[12 + 1], (v2f){S1, -C1});
+  x[12 + 2] = cmul(x[12 + 2], (v2f){-R2, -R2});
+  x[12 + 3] = cmul(x[12 + 3], (v2f){-C1, S1});
   // step B: for k1 = 0..3 a radix-4 over n2  ->  X[k1 + 4 k2] left in x[4 k1 + k2]
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) radix4(x[4 * k1 + 0], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
@@ -72,7 +79,7 @@ __device__ __forceinline__ void dft16(float2 (&x)[16]) {
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = a + 1; b < 4; ++b) {
-      const float2 tmp = x[4 * a + b];
+      const v2f tmp = x[4 * a + b];
       x[4 * a + b] = x[4 * b + a];
       x[4 * b + a] = tmp;
     }
@@ -80,15 +87,24 @@ __device__ __forceinline__ void dft16(float2 (&x)[16]) {
 
 // 256-point forward FFT by the 16 lanes of one group (j = lane & 15).  On entry z[n1] = in[16 n1 + j];
 // on exit z[k2] = Z[j + 16 k2].  xch: this GROUP's 16 x XLD float2 transpose area in LDS; tw = e^{-2 pi i m/512}.
-__device__ __forceinline__ void fft256_g16(float2 (&z)[16], float2* xch, const float2* tw, int j) {
+// The transpose goes through a 16 x XLD FLOAT plane, real parts first, then imaginary parts: half the LDS of a
+// complex plane (the STFT workgroup then fits four times per CU instead of three) for twice the LDS instructions.
+__device__ __forceinline__ void fft256_g16(v2f (&z)[16], float* xch, const float2* tw, int j) {
   dft16(z);  // over n1: z[k1] = A[k1][n2 = j]
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], tw[(2 * j * k1) & 511]);  // W256^(j k1)
+  for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], ld2(&tw[(2 * j * k1) & 511]));  // W256^(j k1)
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) xch[k1 * XLD + j] = z[k1];
+  for (int k1 = 0; k1 < 16; ++k1) xch[k1 * XLD + j] = z[k1].x;
+  wave_sync();
+  float re[16];
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) re[n2] = xch[j * XLD + n2];  // lane j now plays k1 = j
   wave_sync();
 #pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) z[n2] = xch[j * XLD + n2];  // lane j now plays k1 = j
+  for (int k1 = 0; k1 < 16; ++k1) xch[k1 * XLD + j] = z[k1].y;
+  wave_sync();
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) z[n2] = (v2f){re[n2], xch[j * XLD + n2]};
   wave_sync();
   dft16(z);  // over n2: z[k2] = Z[j + 16 k2]
 }
@@ -97,7 +113,7 @@ __device__ __forceinline__ void fft256_g16(float2 (&z)[16], float2* xch, const f
 // bins straight from registers.  BINMAJOR == true: arbitrary strides (the reference's on-disk (257, T)
 // layout): results are staged in LDS and written with consecutive threads on consecutive frames.
 template <bool BINMAJOR, bool CPLX>
-__global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav, int pcm16,
+__global__ __launch_bounds__(256, BINMAJOR ? 2 : 4) void stft_kernel(const void* __restrict__ wav, int pcm16,
                                                    const int64_t* __restrict__ wav_offs,
                                                    const int32_t* __restrict__ nsamp,
                                                    void* __restrict__ out, const int64_t* __restrict__ out_offs,
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
   __shared__ __attribute__((aligned(16))) float smp[NFFT + (FPB - 1) * HOP];
   __shared__ __attribute__((aligned(16))) float win[NFFT];
   __shared__ float2 tw[NFFT];
-  __shared__ float2 xch[16][16 * XLD];  // one transpose area per 16-lane group
+  __shared__ float xch[16][16 * XLD];  // one transpose plane per 16-lane group
   __shared__ float2 ost[BINMAJOR ? FPB : 1][BINMAJOR ? NBIN : 1];
 
   const int u = blockIdx.y;
@@ -183,12 +199,12 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
     const bool more = ti + 1 < TPB && t0 + FPB < T;
     if (more) fetch(t0 + FPB, pre);  // next tile's samples travel while this tile is transformed
     const bool active = fr < nfr;
-    float2 z[16];
+    v2f z[16];
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {  // packed point n = 16 n1 + j  <->  samples 2n, 2n+1
-      const float2 sm = *reinterpret_cast<const float2*>(&smp[fr * HOP + 32 * n1 + 2 * j]);
-      const float2 w = *reinterpret_cast<const float2*>(&win[32 * n1 + 2 * j]);
-      z[n1] = make_float2(sm.x * w.x, sm.y * w.y);
+      const v2f sm = *reinterpret_cast<const v2f*>(&smp[fr * HOP + 32 * n1 + 2 * j]);
+      const v2f w = *reinterpret_cast<const v2f*>(&win[32 * n1 + 2 * j]);
+      z[n1] = sm * w;
     }
     fft256_g16(z, xch[4 * wave + g], tw, j);
 
@@ -201,30 +217,27 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
     if (active) {  // uniform over the 16-lane group, which is all the shuffles below reach
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) {
-        float2 zc;
+        v2f zc;
         zc.x = __shfl(z[15 - k2].x, partner, 64);
         zc.y = __shfl(z[15 - k2].y, partner, 64);
         if (j == 0) zc = z[(16 - k2) & 15];
-        const float2 zk = z[k2];
+        const v2f zk = z[k2], cz = conj(zc);
         const int k = j + 16 * k2;
-        const float2 xe = make_float2(0.5f * (zk.x + zc.x), 0.5f * (zk.y - zc.y));
-        const float2 dd = make_float2(zk.x - zc.x, zk.y + zc.y);
-        const float2 xo = make_float2(0.5f * dd.y, -0.5f * dd.x);
-        const float2 t = cmul(tw[k], xo);
-        const float2 x = make_float2(xe.x + t.x, xe.y + t.y);
+        // X = (Zk + conj Zc)/2 + W^k (-i)(Zk - conj Zc)/2
+        const v2f x = 0.5f * (zk + cz) + cmul(ld2(&tw[k]), 0.5f * mul_mi(zk - cz));
         if (BINMAJOR)
-          ost[fr][k] = x;
+          st2(&ost[fr][k], x);
         else if (CPLX)
-          *reinterpret_cast<float2*>(orow + 32 * k2) = x;
+          *reinterpret_cast<v2f*>(orow + 32 * k2) = x;
         else
           orow[16 * k2] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
       }
       if (j == 0) {  // k = 256: Re Z[0] - Im Z[0]
-        const float2 x = make_float2(z0x - z0y, 0.f);
+        const v2f x = {z0x - z0y, 0.f};
         if (BINMAJOR)
-          ost[fr][256] = x;
+          st2(&ost[fr][256], x);
         else if (CPLX)
-          *reinterpret_cast<float2*>(orow + 512) = x;
+          *reinterpret_cast<v2f*>(orow + 512) = x;
         else
           orow[256] = fabsf(x.x);
       }
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(256) void stft_kernel(const void* __restrict__ wav,
 }
 
 constexpr int RING = FPB + 3;  // row slots of the iSTFT ring: one tile of frames + the 3 frames before it
-constexpr int RLD = 16 * XLD;  // float2 per slot: holds a 257-bin spectrum, the FFT's transpose area, 512 samples
+constexpr int RLD = NBIN + 1;  // float2 per slot: a 257-bin spectrum, then the FFT's 16 x 17 float transpose plane, then 512 samples
 
 // Masked spectra of frames [tfirst, tfirst + COUNT) into their ring slots (zeros outside [0, T)).
 template <int COUNT>
@@ -289,33 +302,30 @@ __device__ __forceinline__ void istft_load(float2 (*rows)[RLD], int tfirst, int 
 
 // Inverse real FFT of frame t by one 16-lane group; the windowed 512 samples replace the spectrum in the slot.
 __device__ __forceinline__ void istft_frame(float2* row, const float2* tw, const float* win, int j) {
-  float2 z[16];
+  v2f z[16];
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) {
     const int k = 16 * n1 + j;
-    float2 a = row[k];
-    float2 b = row[256 - k];
+    v2f a = ld2(&row[k]);
+    v2f b = ld2(&row[256 - k]);
     if (k == 0) {  // irfft ignores Im X[0] and Im X[256]
       a.y = 0.f;
       b.y = 0.f;
     }
-    b.y = -b.y;  // conj(X[256-k])
-    const float2 xe = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-    const float2 hd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-    const float2 wk = make_float2(tw[k].x, -tw[k].y);  // conj(W^k)
-    const float2 xo = cmul(hd, wk);
+    b = conj(b);  // conj(X[256-k])
+    const v2f xe = 0.5f * (a + b), hd = 0.5f * (a - b);
+    const v2f xo = cmul(hd, conj(ld2(&tw[k])));  // * conj(W^k)
     // Z = Xe + i Xo ; feed conj(Z) to the forward FFT
-    z[n1] = make_float2(xe.x - xo.y, -(xe.y + xo.x));
+    z[n1] = (v2f){xe.x - xo.y, -(xe.y + xo.x)};
   }
   wave_sync();  // the spectrum is in registers: the slot now serves as the transpose area, then as the output
-  fft256_g16(z, row, tw, j);
+  fft256_g16(z, reinterpret_cast<float*>(row), tw, j);
   float* tf = reinterpret_cast<float*>(row);
 #pragma unroll
   for (int k2 = 0; k2 < 16; ++k2) {  // z[k2] = Y[n], n = j + 16 k2; x[2n] = Re Y / 256, x[2n+1] = -Im Y / 256
     const int n = j + 16 * k2;
-    const float2 w = *reinterpret_cast<const float2*>(&win[2 * n]);
-    *reinterpret_cast<float2*>(&tf[2 * n]) =
-        make_float2(w.x * (z[k2].x * (1.0f / 256.0f)), w.y * (-z[k2].y * (1.0f / 256.0f)));
+    const v2f w = *reinterpret_cast<const v2f*>(&win[2 * n]);
+    *reinterpret_cast<v2f*>(&tf[2 * n]) = w * (z[k2] * (v2f){1.0f / 256.0f, -1.0f / 256.0f});
   }
 }
 
@@ -326,6 +336,8 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(
     const int64_t* __restrict__ mix_sf, const float* __restrict__ mask, const int64_t* __restrict__ mask_offs,
     const int64_t* __restrict__ mask_st, const int64_t* __restrict__ mask_sf, const int32_t* __restrict__ nframes,
     int S, float* __restrict__ wav_out, int16_t* __restrict__ pcm_out, const int64_t* __restrict__ out_offs, int tpb) {
+  // 45 KB: three workgroups per CU.  (Reading the 6 KB of tables through the vector L1 instead would fit four, but
+  // the 64-bit gather addresses push the kernel over 128 VGPRs into scratch: measured 2.7 -> 4.9 ms.)
   __shared__ __attribute__((aligned(16))) float2 rows[RING][RLD];
   __shared__ __attribute__((aligned(16))) float win[NFFT];
   __shared__ float2 tw[NFFT];
