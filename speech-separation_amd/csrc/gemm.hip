@@ -44,7 +44,9 @@ struct GemmArgs {
 //  slow : every element loaded from a CLAMPED in-range address and zeroed by a select
 //  KMAJOR == false: operand stored [tile dim (M or N)][K]  (transposed into k-major LDS by stash)
 //  KMAJOR == true : operand stored [K][tile dim]            (already k-major)
-template <bool KMAJOR>
+//  VEC == false (operands whose rows are not 16-byte aligned, e.g. the F = 257-edged ones): the fast form is
+//  four unconditional dword loads instead of one float4
+template <bool KMAJOR, bool VEC = true>
 __device__ __forceinline__ void fetch(const float* __restrict__ P, int ld, int dim0, int dimLimit, int k0, int K,
                                       bool fast, int tid, float4 (&r)[PIECES]) {
 #pragma unroll
@@ -63,7 +65,11 @@ __device__ __forceinline__ void fetch(const float* __restrict__ P, int ld, int d
       colLimit = K;
     }
     if (fast) {
-      r[i] = *reinterpret_cast<const float4*>(P + (int64_t)row * ld + col);
+      const float* q = P + (int64_t)row * ld + col;
+      if (VEC)
+        r[i] = *reinterpret_cast<const float4*>(q);
+      else
+        r[i] = make_float4(q[0], q[1], q[2], q[3]);
     } else {
       const bool rok = row < rowLimit;
       const float* q = P + (int64_t)min(row, rowLimit - 1) * ld;
@@ -96,7 +102,8 @@ __device__ __forceinline__ void stash(float (*S)[LD], int tid, const float4 (&r)
   }
 }
 
-template <bool TA, bool TB>
+// VEC == false: the variant for operands with unaligned rows (both operands then use dword loads).
+template <bool TA, bool TB, bool VEC = true>
 __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
   constexpr int LDA = TA ? LD_K : LD_T, LDB = TB ? LD_T : LD_K;
   __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
     m0 = (first + rem2 % gsz) * BM;
     n0 = (rem2 / gsz) * BN;
   }
-  const bool fullA = g.vecA && (m0 + BM <= g.M), fullB = g.vecB && (n0 + BN <= g.N);
+  const bool fullA = (g.vecA || !VEC) && (m0 + BM <= g.M), fullB = (g.vecB || !VEC) && (n0 + BN <= g.N);
   const int z = blockIdx.z, ks = blockIdx.y;
   const float* A = g.A + z * g.sA;
   const float* B = g.B + z * g.sB;
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
   const int nk = (kend - kbeg + BK - 1) / BK;
   float4 ra[PIECES], rb[PIECES];
   // A is k-major in memory when TA (stored K x M); B is k-major when !TB (stored K x N)
-  fetch<TA>(A, g.lda, m0, g.M, kbeg, kend, fullA && kbeg + BK <= kend, tid, ra);
-  fetch<!TB>(B, g.ldb, n0, g.N, kbeg, kend, fullB && kbeg + BK <= kend, tid, rb);
+  fetch<TA, VEC>(A, g.lda, m0, g.M, kbeg, kend, fullA && kbeg + BK <= kend, tid, ra);
+  fetch<!TB, VEC>(B, g.ldb, n0, g.N, kbeg, kend, fullB && kbeg + BK <= kend, tid, rb);
   stash<TA, LDA>(As[0], tid, ra);
   stash<!TB, LDB>(Bs[0], tid, rb);
   __syncthreads();
@@ -156,8 +163,8 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
     if (more) {
       const int k0 = kbeg + (kt + 1) * BK;
       const bool kfull = k0 + BK <= kend;  // block-uniform
-      fetch<TA>(A, g.lda, m0, g.M, k0, kend, fullA && kfull, tid, ra);
-      fetch<!TB>(B, g.ldb, n0, g.N, k0, kend, fullB && kfull, tid, rb);
+      fetch<TA, VEC>(A, g.lda, m0, g.M, k0, kend, fullA && kfull, tid, ra);
+      fetch<!TB, VEC>(B, g.ldb, n0, g.N, k0, kend, fullB && kfull, tid, rb);
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
@@ -483,7 +490,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, g);
     else
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, g);
-  } else {
+  } else if (g.vecA && g.vecB) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
     else if (!transA && transB)
@@ -492,6 +499,15 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
     else
       hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
+  } else {  // an operand with unaligned rows (F = 257): dword-load variant
+    if (!transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_kernel<false, false, false>), grid, dim3(256), 0, st, g);
+    else if (!transA && transB)
+      hipLaunchKernelGGL((gemm_f32_kernel<false, true, false>), grid, dim3(256), 0, st, g);
+    else if (transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_kernel<true, false, false>), grid, dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), grid, dim3(256), 0, st, g);
   }
   SK_CHECK_LAUNCH("sk_gemm");
   if (splitk > 1) {
