@@ -78,7 +78,7 @@ def device_info():
 
 
 # ----------------------------------------------------------------------------- GEMM
-_SLOTS = None
+_NUM_CUS = None
 
 
 def pick_splitk(M, N, K, batch=1):
@@ -86,10 +86,10 @@ def pick_splitk(M, N, K, batch=1):
     the matrix pipe of a CU is saturated by its resident 128x128 blocks, so time goes with the LARGEST number
     of blocks any CU gets, ceil(blocks / CUs); choose the slice count that minimises that quantisation loss
     plus the cost of writing and re-reading the partial slabs (measured: 1400 tiles on 256 CUs run at 91 %)."""
-    global _SLOTS
-    if _SLOTS is None:
-        _SLOTS = device_info()[0]
-    cus = _SLOTS
+    global _NUM_CUS
+    if _NUM_CUS is None:
+        _NUM_CUS = device_info()[0]
+    cus = _NUM_CUS
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
     if tiles >= 16 * cus or K < 2048:
         return 1
