@@ -149,6 +149,14 @@ int sk_bn_apply(const float* x, const float* mean, const float* var, const float
 /* training-mode backward: dgamma, dbeta, dx from dout, x and the batch statistics */
 int sk_bn_bwd(const float* dout, const float* x, const float* mean, const float* var, const float* gamma,
               float* dx, float* dgamma, float* dbeta, void* ws, int R, int C, float eps, sk_stream_t stream);
+/* The same in two halves, for BatchNorm statistics shared by several devices (data-parallel "sync" option): local
+ * column sums dbeta = sum dy, dgamma = sum dy*xhat, then -- after the caller has summed them over the devices --
+ * dx from the global sums; `count` = rows that mean / var and the sums cover (all devices). */
+int sk_bn_bwd_sums(const float* dout, const float* x, const float* mean, const float* var, float* dgamma,
+                   float* dbeta, void* ws, int R, int C, float eps, sk_stream_t stream);
+int sk_bn_bwd_apply(const float* dout, const float* x, const float* mean, const float* var, const float* gamma,
+                    const float* dgamma, const float* dbeta, float* dx, int R, int C, double count, float eps,
+                    sk_stream_t stream);
 
 /* out[c] (+)= sum_r x[r*ld + c]   (bias gradients); ws >= sk_bn_workspace_bytes(R,C) */
 int sk_colsum(const float* x, int R, int C, int ld, float* out, int accumulate, void* ws, sk_stream_t stream);

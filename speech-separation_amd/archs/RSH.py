@@ -187,7 +187,7 @@ class SepDNN(SepDNNBase):
     for key in kwargs.keys():
       print('modelparam:', key, kwargs[key])
     self._build(gpuid, self.feat_dim * 2, self.feat_dim, int(kwargs.get('hidden_dim', 600)),
-                int(kwargs.get('num_layers', 2)), str(kwargs.get('dtype', 'fp32')))
+                int(kwargs.get('num_layers', 2)), str(kwargs.get('dtype', 'fp32')), kwargs.get('sync_bn', '0'))
 
   def forward_padded(self, x, lens):
     """x (T,B,2F) -> mask (T,B,F); self.hidden is replaced by the LSTM's final state (archs/RSH.py:172)."""

@@ -214,7 +214,7 @@ class SepDNN(SepDNNBase):
       print('modelparam:', key, kwargs[key])
     # the reference hard-codes 2 x 600 (archs/uPIT.py:115-119); hidden_dim / num_layers widen it
     self._build(gpuid, self.feat_dim, self.feat_dim * self.num_spk, int(kwargs.get('hidden_dim', 600)),
-                int(kwargs.get('num_layers', 2)), str(kwargs.get('dtype', 'fp32')))
+                int(kwargs.get('num_layers', 2)), str(kwargs.get('dtype', 'fp32')), kwargs.get('sync_bn', '0'))
 
   def forward_padded(self, x, lens):
     """x (T,B,F) time-major zero-padded CUDA tensor, lens int32 CUDA (B) -> mask (T,B,F*S)."""

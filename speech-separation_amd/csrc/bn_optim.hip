@@ -84,14 +84,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
-// dx = gamma * rstd / R * (R*dy - dbeta - xhat * dgamma)
+// dx = gamma * rstd / N * (N*dy - dbeta - xhat * dgamma), N = rows the sums dbeta / dgamma (and mean / var) cover
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ var,
                                                            const float* __restrict__ gamma,
                                                            const float* __restrict__ dgamma,
                                                            const float* __restrict__ dbeta, float* __restrict__ dx,
-                                                           int64_t total, int R, int C, float eps) {
-  const float invR = 1.0f / (float)R;
+                                                           int64_t total, float count, int C, float eps) {
+  const float invR = 1.0f / count;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c = (int)(i % C);
     const float rs = 1.0f / sqrtf(var[c] + eps);
@@ -210,11 +210,9 @@ extern "C" int sk_bn_apply(const float* x, const float* mean, const float* var, 
   return SK_OK;
 }
 
-extern "C" int sk_bn_bwd(const float* dout, const float* x, const float* mean, const float* var, const float* gamma,
-                         float* dx, float* dgamma, float* dbeta, void* ws, int R, int C, float eps,
-                         sk_stream_t stream) {
-  SK_CHECK_ARG(dout && x && mean && var && gamma && dx && dgamma && dbeta && ws && R > 1 && C > 0,
-               "sk_bn_bwd: bad arguments");
+extern "C" int sk_bn_bwd_sums(const float* dout, const float* x, const float* mean, const float* var, float* dgamma,
+                              float* dbeta, void* ws, int R, int C, float eps, sk_stream_t stream) {
+  SK_CHECK_ARG(dout && x && mean && var && dgamma && dbeta && ws && R > 0 && C > 0, "sk_bn_bwd_sums: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int nch = (int)sk_cdiv(R, RCH);
   float* p0 = (float*)ws;
@@ -223,11 +221,29 @@ extern "C" int sk_bn_bwd(const float* dout, const float* x, const float* mean, c
   if (rc) return rc;
   hipLaunchKernelGGL(colfin_kernel, dim3((unsigned)sk_cdiv(C, 256)), dim3(256), 0, st, p0, nch, C, 1.0f, 0, dbeta);
   hipLaunchKernelGGL(colfin_kernel, dim3((unsigned)sk_cdiv(C, 256)), dim3(256), 0, st, p1, nch, C, 1.0f, 0, dgamma);
-  const int64_t total = (int64_t)R * C;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, dout, x, mean, var, gamma,
-                     dgamma, dbeta, dx, total, R, C, eps);
-  SK_CHECK_LAUNCH("sk_bn_bwd");
+  SK_CHECK_LAUNCH("sk_bn_bwd_sums");
   return SK_OK;
+}
+
+extern "C" int sk_bn_bwd_apply(const float* dout, const float* x, const float* mean, const float* var,
+                               const float* gamma, const float* dgamma, const float* dbeta, float* dx, int R, int C,
+                               double count, float eps, sk_stream_t stream) {
+  SK_CHECK_ARG(dout && x && mean && var && gamma && dgamma && dbeta && dx && R > 0 && C > 0 && count >= 1.0,
+               "sk_bn_bwd_apply: bad arguments");
+  const int64_t total = (int64_t)R * C;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, dout, x, mean,
+                     var, gamma, dgamma, dbeta, dx, total, (float)count, C, eps);
+  SK_CHECK_LAUNCH("sk_bn_bwd_apply");
+  return SK_OK;
+}
+
+extern "C" int sk_bn_bwd(const float* dout, const float* x, const float* mean, const float* var, const float* gamma,
+                         float* dx, float* dgamma, float* dbeta, void* ws, int R, int C, float eps,
+                         sk_stream_t stream) {
+  SK_CHECK_ARG(R > 1, "sk_bn_bwd: bad arguments");
+  int rc = sk_bn_bwd_sums(dout, x, mean, var, dgamma, dbeta, ws, R, C, eps, stream);
+  if (rc) return rc;
+  return sk_bn_bwd_apply(dout, x, mean, var, gamma, dgamma, dbeta, dx, R, C, (double)R, eps, stream);
 }
 
 extern "C" int sk_colsum(const float* x, int R, int C, int ld, float* out, int accumulate, void* ws,

@@ -39,6 +39,8 @@ PROTOTYPES = {
     "sk_bn_update_running": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "sk_bn_apply": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "sk_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "sk_bn_bwd_sums": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "sk_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, C.c_double, _f, _p]),
     "sk_colsum": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
     "sk_sigmoid_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "sk_pit_workspace_bytes": (_sz, [_i, _i, _i]),

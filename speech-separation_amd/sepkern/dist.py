@@ -7,7 +7,10 @@ whose batch statistics stay per-rank (as torch's DistributedDataParallel does by
   * the PIT loss of every rank is divided by the GLOBAL norm sum(len)*F (one scalar all-reduce,
     known before the forward pass because it depends on lengths only),
   * the flat fp32 gradient buffer is summed with ONE all-reduce per step, after which every rank
-    runs the identical clip + Adam update.
+    runs the identical clip + Adam update,
+  * optionally (conf key sync_bn=1 / SEPKERN_SYNC_BN=1) BatchNorm uses the statistics of the GLOBAL batch: one
+    all-gather of the per-rank (count, mean, variance) in the forward pass and one all-reduce of the two
+    per-channel sums in the backward pass; the update then equals the single-device global-batch update.
 These helpers are backend-agnostic so the N>1 path is covered by world_size-2 gloo tests on CPU.
 """
 import os
@@ -67,3 +70,30 @@ def allreduce_grads(flat_grad):
     if is_parallel():
         dist.all_reduce(flat_grad)
     return flat_grad
+
+
+def combine_bn_stats(mean, var, count):
+    """Per-rank batch statistics (mean, biased variance over `count` rows) -> statistics of the union of all ranks'
+    rows, by the pairwise-combination formula M2 = sum_r n_r (var_r + (mean_r - mean)^2).  One all-gather.
+    Returns (mean, var, total_count); the inputs unchanged when not parallel."""
+    if not is_parallel():
+        return mean, var, float(count)
+    C = mean.numel()
+    mine = torch.cat([mean.reshape(-1), var.reshape(-1), mean.new_full((1,), float(count))])
+    allr = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(allr, mine)
+    st = torch.stack(allr)                                   # (world, 2C+1)
+    n = st[:, 2 * C:2 * C + 1]                               # (world, 1)
+    total = n.sum()
+    gmean = (st[:, :C] * n).sum(0) / total
+    gvar = (n * (st[:, C:2 * C] + (st[:, :C] - gmean) ** 2)).sum(0) / total
+    return gmean.contiguous(), gvar.contiguous(), float(total.item())
+
+
+def allreduce_bn_sums(dgamma, dbeta):
+    """Global per-channel sums for the BatchNorm backward (copies; the local ones stay the parameter gradients that
+    the flat all-reduce sums later)."""
+    both = torch.stack([dgamma, dbeta])
+    if is_parallel():
+        dist.all_reduce(both)
+    return both[0].contiguous(), both[1].contiguous()

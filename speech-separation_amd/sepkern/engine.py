@@ -12,6 +12,7 @@ import os
 
 import torch
 
+from . import dist as skdist
 from . import ops
 from ._lib import SepkernError
 
@@ -64,13 +65,15 @@ class ParamLayout:
 class Engine:
     """Forward / backward of the network on one device."""
 
-    def __init__(self, in_dim, out_dim, hidden, layers, device, precision="fp32"):
+    def __init__(self, in_dim, out_dim, hidden, layers, device, precision="fp32", sync_bn=False):
         if precision not in ("fp32", "bf16"):
             raise SepkernError("precision must be 'fp32' or 'bf16' (got %r)" % (precision,))
         # bf16: EVERY matrix product (input projections, Linear, the recurrence h W_hh^T, their data and weight
         # gradients) rounds both operands to bf16 on the way into the matrix cores and accumulates in fp32;
         # parameters, activations, cell state, gradients, BatchNorm, the loss and Adam stay fp32.
         self.precision, self.bf16 = precision, precision == "bf16"
+        # data-parallel runs only: BatchNorm over the GLOBAL batch instead of per rank (sepkern/dist.py)
+        self.sync_bn = bool(sync_bn) or os.environ.get("SEPKERN_SYNC_BN", "0") == "1"
         if hidden % 4 != 0 or hidden > 1024:
             raise SepkernError("hidden_dim must be a multiple of 4 and <= 1024 (got %d)" % hidden)
         self.I, self.O, self.H, self.L = in_dim, out_dim, hidden, layers
@@ -150,9 +153,12 @@ class Engine:
             mean = torch.empty(2 * H, device=dev)
             var = torch.empty(2 * H, device=dev)
             ops.bn_stats(y2d, mean, var)
-            ops.bn_update_running(mean, var, self.running_mean, self.running_var, R, self.momentum)
+            bn_count = float(R)
+            if self.sync_bn:                             # statistics of the global batch (one all-gather)
+                mean, var, bn_count = skdist.combine_bn_stats(mean, var, R)
+            ops.bn_update_running(mean, var, self.running_mean, self.running_var, int(bn_count), self.momentum)
         else:
-            mean, var = self.running_mean, self.running_var
+            mean, var, bn_count = self.running_mean, self.running_var, float(R)
         xbn = torch.empty(R, 2 * H, device=dev)
         ops.bn_apply(y2d, mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
         mask = torch.empty(T, B, O, device=dev)
@@ -160,7 +166,7 @@ class Engine:
                  bias=self.p("lin.bias"), act=1, bf16=self.bf16)
         ctx = None
         if save:
-            ctx = dict(saved=saved, mean=mean, var=var, xbn=xbn, mask=mask, lens=lens, h0=h0, c0=c0,
+            ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, mask=mask, lens=lens, h0=h0, c0=c0,
                        T=T, B=B, training=training)
         return mask, hn, cn, ctx
 
@@ -197,9 +203,13 @@ class Engine:
         dy = torch.empty(R, 2 * H, device=dev)
         dgamma = torch.empty(2 * H, device=dev)
         dbeta = torch.empty(2 * H, device=dev)
-        ops.bn_bwd(dxbn, y_top, ctx["mean"], ctx["var"], self.p("bn.weight"), dy, dgamma, dbeta, self.eps)
-        put("bn.weight", dgamma)
+        ops.bn_bwd_sums(dxbn, y_top, ctx["mean"], ctx["var"], dgamma, dbeta, self.eps)
+        put("bn.weight", dgamma)                         # local sums: the flat all-reduce adds the ranks up later
         put("bn.bias", dbeta)
+        if self.sync_bn:                                 # dx needs the sums over the global batch (one all-reduce)
+            dgamma, dbeta = skdist.allreduce_bn_sums(dgamma, dbeta)
+        ops.bn_bwd_apply(dxbn, y_top, ctx["mean"], ctx["var"], self.p("bn.weight"), dgamma, dbeta, dy, ctx["bn_count"],
+                         self.eps)
         del dxbn
         ws = None
         dh0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None

@@ -46,13 +46,14 @@ class NetFn(torch.autograd.Function):
 class SepDNNBase(nn.Module):
   """BLSTM(in_dim -> H, L layers, bidirectional) -> BatchNorm1d(2H) -> Linear(2H -> out_dim) -> sigmoid."""
 
-  def _build(self, gpuid, in_dim, out_dim, hidden_dim, num_layers, precision="fp32"):
+  def _build(self, gpuid, in_dim, out_dim, hidden_dim, num_layers, precision="fp32", sync_bn=False):
     self.gpuid = gpuid
     if int(gpuid) < 0:
       raise SepkernError("SepDNN(gpuid=%s): this build has no CPU path; it runs on an MI355X only" % gpuid)
     self.in_dim, self.out_dim = int(in_dim), int(out_dim)
     self.hidden_dim, self.num_layers = int(hidden_dim), int(num_layers)
     self.precision = str(precision)
+    self.sync_bn = str(sync_bn).lower() in ("1", "true", "yes")
     H, L = self.hidden_dim, self.num_layers
     # Initial values exactly as the reference draws them (nn.LSTM, nn.Linear, nn.BatchNorm1d constructed in
     # this order consume the RNG identically, archs/uPIT.py:115-119 / archs/RSH.py:155-159); the modules are
@@ -100,7 +101,7 @@ class SepDNNBase(nn.Module):
       eng.running_mean, eng.running_var = self.bn.running_mean, self.bn.running_var
       return eng
     with torch.cuda.device(dev):
-      eng = Engine(self.in_dim, self.out_dim, self.hidden_dim, self.num_layers, dev, self.precision)
+      eng = Engine(self.in_dim, self.out_dim, self.hidden_dim, self.num_layers, dev, self.precision, self.sync_bn)
     with torch.no_grad():
       for p, v in self._named_views(eng.p):
         v.copy_(p.data)

@@ -339,6 +339,18 @@ def bn_bwd(dout, x2d, mean, var, gamma, dx, dgamma, dbeta, eps):
               _ptr(dbeta), _ptr(bn_ws(R, Cc)), R, Cc, float(eps), _stream())
 
 
+def bn_bwd_sums(dout, x2d, mean, var, dgamma, dbeta, eps):
+    R, Cc = x2d.shape
+    _lib.call("sk_bn_bwd_sums", _ptr(dout), _ptr(x2d), _ptr(mean), _ptr(var), _ptr(dgamma), _ptr(dbeta),
+              _ptr(bn_ws(R, Cc)), R, Cc, float(eps), _stream())
+
+
+def bn_bwd_apply(dout, x2d, mean, var, gamma, dgamma, dbeta, dx, count, eps):
+    R, Cc = x2d.shape
+    _lib.call("sk_bn_bwd_apply", _ptr(dout), _ptr(x2d), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
+              _ptr(dx), R, Cc, float(count), float(eps), _stream())
+
+
 def colsum(x, R, Ccols, ld, out, accumulate=False, ws_tag="bn"):
     _lib.call("sk_colsum", _ptr(x), R, Ccols, ld, _ptr(out), int(accumulate), _ptr(bn_ws(R, Ccols, ws_tag)), _stream())
 

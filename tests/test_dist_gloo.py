@@ -120,3 +120,38 @@ def test_two_rank_dp_equals_single_process_global_batch():
         np.testing.assert_allclose(tot, float(loss), rtol=1e-5)
         np.testing.assert_allclose(flat, ref, rtol=2e-4, atol=1e-7)
     np.testing.assert_array_equal(res[0][3], res[1][3])          # every rank holds the identical summed gradient
+
+
+def _bn_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sepkern import dist as skdist
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(n, 5, generator=g) * (1 + i) + i for i, n in enumerate((7, 12))]      # unequal shard sizes
+    x = xs[rank]
+    mean, var, n = skdist.combine_bn_stats(x.mean(0), x.var(0, unbiased=False), x.shape[0])
+    dg, db = skdist.allreduce_bn_sums(x.sum(0), (x * x).sum(0))
+    allx = torch.cat(xs)
+    ok = (n == 19.0 and torch.allclose(mean, allx.mean(0), atol=1e-6) and
+          torch.allclose(var, allx.var(0, unbiased=False), rtol=1e-5) and
+          torch.allclose(dg, allx.sum(0), rtol=1e-6) and torch.allclose(db, (allx * allx).sum(0), rtol=1e-6))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bn_statistics_of_the_global_batch_over_two_ranks():
+    """The optional BatchNorm exchange of the data-parallel path (sepkern.dist.combine_bn_stats / allreduce_bn_sums):
+    per-rank (count, mean, biased variance) combine to the statistics of the union, per-channel sums add up."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]

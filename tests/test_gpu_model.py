@@ -314,3 +314,44 @@ def test_coscheduled_backward_is_bitwise_the_serial_backward(arch):
         g_co, l_co = grads(True)
         assert l_co == l_ser
         assert torch.equal(g_co, g_ser)
+
+
+def test_data_parallel_sync_bn_equals_global_batch(tmp_path):
+    """with the optional BatchNorm exchange (sync_bn=1: one all-gather of per-rank statistics forward, one
+    all-reduce of the two per-channel sums backward) the data-parallel update equals the single-device update on the
+    global batch.  2 ranks on cuda:0 over gloo (LSTM per-step mode: two processes cannot both keep a persistent grid
+    resident on one GPU) against one process holding all 8 utterances."""
+    import socket
+    import subprocess
+    import sys as _sys
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    worker = os.path.join(tests_dir, "_dp_syncbn_worker.py")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, SEPKERN_DIST_BACKEND="gloo", SEPKERN_LSTM_MODE="2")
+    dp = str(tmp_path / "dp.npz")
+    r = subprocess.run([_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), worker, dp, "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    single = str(tmp_path / "single.npz")
+    env1 = {k: v for k, v in env.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([_sys.executable, worker, single, "0"], env=env1, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    a, b = np.load(dp), np.load(single)
+    assert float(a["norm"]) == float(b["norm"])
+    np.testing.assert_allclose(float(a["loss"]), float(b["loss"]), rtol=2e-6)
+    np.testing.assert_allclose(a["running_mean"], b["running_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(a["running_var"], b["running_var"], rtol=1e-5, atol=1e-7)
+    err = np.linalg.norm(a["grad"].astype(np.float64) - b["grad"]) / np.linalg.norm(b["grad"])
+    assert err < 2e-5, err
+    # and without the exchange the two differ (per-rank statistics): the option is doing something
+    nosync = str(tmp_path / "nosync.npz")
+    r = subprocess.run([_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), worker, nosync, "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    c = np.load(nosync)
+    assert np.linalg.norm(c["grad"].astype(np.float64) - b["grad"]) / np.linalg.norm(b["grad"]) > 1e-3
