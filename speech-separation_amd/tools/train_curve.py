@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Sanity run, not a benchmark: N optimisation steps of the 3x896 uPIT model on ONE fixed synthetic batch (the bench's
+WSJ0-2mix-shaped 32 x 400 frames) with the bench's optimiser settings, printing the loss every few steps -- the loss must
+fall monotonically-ish and stay finite, in fp32 and in bf16 arithmetic, with the engine's co-scheduling on."""
+import contextlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "speech-separation_amd"), os.path.join(ROOT, "speech-separation_amd", "archs")):
+    sys.path.insert(0, p)
+import bench  # noqa: E402  (make_batch)
+import uPIT  # noqa: E402
+from sepkern import ops, synth  # noqa: E402
+from sepkern.optim import ClipAdam  # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    for dt in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(sys.stderr):
+            model = uPIT.SepDNN(0, num_spk="2", hidden_dim="896", num_layers="3", dtype=dt)
+        model.cuda()
+        model.train()
+        model.hidden_generator = torch.Generator(device="cuda")
+        model.hidden_generator.manual_seed(1234)
+        opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
+        mix, srcs, lens, _ = bench.make_batch(torch, ops, synth, 32, 400, 2, 0)
+        out = []
+        for i in range(steps):
+            loss, norm = uPIT.compute_loss_padded(model, mix, srcs, lens)
+            loss.backward()
+            opt.step()
+            if i % 20 == 0 or i == steps - 1:
+                out.append("%d:%.5f" % (i, float(loss)))
+        v = float(loss)
+        assert v == v and v > 0
+        print("%s  loss by step  %s" % (dt, "  ".join(out)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
