@@ -191,13 +191,25 @@ class Engine:
             else:
                 self.g(name).copy_(val)
 
+        overlap = self.overlap and L > 1 and self.lstm_mode == 0
+        if overlap and self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        keep = []                                        # tensors used on the side stream stay alive until the join
         dz = torch.empty_like(dmask)
         ops.sigmoid_bwd(dmask, ctx["mask"], dz)
-        ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), O, 2 * H, R, O, 2 * H, 2 * H, transA=True, accumulate=acc,
-                 splitk=0, bf16=self.bf16)
-        ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc)
         dxbn = torch.empty(R, 2 * H, device=dev)
         ops.gemm(dz, self.p("lin.weight"), dxbn, R, 2 * H, O, O, 2 * H, 2 * H, bf16=self.bf16)
+        # the Linear layer's own gradients are needed by nobody before clip+Adam: side stream, next to the top
+        # layer's recurrence
+        stream = self.side if overlap else main
+        if stream is not main:
+            stream.wait_stream(main)
+        with torch.cuda.stream(stream):
+            ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), O, 2 * H, R, O, 2 * H, 2 * H, transA=True, accumulate=acc,
+                     splitk=0, ws_tag="gemm_side" if overlap else "gemm", bf16=self.bf16)
+            ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc, ws_tag="bn_side" if overlap else "bn")
+            keep.append(dz)
         del dz
         y_top = ctx["saved"][-1][3].view(R, 2 * H)
         dy = torch.empty(R, 2 * H, device=dev)
@@ -215,11 +227,6 @@ class Engine:
         dh0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
         dc0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
         dx = None
-        overlap = self.overlap and L > 1 and self.lstm_mode == 0
-        if overlap and self.side is None:
-            self.side = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream(dev)
-        keep = []                                        # tensors used on the side stream stay alive until the join
         for l in range(L - 1, -1, -1):
             inp, gates, cs, y = ctx["saved"][l]
             I = I0 if l == 0 else 2 * H
