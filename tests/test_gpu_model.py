@@ -143,7 +143,8 @@ def _oracle_like(model, H, L, S):
     return o
 
 
-@pytest.mark.parametrize("H,L,S,B,T", [(300, 2, 2, 8, 40), (896, 3, 2, 32, 24), (600, 2, 3, 5, 30)])
+@pytest.mark.parametrize("H,L,S,B,T", [(300, 2, 2, 8, 40), (896, 3, 2, 32, 24), (600, 2, 3, 5, 30), (20, 1, 1, 3, 10),
+                                       (256, 1, 4, 2, 6)])
 def test_configs_match_oracle(arch, H, L, S, B, T):
     """BASELINE configs 1 (2x300), 2 (3x896, B=32) and 4 (3 speakers) against the CPU oracle, ragged lengths."""
     torch.manual_seed(H + L)
