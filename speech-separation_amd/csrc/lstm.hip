@@ -522,7 +522,7 @@ __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* 
                                          f32x4& acc0, f32x4& acc1) {
   using C = BwdCfg<KS, BF>;
   if constexpr (I < C::NSB) {
-    constexpr int younger = C::cnt(I + 1) + (C::DEPTH > 2 ? C::cnt(I + 2) : 0);
+    constexpr int younger = C::cnt(I + 1) + (C::DEPTH > 2 ? C::cnt(I + 2) : 0) + (C::DEPTH > 3 ? C::cnt(I + 3) : 0);
     wait_vmcnt<younger>();
     bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
     if constexpr (I + C::DEPTH < C::NSB) {
@@ -547,6 +547,7 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
   bwd_issue<KS, BF, 0>(xsrc, ring, w, lane);
   bwd_issue<KS, BF, 1>(xsrc, ring, w, lane);
   if constexpr (BwdCfg<KS, BF>::DEPTH > 2) bwd_issue<KS, BF, 2>(xsrc, ring, w, lane);
+  if constexpr (BwdCfg<KS, BF>::DEPTH > 3) bwd_issue<KS, BF, 3>(xsrc, ring, w, lane);
   bwd_ring<KS, BF, 0>(wreg, xsrc, ring, w, lane, acc0, acc1);
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
