@@ -33,6 +33,7 @@ except ImportError:  # the frozen copy exp/<...>/arch.py is imported from anothe
     import sepkern  # noqa: F401
 from sepkern import dist as skdist
 from sepkern import ops
+from sepkern._lib import SepkernError
 from sepkern.model import SepDNNBase, to_padded as _to_padded
 
 
@@ -186,8 +187,12 @@ class SepDNN(SepDNNBase):
     self.feat_dim = int(kwargs.get('feat_dim', 257))
     for key in kwargs.keys():
       print('modelparam:', key, kwargs[key])
+    # sync_bn is a uPIT option: here the network runs once per speaker and the ranks of a data-parallel job may hold
+    # batches with different speaker counts, so a collective inside the forward pass could not be matched
+    if str(kwargs.get('sync_bn', '0')).lower() in ('1', 'true', 'yes'):
+      raise SepkernError("RSH does not support sync_bn (ranks may run different numbers of passes)")
     self._build(gpuid, self.feat_dim * 2, self.feat_dim, int(kwargs.get('hidden_dim', 600)),
-                int(kwargs.get('num_layers', 2)), str(kwargs.get('dtype', 'fp32')), kwargs.get('sync_bn', '0'))
+                int(kwargs.get('num_layers', 2)), str(kwargs.get('dtype', 'fp32')))
 
   def forward_padded(self, x, lens):
     """x (T,B,2F) -> mask (T,B,F); self.hidden is replaced by the LSTM's final state (archs/RSH.py:172)."""
