@@ -245,8 +245,9 @@ def compute_loss_padded(model, groups, plotdir=""):
         plot.plot_spec(sources[int(sel[0])][:, 0].cpu().numpy(), prefix + 'Chosen_Source.png')
       combos = _AttFn.apply(combos, mask_out, True)
 
-  # data-parallel: the global frame count normalises every rank's loss (sepkern.dist)
-  if skdist.is_parallel():
+  # data-parallel: the global frame count normalises every rank's loss (sepkern.dist) -- training steps only:
+  # the CV pass runs the whole, unsharded set on every rank and keeps its local norm
+  if skdist.is_parallel() and model.training and torch.is_grad_enabled():
     gn = norm.reshape(1).clone()
     torch.distributed.all_reduce(gn)
     norm = gn[0]

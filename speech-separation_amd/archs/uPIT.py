@@ -246,12 +246,15 @@ def compute_loss_padded(model, mix, sources, lens, plotdir=""):
 
   # data-parallel: divide by the GLOBAL frame count so that the summed gradients equal the
   # single-device gradient of the global batch (None = single process, kernel uses sum(lens)*F)
-  norm_override = skdist.global_norm(lens, model.feat_dim)
+  # -- only while training: the CV pass runs the whole (unsharded) set on every rank, local norm.
+  training_step = model.training and torch.is_grad_enabled()
+  norm_override = skdist.global_norm(lens, model.feat_dim) if training_step else None
 
   mask_out = model.forward_padded(mix, lens)
   # mask_out: tensor of shape (seq_length, batch, feat_dim*num_spk)
   out, best = _PitFn.apply(mask_out, mix, lens, norm_override, *sources)
   loss, norm = out[0], out[1].detach()
+  model.last_best_perm = best.detach()      # arg-min permutation per utterance (index into itertools.permutations)
 
   if plotdir:
     sys.path.append('tools')

@@ -77,7 +77,7 @@ inline WsLayout ws_layout(int B, int H, bool bf = false) {
   const size_t Hp = 16 * (size_t)w.KS;
   w.ctrl = 0;
   w.flags = 256;
-  const size_t nflags = 2 * (size_t)w.NBG * w.KS;
+  const size_t nflags = 2 * (size_t)w.NBG * 2 * w.KS;  // up to 2 KS unit groups (8-unit workgroups)
   w.xbuf = w.flags + sk_align(nflags * 4, 256);
   const size_t xbytes = 2 * 2 * (size_t)w.NBG * Hp * 64 * 4;  // backward exchange is the larger one
   w.state = w.xbuf + sk_align(xbytes, 256);
@@ -102,6 +102,7 @@ struct FwdArgs {
   unsigned* flags;
   unsigned* ctrl;
   int T, B, H, NBG, G, s_begin, s_end;
+  int map, nby;  // block id -> (unit group, batch-group block, direction) assignment (speed only), grid y extent
 };
 
 struct BwdArgs {
@@ -207,20 +208,58 @@ __device__ __forceinline__ void wait_vmcnt() {
 // h_t is in flight to the other workgroups the next group computes.
 constexpr int GMAX = 8;
 
-template <int KS, bool BF>
-__global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
+// Which (unit group, batch-group block, direction) a workgroup takes.  Any bijection is correct (the hand-off is
+// placement-independent); the choice only decides which workgroups share an XCD's L2 / a CU.  Observed dispatch:
+// linear block id L lands on XCD L % 8, so
+//   map 0: direction-major, batch-group-major, unit group fastest (every stream spread over all 8 XCDs);
+//   map 1: the streams (direction x batch-group block) are dealt to XCD groups: with S streams and 8 % S == 0 a
+//          stream's workgroups all sit on 8/S XCDs, so its h_t exchange crosses fewer L2s;
+//   map 2: as 1 for pairs of streams: XCD group g hosts streams 2g and 2g+1, the first half of every XCD's run one
+//          stream and the second half the other (two workgroups that share a CU then belong to different streams).
+__device__ __forceinline__ void decode_block(int L, int NUG, int nby, int map, int& ug, int& by, int& dir) {
+  const int S = nby * 2, total = NUG * S;
+  int stream, u;
+  const int x = L & 7, j = L >> 3, per_xcd = total >> 3;
+  if (map == 1 && (total & 7) == 0 && (8 % S) == 0 && (NUG % (8 / S)) == 0) {
+    const int g = 8 / S;                 // XCDs per stream
+    stream = x / g;
+    u = j * g + (x % g);                 // per_xcd * g == NUG
+  } else if (map == 2 && (total & 7) == 0 && (S & 1) == 0 && (8 % (S / 2)) == 0 && ((2 * NUG) % (8 / (S / 2))) == 0 &&
+             (per_xcd & 1) == 0) {
+    const int g = 8 / (S / 2);           // XCDs per pair of streams
+    const int half = per_xcd >> 1;       // workgroups of one stream on one XCD
+    stream = 2 * (x / g) + (j >= half ? 1 : 0);
+    u = (j % half) * g + (x % g);        // half * g == NUG
+  } else {
+    stream = L / NUG;
+    u = L - stream * NUG;
+  }
+  ug = u;
+  by = stream % nby;
+  dir = stream / nby;
+}
+
+// NW = waves per workgroup.  8: 16 hidden units per workgroup (4 gate-row tiles x 2 K halves), one workgroup per CU.
+// 4: 8 units per workgroup (2 tiles x 2 K halves), TWO workgroups per CU that belong to different streams: while one
+// waits for its hand-off the other has the matrix pipe, so a step costs the chain plus HALF the MFMA time.
+template <int KS, bool BF, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int HP = 16 * KS;
+  constexpr int MT = NW / 2;              // gate-row tiles (4 units each) per workgroup
+  constexpr int NT = NW * 64;
+  constexpr int NUG = HP / (4 * MT);      // unit groups = workgroups per (direction, batch-group block)
   constexpr int NCH = BF ? HP / 32 : KS;  // 1 KB chunks of the h image (16 k each in fp32, 32 k in bf16)
   constexpr int NQ = NCH / 2;             // chunks per wave (one K half)
   static_assert(NCH % 2 == 0, "image chunks must split into two K halves");
   __shared__ __attribute__((aligned(16))) float hs[16 * HP];  // B-operand image of h_{s-1}: [k/4][16 rows][4]
-  __shared__ __attribute__((aligned(16))) float red[4][64][4];
-  __shared__ float st_c[GMAX][256], st_h[GMAX][256];          // per-group cell state of the owner lanes
+  __shared__ __attribute__((aligned(16))) float red[MT][64][4];
+  __shared__ float st_c[GMAX][64 * MT], st_h[GMAX][64 * MT];  // per-group cell state of the owner lanes
   __shared__ int s_abort;
 
-  const int ug = blockIdx.x, by = blockIdx.y, dir = blockIdx.z;
+  int ug, by, dir;
+  decode_block((int)blockIdx.x, NUG, a.nby, a.map, ug, by, dir);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int mt = w & 3, kh = w >> 2;
+  const int mt = w % MT, kh = w / MT;
   const int T = a.T, B = a.B, H = a.H, NBG = a.NBG, G = a.G;
 
   // ---- W_hh slice -> registers.  MFMA A operand: lane l supplies A[i = l&15][k = l>>4];
@@ -230,7 +269,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
   bf16x8 wb[BF ? NQ : 1];
   {
     const int i = lane & 15, kq = lane >> 4;
-    const int unit_i = ug * 16 + 4 * mt + (i >> 2), g_i = i & 3;
+    const int unit_i = ug * (4 * MT) + 4 * mt + (i >> 2), g_i = i & 3;
     const bool rowok = unit_i < H;
     const float* wrow = a.whh + ((size_t)dir * 4 * H + (size_t)g_i * H + unit_i) * H;
 #pragma unroll
@@ -254,11 +293,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
   }
 
   const int u_l = lane >> 4, bl = lane & 15;
-  const int unit = ug * 16 + 4 * mt + u_l;
+  const int unit = ug * (4 * MT) + 4 * mt + u_l;
   const bool owner = kh == 0;  // this wave carries cells
   const int oi = mt * 64 + lane;
   const size_t xblk = (size_t)16 * HP;  // floats per (parity, dir, batch group) exchange block
-  const int xoff = ((ug * 4 + mt) * 16 + bl) * 4 + u_l;  // fp32 image position of (k = unit, row = bl)
+  const int xoff = ((unit >> 2) * 16 + bl) * 4 + (unit & 3);  // fp32 image position of (k = unit, row = bl)
   const size_t hst = (size_t)2 * NBG * 16 * HP;           // second state array (bf16: exact h between step launches)
 
   if (owner) {
@@ -296,7 +335,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
       const int len_b = (b < B) ? a.lens[b] : 0;
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
-      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * NUG;
       SK_STAMP(7);
       // 1. this step's input-projection terms (independent of the recurrence: issue early)
       float gxv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -312,7 +351,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
       // the split costs 2 % in fp32 and gains 1.5 % in bf16).
       if (s == 0) {
         if (BF) {
-          for (int i = tid; i < 16 * (HP / 8); i += NTHREADS) {
+          for (int i = tid; i < 16 * (HP / 8); i += NT) {
             const int bb = i & 15, c8 = i >> 4;  // row, k/8
             const int brow = bg * 16 + bb, k = 8 * c8;
             float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
@@ -322,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
             *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(hs) + bf_img(k, bb)) = pack8(v0, v1);
           }
         } else {
-          for (int i = tid; i < 16 * (HP / 4); i += NTHREADS) {
+          for (int i = tid; i < 16 * (HP / 4); i += NT) {
             const int bb = i & 15, c = i >> 4;  // row, k/4
             const int brow = bg * 16 + bb;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -331,9 +370,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
           }
         }
       } else if (!BF || !owner) {
-        constexpr int PP = KS / NCH;    // unit groups (flags) per piece: 1 in fp32, 2 in bf16
-        constexpr int NCW = BF ? 4 : 8;  // consumer waves
-        const int wq = BF ? w - 4 : w;
+        constexpr int PP = NUG / NCH;            // unit groups (flags) per 1 KB piece
+        constexpr int NCW = BF ? NW / 2 : NW;    // consumer waves
+        static_assert(PP * ((NCH + NCW - 1) / NCW) <= 64, "one lane per polled flag");
+        const int wq = BF ? w - NW / 2 : w;
         bool ok = true;
         if (s > a.s_begin) {
           const int piece = wq + NCW * (lane / PP);
@@ -410,7 +450,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_fwd_kernel(FwdArgs a) {
             float* xdst = (s & 1) ? xb1 : xb0;
             __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs,
-                                                  (unsigned)(bf_img(ug * 16 + 4 * mt, bl) * 2), 0, 16 /* sc1 */);
+                                                  (unsigned)(bf_img(ug * (4 * MT) + 4 * mt, bl) * 2), 0, 16 /* sc1 */);
           }
         } else {
           __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
@@ -781,8 +821,11 @@ __global__ __launch_bounds__(256) void hprev_kernel(const float* __restrict__ y,
 }
 
 template <int KS, bool BF>
-int launch_fwd(const FwdArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF>), grid, dim3(NTHREADS), 0, st, a);
+int launch_fwd(const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
+  if (half)
+    hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 4>), dim3((unsigned)nblocks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 8>), dim3((unsigned)nblocks), dim3(512), 0, st, a);
   return 0;
 }
 template <int KS, bool BF>
@@ -791,18 +834,18 @@ int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
   return 0;
 }
 
-int dispatch_fwd(int KS, bool bf, const FwdArgs& a, dim3 grid, hipStream_t st) {
+int dispatch_fwd(int KS, bool bf, const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
   if (bf) switch (KS) {
-      case 20: return launch_fwd<20, true>(a, grid, st);
-      case 40: return launch_fwd<40, true>(a, grid, st);
-      case 56: return launch_fwd<56, true>(a, grid, st);
-      default: return launch_fwd<64, true>(a, grid, st);
+      case 20: return launch_fwd<20, true>(a, half, nblocks, st);
+      case 40: return launch_fwd<40, true>(a, half, nblocks, st);
+      case 56: return launch_fwd<56, true>(a, half, nblocks, st);
+      default: return launch_fwd<64, true>(a, half, nblocks, st);
     }
   switch (KS) {
-    case 20: return launch_fwd<20, false>(a, grid, st);
-    case 38: return launch_fwd<38, false>(a, grid, st);
-    case 56: return launch_fwd<56, false>(a, grid, st);
-    default: return launch_fwd<64, false>(a, grid, st);
+    case 20: return launch_fwd<20, false>(a, half, nblocks, st);
+    case 38: return launch_fwd<38, false>(a, half, nblocks, st);
+    case 56: return launch_fwd<56, false>(a, half, nblocks, st);
+    default: return launch_fwd<64, false>(a, half, nblocks, st);
   }
 }
 int dispatch_bwd(int KS, bool bf, const BwdArgs& a, dim3 grid, hipStream_t st) {
@@ -832,10 +875,10 @@ int num_cus() {
 
 // Smallest number of batch groups per workgroup for which the whole grid (one workgroup per CU) is
 // co-resident; 0 if even GMAX groups per workgroup do not fit (then the caller launches per step).
-int groups_per_wg(int KS, int NBG, int gmin) {
+int groups_per_wg(int NUG, int NBG, int gmin, int wg_per_cu = 1) {
   const int cus = num_cus();
   for (int g = (gmin < 1 ? 1 : gmin); g <= GMAX; ++g)
-    if (KS * ((NBG + g - 1) / g) * 2 <= cus) return g;
+    if (NUG * ((NBG + g - 1) / g) * 2 <= cus * wg_per_cu) return g;
   return 0;
 }
 
@@ -843,7 +886,7 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 17) == 0,
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 20) == 0,
                "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
@@ -867,6 +910,8 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   if (rc) return rc;
   const int gmin = (mode >> 8) & 0xff;  // bits 8..15: minimum batch groups per workgroup (frees CUs for concurrent kernels)
   const bool bf = (mode >> 16) & 1;     // bit 16: bf16 matrix-core inputs
+  const bool half = (mode >> 17) & 1;   // bit 17: 8-unit, 256-thread workgroups, two per CU
+  const int map = (mode >> 18) & 3;     // bits 18..19: block id -> stream assignment (speed only)
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -877,20 +922,22 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
-  const int G = groups_per_wg(L.KS, L.NBG, gmin);
+  const int NUG = half ? 2 * L.KS : L.KS;
+  const int G = groups_per_wg(NUG, L.NBG, gmin, half ? 2 : 1);
   const bool fits = G > 0;
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
-  dim3 grid((unsigned)L.KS, (unsigned)nby, 2);
+  a.map = map; a.nby = nby;
+  const int nblocks = NUG * nby * 2;
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));  // status word + flags
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T;
-    dispatch_fwd(L.KS, bf, a, grid, st);
+    dispatch_fwd(L.KS, bf, a, half, nblocks, st);
   } else {
     for (int s = 0; s < T; ++s) {
       a.s_begin = s; a.s_end = s + 1;
-      dispatch_fwd(L.KS, bf, a, grid, st);
+      dispatch_fwd(L.KS, bf, a, half, nblocks, st);
     }
   }
   SK_CHECK_LAUNCH("sk_lstm_fwd");

@@ -85,6 +85,10 @@ class Engine:
         self.running_var = torch.ones(2 * hidden, device=device)
         self.eps, self.momentum = 1e-5, 0.1
         self.lstm_mode = int(os.environ.get("SEPKERN_LSTM_MODE", "0"))
+        # forward recurrence geometry (speed only): "half,map" -- half=1: 8-unit / 256-thread workgroups, two per CU;
+        # map 0..2: block id -> stream assignment (csrc/lstm.hip::decode_block)
+        fv = os.environ.get("SEPKERN_LSTM_FWD", "0,0").split(",")
+        self.fwd_half, self.fwd_map = bool(int(fv[0])), int(fv[1]) if len(fv) > 1 else 0
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one.
         # SEPKERN_OVERLAP=2 (default): the recurrence keeps its one-workgroup-per-CU grid and the GEMM blocks
         # become CO-RESIDENT on its CUs -- a persistent workgroup leaves >=124 VGPRs per SIMD lane and >=69 KB of
@@ -144,7 +148,7 @@ class Engine:
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
             ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
                               hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
-                              T, B, H, self.lstm_mode, bf16=self.bf16)
+                              T, B, H, self.lstm_mode, bf16=self.bf16, half=self.fwd_half, blockmap=self.fwd_map)
             saved.append((inp, gx, cs, y))
             inp, I = y, 2 * H
         self._check_status(ws)

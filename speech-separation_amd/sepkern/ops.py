@@ -367,10 +367,12 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
-def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False):
-    """bf16=True: W_hh and h_{t-1} enter the matrix cores rounded to bf16 (fp32 accumulate, fp32 state)."""
+def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0):
+    """bf16=True: W_hh and h_{t-1} enter the matrix cores rounded to bf16 (fp32 accumulate, fp32 state).
+    half=True: 8-unit / 256-thread workgroups, two per CU (include/sepkern.h, mode bit 17); blockmap 0..2: which
+    workgroups share an XCD / a CU (mode bits 18..19; speed only)."""
     ws = lstm_ws(T, B, H)
-    mode = int(mode) | (0x10000 if bf16 else 0)
+    mode = int(mode) | (0x10000 if bf16 else 0) | (0x20000 if half else 0) | ((int(blockmap) & 3) << 18)
     with _timed("lstm_fwd_kernel", 2.0 * T * B * 2 * 4 * H * H):
         _lib.call("sk_lstm_fwd", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(y), _ptr(gates), _ptr(cs),
                   _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, _stream())

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Stand-alone timing of the persistent BLSTM recurrence kernels (one layer, both directions), variants interleaved
+in ONE process (cdna_hip_programming.md 5.4 rule 24): us per time step, median and min over the rounds, plus the
+largest difference of every variant's outputs from variant 0's (the variants are the same arithmetic: expected 0
+or rounding-order level).
+
+    python tools/lstm_bench.py [--bf16] [--T 400] [--B 32] [--H 896] [--rounds 7] [--fwd "0,0;1,0;1,2"] [--bwd "0;1"]
+
+--fwd: list of "half,map" (sk_lstm_fwd mode bits 17 and 18..19); --bwd: list of backward variants (mode bits 17..).
+"""
+import argparse
+import os
+import statistics
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sepkern import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--T", type=int, default=400)
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--H", type=int, default=896)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--fwd", default="0,0;1,0;1,1;1,2;0,1")
+    ap.add_argument("--bwd", default="0")
+    ap.add_argument("--ragged", action="store_true")
+    a = ap.parse_args()
+    T, B, H, bf = a.T, a.B, a.H, a.bf16
+    torch.manual_seed(0)
+    gx = torch.randn(T, B, 2, 4 * H, device="cuda") * 0.5
+    whh = torch.randn(2, 4 * H, H, device="cuda") / 30
+    h0, c0 = torch.randn(2, B, H, device="cuda"), torch.randn(2, B, H, device="cuda")
+    lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    if a.ragged:
+        lens[1::3] = max(1, (5 * T) // 6)
+    dy = torch.randn(T, B, 2 * H, device="cuda")
+    fwd_vars = [tuple(int(v) for v in s.split(",")) for s in a.fwd.split(";") if s]
+    bwd_vars = [int(s) for s in a.bwd.split(";") if s != ""]
+
+    def run_fwd(var):
+        g = gx.clone()
+        y, cs = torch.empty(T, B, 2 * H, device="cuda"), torch.empty(T, B, 2, H, device="cuda")
+        hn, cn = torch.empty(2, B, H, device="cuda"), torch.empty(2, B, H, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, hn, cn, T, B, H, 1, bf16=bf, half=bool(var[0]), blockmap=var[1])
+        e1.record()
+        torch.cuda.synchronize()
+        ops.lstm_status(ws)
+        return e0.elapsed_time(e1), (y, g, cs, hn, cn)
+
+    def run_bwd(var, saved):
+        y, g, cs, hn, cn = saved
+        gg = g.clone()
+        dh0, dc0 = torch.empty(2, B, H, device="cuda"), torch.empty(2, B, H, device="cuda")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, lens, gg, dh0, dc0, T, B, H, 1 | (var << 17), bf16=bf)
+        e1.record()
+        torch.cuda.synchronize()
+        ops.lstm_status(ws)
+        return e0.elapsed_time(e1), (gg, dh0, dc0)
+
+    ref_f = ref_b = None
+    tf = {v: [] for v in fwd_vars}
+    tb = {v: [] for v in bwd_vars}
+    df = {v: 0.0 for v in fwd_vars}
+    db = {v: 0.0 for v in bwd_vars}
+    for r in range(a.rounds + 1):
+        for v in fwd_vars:
+            ms, out = run_fwd(v)
+            if ref_f is None:
+                ref_f = out
+            df[v] = max(df[v], max(float((x - y).abs().max()) for x, y in zip(out, ref_f)))
+            if r:
+                tf[v].append(ms)
+        for v in bwd_vars:
+            ms, out = run_bwd(v, ref_f)
+            if ref_b is None:
+                ref_b = out
+            db[v] = max(db[v], max(float((x - y).abs().max()) for x, y in zip(out, ref_b)))
+            if r:
+                tb[v].append(ms)
+    print("BLSTM recurrence, T=%d B=%d H=%d %s%s: us per step (median / min over %d rounds), max |diff| vs first variant"
+          % (T, B, H, "bf16" if bf else "fp32", " ragged" if a.ragged else "", a.rounds))
+    for v in fwd_vars:
+        print("  fwd half=%d map=%d : %7.3f / %7.3f   diff %.3g" % (v[0], v[1], 1e3 * statistics.median(tf[v]) / T,
+                                                                  1e3 * min(tf[v]) / T, df[v]))
+    for v in bwd_vars:
+        print("  bwd variant %d     : %7.3f / %7.3f   diff %.3g" % (v, 1e3 * statistics.median(tb[v]) / T,
+                                                                  1e3 * min(tb[v]) / T, db[v]))
+
+
+if __name__ == "__main__":
+    main()
