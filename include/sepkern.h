@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 100
+#define SK_VERSION 101
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -122,18 +122,22 @@ int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const flo
                 int T, int B, int H, int mode, sk_stream_t stream);
 /* Same, with the gradient wrt the final state (dhn, dcn: (2,B,H), either may be NULL = 0) as an extra input:
  * needed when hn/cn feed a later computation (the RSH arch carries the hidden state from pass to pass,
- * reference archs/RSH.py:172). */
+ * reference archs/RSH.py:172), and two optional by-products that spare the caller a pass over dgx each:
+ *   dbias    (ceil(B/16), 2, 4H)  partial sums of dG over (t, b), one row per 16-row batch group block of the
+ *            grid (unused rows are 0): their column sum is the gradient of b_ih and of b_hh;
+ *   dg_first (2, B, 4H)  dG of every row's FIRST recurrent step -- forward direction t = 0, reverse direction
+ *            t = lens[b]-1 -- the only steps whose recurrent input is h0 instead of a stored output:
+ *            dW_hh[d] = dgx[1:, :, d]^T y[:-1, :, d-half]  (time-shifted, d = 0; mirrored for d = 1)
+ *                     + dg_first[d]^T h0[d]. */
 int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
                       const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
-                      void* ws, int T, int B, int H, int mode, sk_stream_t stream);
-/* After a persistent launch has completed: 0, or SK_ETIMEOUT if a bounded spin gave up
- * (reads one word of the workspace back to the host; synchronises the stream). */
-int sk_lstm_status(const void* ws, sk_stream_t stream);
-/* dW_hh += sum_t dgx_t^T h_{t-1}: fills hprev (T,B,2,H) with the recurrent input of every step
- * (h0 at a row's first step, the previous output otherwise, 0 at padded positions). */
-int sk_lstm_hprev(const float* y, const float* h0, const int32_t* lens, float* hprev,
-                  int T, int B, int H, sk_stream_t stream);
-
+                      float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, sk_stream_t stream);
+/* Word 0 of the workspace is a STICKY status word: a launch whose bounded spin gave up sets it (no launch clears
+ * it; allocate the workspace zeroed).  Its address can be handed to sk_grad_norm as `guard` (as a float: any
+ * non-zero bit pattern counts) so that a failed launch never reaches the weights, without a host sync per step.
+ * sk_lstm_status: 0, or SK_ETIMEOUT if a launch since the last call timed out (reads the word back to the host,
+ * synchronises the stream, clears the word). */
+int sk_lstm_status(void* ws, sk_stream_t stream);
 /* ---------------------------------------------------------------- BatchNorm1d over (rows, C)
  * Replaces nn.BatchNorm1d(2H) on (B, 2H, T) (reference archs/uPIT.py:119,138): statistics over
  * ALL rows = B*T_max positions, zero-padded frames included.
@@ -203,10 +207,15 @@ int sk_att_update_bwd(const float* dx_out, const float* x_out, float* dx_in, flo
 /* ---------------------------------------------------------------- clip_grad_norm_ + Adam
  * Replaces torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step()
  * (reference steps/train_qsub.py:121-122) on ONE flat fp32 buffer holding every parameter.
- *   scal[0] = total grad L2 norm, scal[1] = clip coefficient min(1, max_norm/(norm+1e-6))
+ *   scal[0] = total grad L2 norm, scal[1] = clip coefficient min(1, max_norm/(norm+1e-6)),
+ *   scal[2] = 1 when this step is skipped, scal[3] = count of skipped steps (caller zeroes scal once).
+ * guard (may be NULL): device float; non-zero means "the gradients of this step are not to be trusted" (a
+ * persistent recurrence launch timed out, on this rank or -- summed by the data-parallel all-reduce -- on any
+ * rank): sk_clip_adam then leaves parameters and moments untouched.
  * step is the 1-based Adam step count. ws >= sk_optim_workspace_bytes(n). */
 size_t sk_optim_workspace_bytes(int64_t n);
-int sk_grad_norm(const float* g, int64_t n, float max_norm, float* scal, void* ws, sk_stream_t stream);
+int sk_grad_norm(const float* g, int64_t n, float max_norm, const float* guard, float* scal, void* ws,
+                 sk_stream_t stream);
 int sk_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* scal,
                  float lr, float beta1, float beta2, float eps, int step, sk_stream_t stream);
 

@@ -118,6 +118,11 @@ class TrainSet(Dataset):
   def __len__(self):
     return len(self.list)
 
+  def frame_counts(self):
+    """Frames per utterance, from the npz headers only (length-balanced sharding across GPUs)."""
+    from sepkern.data import npz_frames
+    return [npz_frames(path) for path in self.list]
+
   def __getitem__(self, idx):
     feat = np.load(self.list[idx])
     mix_mag_spec = feat['mix'].transpose()
@@ -268,9 +273,11 @@ def compute_loss(model, epoch, batch_sample, plotdir=""):
 
 
 # define test pass
-def compute_masks(model, batch_sample, out_dir):
+def estimate_masks(model, batch_sample):
+  """The arithmetic half of compute_masks: [(file name, {'s1': (257,T_i) float32, ...}), ...] for one batch."""
   dev = model.lin.weight.device
   model.zero_grad()
+  out = []
 
   for num_spk in range(batch_sample.max_spk):
     if batch_sample.sub_batch_lens[num_spk] > 0:
@@ -287,5 +294,10 @@ def compute_masks(model, batch_sample, out_dir):
           mask_np = mask_out.permute(1, 0, 2).cpu().numpy()
           for i in range(batch):
             dicts[i]['s' + str(dnn_pass + 1)] = mask_np[i].transpose()[:, 0:lens_h[i]]
-      for i in range(batch):
-        np.savez_compressed(out_dir + '/' + name[i], **(dicts[i]))
+      out += [(name[i], dicts[i]) for i in range(batch)]
+  return out
+
+
+def compute_masks(model, batch_sample, out_dir):
+  for name, file_dict in estimate_masks(model, batch_sample):
+    np.savez_compressed(out_dir + '/' + name, **file_dict)

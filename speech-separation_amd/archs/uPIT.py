@@ -104,6 +104,11 @@ class TrainSet(Dataset):
   def __len__(self):
     return len(self.list)
 
+  def frame_counts(self):
+    """Frames per utterance, from the npz headers only (length-balanced sharding across GPUs)."""
+    from sepkern.data import npz_frames
+    return [npz_frames(path) for path in self.list]
+
   def __getitem__(self, idx):
     feat = np.load(self.list[idx])
     mix_mag_spec = feat['mix'].transpose()
@@ -147,6 +152,10 @@ class WavTrainSet(Dataset):
 
   def __len__(self):
     return len(self.items)
+
+  def frame_counts(self):
+    from sepkern.data import wav_frames
+    return [wav_frames(files[0]) for files in self.items]
 
   def __getitem__(self, idx):
     import scipy.io.wavfile
@@ -284,7 +293,9 @@ def compute_loss(model, epoch, batch_sample, plotdir=""):
 
 
 # define test pass
-def compute_masks(model, batch_sample, out_dir):
+def estimate_masks(model, batch_sample):
+  """The arithmetic half of compute_masks: [(file name, {'s1': (257,T_i) float32, ...}), ...] for one batch, without
+  touching the disk (steps/eval_qsub.py overlaps the zlib compression of one batch with the next batch's GPU work)."""
   dev = model.lin.weight.device
   mix, lens = _to_padded(batch_sample['mix'], dev)
   name = batch_sample['name']
@@ -297,9 +308,16 @@ def compute_masks(model, batch_sample, out_dir):
     mask_out = model.forward_padded(mix, lens).permute(1, 0, 2)
   mask_np = mask_out.cpu().numpy()
   lens = lens.cpu().numpy()
+  out = []
   for i in range(len(name)):
     mask = mask_np[i].transpose()[:, 0:lens[i]]
     file_dict = dict()
     for src in range(model.num_spk):
       file_dict['s' + str(src + 1)] = mask[src * model.feat_dim:(src + 1) * model.feat_dim]
-    np.savez_compressed(out_dir + '/' + name[i], **file_dict)
+    out.append((name[i], file_dict))
+  return out
+
+
+def compute_masks(model, batch_sample, out_dir):
+  for name, file_dict in estimate_masks(model, batch_sample):
+    np.savez_compressed(out_dir + '/' + name, **file_dict)

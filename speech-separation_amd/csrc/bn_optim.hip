@@ -121,8 +121,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
+// scal[0] = total norm, scal[1] = clip coefficient, scal[2] = 1 if this step is to be SKIPPED, scal[3] = number of
+// skipped steps so far.  guard (may be NULL): a device word that is non-zero when the gradients of this step cannot be
+// trusted (a persistent recurrence launch timed out on some rank: sepkern/engine.py puts the LSTM workspace's sticky
+// status word behind the flat gradient, where the data-parallel all-reduce sums it over the ranks).
 __global__ __launch_bounds__(256) void norm_fin_kernel(const float* __restrict__ part, int nb, float max_norm,
-                                                       float* __restrict__ scal) {
+                                                       const float* __restrict__ guard, float* __restrict__ scal) {
   __shared__ float red[4];
   float a = 0.f;
   for (int i = threadIdx.x; i < nb; i += 256) a += part[i];
@@ -130,8 +134,11 @@ __global__ __launch_bounds__(256) void norm_fin_kernel(const float* __restrict__
   if (threadIdx.x == 0) {
     const float norm = sqrtf(s);
     const float coef = max_norm / (norm + 1e-6f);
+    const bool skip = guard && guard[0] != 0.f;
     scal[0] = norm;
     scal[1] = coef < 1.0f ? coef : 1.0f;
+    scal[2] = skip ? 1.f : 0.f;
+    if (skip) scal[3] += 1.f;
   }
 }
 
@@ -139,6 +146,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                         const float* __restrict__ scal, float lr, float beta1,
                                                         float beta2, float eps, float bc1, float bc2_sqrt) {
+  if (scal[2] != 0.f) return;  // untrusted gradients never reach the weights or the moments (grid-uniform)
   const float coef = scal[1];
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -271,12 +279,13 @@ extern "C" size_t sk_optim_workspace_bytes(int64_t n) {
   return sk_align(NORM_BLOCKS * sizeof(float), 256);
 }
 
-extern "C" int sk_grad_norm(const float* g, int64_t n, float max_norm, float* scal, void* ws, sk_stream_t stream) {
+extern "C" int sk_grad_norm(const float* g, int64_t n, float max_norm, const float* guard, float* scal, void* ws,
+                            sk_stream_t stream) {
   SK_CHECK_ARG(g && scal && ws && n > 0, "sk_grad_norm: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)(sk_cdiv(n, 256) < NORM_BLOCKS ? sk_cdiv(n, 256) : NORM_BLOCKS);
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, st, g, n, (float*)ws);
-  hipLaunchKernelGGL(norm_fin_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nb, max_norm, scal);
+  hipLaunchKernelGGL(norm_fin_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, nb, max_norm, guard, scal);
   SK_CHECK_LAUNCH("sk_grad_norm");
   return SK_OK;
 }

@@ -51,6 +51,7 @@ __device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((
 
 constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 constexpr int NTHREADS = 512;
+constexpr int NREP = 8;  // flag replicas (one per XCD label) when replication is on
 
 #define SK_RLX __ATOMIC_RELAXED
 #define SK_AGENT __HIP_MEMORY_SCOPE_AGENT
@@ -58,7 +59,7 @@ constexpr int NTHREADS = 512;
 #define SK_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 struct WsLayout {
-  size_t ctrl, flags, xbuf, state, total;
+  size_t sticky, ctrl, flags, xbuf, state, total;
   int KS, NBG;
 };
 
@@ -75,9 +76,10 @@ inline WsLayout ws_layout(int B, int H, bool bf = false) {
   w.KS = pick_ks(H, bf);
   w.NBG = (B + 15) / 16;
   const size_t Hp = 16 * (size_t)w.KS;
-  w.ctrl = 0;
-  w.flags = 256;
-  const size_t nflags = 2 * (size_t)w.NBG * 2 * w.KS;  // up to 2 KS unit groups (8-unit workgroups)
+  w.sticky = 0;  // word 0: set by any launch whose bounded wait gave up; cleared only by sk_lstm_status
+  w.ctrl = 256;  // per-launch status word (+ diagnostic stamps); zeroed with the flags by every call
+  w.flags = 512;
+  const size_t nflags = NREP * 2 * (size_t)w.NBG * 2 * w.KS;  // up to 2 KS unit groups, NREP replicas
   w.xbuf = w.flags + sk_align(nflags * 4, 256);
   const size_t xbytes = 2 * 2 * (size_t)w.NBG * Hp * 64 * 4;  // backward exchange is the larger one
   w.state = w.xbuf + sk_align(xbytes, 256);
@@ -101,8 +103,10 @@ struct FwdArgs {
   float* state;
   unsigned* flags;
   unsigned* ctrl;
+  unsigned* sticky;
   int T, B, H, NBG, G, s_begin, s_end;
   int map, nby;  // block id -> (unit group, batch-group block, direction) assignment (speed only), grid y extent
+  int opt;       // bit 0: one polling wave per workgroup; bit 1: flags replicated per XCD label
 };
 
 struct BwdArgs {
@@ -117,12 +121,27 @@ struct BwdArgs {
   float* dc0;
   const float* dhn;  // gradient wrt the final state (2,B,H), may be NULL (= 0)
   const float* dcn;
+  float* dbias;      // (grid y, 2, 4H) per-workgroup-row partial sums of dG over (t, b), may be NULL
   float* xbuf;
   float* state;
   unsigned* flags;
   unsigned* ctrl;
+  unsigned* sticky;
   int T, B, H, NBG, G, s_begin, s_end, final_mm;
+  int map, nby;
 };
+
+// Flag replication (opt bit 1): every producer raises its flag in NREP copies with ONE store instruction (NREP lanes,
+// NREP different lines) and a consumer polls the copy selected by its XCD id, so that the pollers of a stream
+// are spread over NREP memory channels instead of hammering one or two lines.  Which copy a consumer reads is
+// irrelevant for correctness (all copies are written behind the same drain + barrier).
+__device__ __forceinline__ int flag_replica(int opt) {
+  return (opt & 2) ? (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) : 0;  // HW_REG_XCC_ID[3:0]
+}
+__device__ __forceinline__ void raise_flag(unsigned* flags0, size_t rep_stride, int opt, int tid, unsigned value) {
+  const int n = (opt & 2) ? NREP : 1;
+  if (tid < n) __hip_atomic_store(flags0 + (size_t)tid * rep_stride, value, SK_RLX, SK_AGENT);
+}
 
 // Wave 0 waits until every flag of its (direction, batch group) has reached `target`.
 __device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigned target, unsigned* ctrl, int lane) {
@@ -134,7 +153,10 @@ __device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigne
     if ((it & 63u) == 63u) {
       if (__hip_atomic_load(ctrl, SK_RLX, SK_AGENT) != 0u) return false;  // another workgroup gave up
       if (wall_clock64() - t0 > SPIN_TICKS) {
-        if (lane == 0) __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
+        if (lane == 0) {
+          __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
+          __hip_atomic_store(ctrl - 64, 1u, SK_RLX, SK_AGENT);  // the sticky word (workspace word 0), see ws_layout
+        }
         return false;
       }
     }
@@ -151,7 +173,10 @@ __device__ __forceinline__ bool wait_flags_sel(const unsigned* flags, int idx, u
     if ((it & 63u) == 63u) {
       if (__hip_atomic_load(ctrl, SK_RLX, SK_AGENT) != 0u) return false;  // another workgroup gave up
       if (wall_clock64() - t0 > SPIN_TICKS) {
-        if (lane == 0) __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
+        if (lane == 0) {
+          __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
+          __hip_atomic_store(ctrl - 64, 1u, SK_RLX, SK_AGENT);  // the sticky word (workspace word 0), see ws_layout
+        }
         return false;
       }
     }
@@ -335,7 +360,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       const int len_b = (b < B) ? a.lens[b] : 0;
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
-      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * NUG;
+      const size_t rep_stride = (size_t)2 * NBG * NUG;
+      unsigned* const flags0 = a.flags + (size_t)(dir * NBG + bg) * NUG;  // replica 0 of this stream's flags
+      const unsigned* const myflags = flags0 + (size_t)flag_replica(a.opt) * rep_stride;
       SK_STAMP(7);
       // 1. this step's input-projection terms (independent of the recurrence: issue early)
       float gxv[4] = {0.f, 0.f, 0.f, 0.f};
@@ -349,6 +376,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       // barrier in between.  fp32: all 8 waves pull (56 pieces); bf16 (28 pieces, latency-bound): only the four
       // waves that own no cells, so nothing of the hand-off queues behind the owners' bulk stores (measured:
       // the split costs 2 % in fp32 and gains 1.5 % in bf16).
+      if ((a.opt & 1) && s > a.s_begin && s > 0) {
+        // option: ONE polling wave per workgroup (8x fewer pollers on the flag lines, one more barrier)
+        if (w == 0 && !wait_flags(myflags, NUG, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
+        __syncthreads();
+      }
       if (s == 0) {
         if (BF) {
           for (int i = tid; i < 16 * (HP / 8); i += NT) {
@@ -376,10 +408,14 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         const int wq = BF ? w - NW / 2 : w;
         bool ok = true;
         if (s > a.s_begin) {
-          const int piece = wq + NCW * (lane / PP);
-          const int idx = (lane < PP * ((NCH + NCW - 1) / NCW) && piece < NCH) ? piece * PP + lane % PP : -1;
-          ok = wait_flags_sel(myflags, idx, (unsigned)s, a.ctrl, lane);
-          if (!ok && lane == 0) s_abort = 1;
+          if (a.opt & 1) {
+            ok = !s_abort;  // wave 0 polled for the workgroup (above)
+          } else {
+            const int piece = wq + NCW * (lane / PP);
+            const int idx = (lane < PP * ((NCH + NCW - 1) / NCW) && piece < NCH) ? piece * PP + lane % PP : -1;
+            ok = wait_flags_sel(myflags, idx, (unsigned)s, a.ctrl, lane);
+            if (!ok && lane == 0) s_abort = 1;
+          }
         }
         if (ok) {
           const float* src = ((s - 1) & 1) ? xb1 : xb0;
@@ -466,7 +502,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         c_out = c_new;
       }
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+      raise_flag(flags0 + ug, rep_stride, a.opt, tid, (unsigned)(s + 1));
       // 7. ... then the bulk stores of the step, off the critical path
       if (cellok) {
         a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = y_out;
@@ -602,6 +638,9 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
   return v;
 }
 
+// Keep this kernel at 192 VGPRs or fewer (bias-gradient sums live in LDS for that reason): two waves per SIMD then leave 128 registers per lane for ONE co-resident GEMM wave (the
+// weight-gradient GEMMs of the layer above run next to this recurrence on the same CUs, sepkern/engine.py); at 200+
+// no GEMM block fits beside it and the co-scheduling is lost (measured: 39.3 -> 40.9 ms per step).
 template <int KS, bool BF>
 __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   using C = BwdCfg<KS, BF>;
@@ -609,9 +648,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float ring_all[8][C::DEPTH * C::SB * 256];
   __shared__ float red[8][16][17];
   __shared__ float st_carry[GMAX][256], st_dc[GMAX][256];  // per-group recurrent state of the owner lanes
+  __shared__ __attribute__((aligned(16))) float st_db[256][4];  // owner lanes: running sum of their cells' dG (bias gradient)
   __shared__ int s_abort;
 
-  const int ug = blockIdx.x, by = blockIdx.y, dir = blockIdx.z;
+  int ug, by, dir;
+  decode_block((int)blockIdx.x, KS, a.nby, a.map, ug, by, dir);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int T = a.T, B = a.B, H = a.H, NBG = a.NBG, G = a.G;
   float* const ring = &ring_all[w][0];
@@ -647,7 +688,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   const int oi = (w & 3) * 64 + lane;
   const size_t xblk = (size_t)HP * 64;  // floats per (parity, dir, batch group) exchange block
   // image position of k' = 4*unit + 0..3, row bl: fp32 floats / bf16 elements (chunk unit>>3, octet (unit&7)>>1)
-  const size_t xoff = BF ? (size_t)bf_img(4 * unit, bl) : ((size_t)unit * 16 + bl) * 4;
+  const unsigned xoff = BF ? (unsigned)bf_img(4 * unit, bl) : (unsigned)(unit * 16 + bl) * 4u;
   const size_t st2 = (size_t)2 * NBG * 16 * HP;
 
   // carry = gradient wrt h that passes straight through a frozen (padded) step
@@ -673,6 +714,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   __syncthreads();
   SK_STAMP_DECL
 
+  if (owner) *reinterpret_cast<f32x4*>(&st_db[oi][0]) = f32x4{0.f, 0.f, 0.f, 0.f};  // read and written by the same lane only
   bool aborted = false;
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
@@ -734,6 +776,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
           dpre[3] = dout * go * (1.0f - go);
           dc_rec = dc * gf;
           carry = 0.f;
+          if (a.dbias) *reinterpret_cast<f32x4*>(&st_db[oi][0]) += dpre;
         } else {
           carry = dh_rec;  // frozen step: h_t = h_{t-1}
         }
@@ -769,6 +812,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   SK_STAMP_FLUSH(a.ctrl);
 
   if (aborted) return;
+  if (a.dbias && owner) {
+    // bias gradient: sum of this workgroup's dG over its batch rows (16 lanes of a unit, fixed order) -- one
+    // partial row per grid-y block; the buffer is zeroed by the host, step launches (mode 2) add to it
+    f32x4 dbsum = *reinterpret_cast<const f32x4*>(&st_db[oi][0]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float v = dbsum[r];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      dbsum[r] = v;
+    }
+    if (bl == 0 && unit < H) {
+      float* dbp = a.dbias + ((size_t)by * 2 + dir) * 4 * H + unit;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dbp[(size_t)r * H] += dbsum[r];
+    }
+  }
   for (int gi = 0; gi < G; ++gi) {
     const int bg = by * G + gi;
     if (bg >= NBG) break;
@@ -778,7 +840,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       // gradient wrt the initial state: one more product with the last published dG (s_end == T)
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
-      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+      const unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
       if (T > a.s_begin && w == 0) {
         if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane) && lane == 0) s_abort = 1;
       }
@@ -799,25 +861,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
 }
 
 
-// hprev[t][b][dir][:] = recurrent input of step (t, dir) for row b (see sk_lstm_hprev)
-__global__ __launch_bounds__(256) void hprev_kernel(const float* __restrict__ y, const float* __restrict__ h0,
-                                                    const int* __restrict__ lens, float* __restrict__ hprev, int T,
-                                                    int B, int H) {
-  const int64_t row = blockIdx.x;  // (t*B + b)*2 + dir
-  const int dir = (int)(row & 1);
-  const int64_t tb = row >> 1;
-  const int b = (int)(tb % B), t = (int)(tb / B);
+// dg_first[dir][b][:] = dgx[t0][b][dir][:] with t0 = 0 (forward) / lens[b]-1 (reverse): the dG of the one step of every
+// row whose recurrent input is h0 rather than a stored output (its term of dW_hh pairs with h0).  2B rows of 4H floats.
+__global__ __launch_bounds__(256) void first_dg_kernel(const float* __restrict__ dgx, const int* __restrict__ lens,
+                                                       float* __restrict__ out, int T, int B, int H) {
+  const int b = blockIdx.x % B, dir = blockIdx.x / B;
   const int len = lens[b];
-  for (int k = threadIdx.x; k < H; k += 256) {
-    float v = 0.f;
-    if (t < len) {
-      if (dir == 0)
-        v = t > 0 ? y[((int64_t)(t - 1) * B + b) * 2 * H + k] : h0[(int64_t)b * H + k];
-      else
-        v = (t + 1 < len) ? y[((int64_t)(t + 1) * B + b) * 2 * H + H + k] : h0[((int64_t)B + b) * H + k];
-    }
-    hprev[row * H + k] = v;
-  }
+  const int t0 = dir ? (len < 1 ? 0 : (len > T ? T : len) - 1) : 0;
+  const float4* src = reinterpret_cast<const float4*>(dgx + (((size_t)t0 * B + b) * 2 + dir) * 4 * H);
+  float4* dst = reinterpret_cast<float4*>(out + ((size_t)dir * B + b) * 4 * H);
+  const bool live = len >= 1;
+  for (int i = threadIdx.x; i < H; i += 256) dst[i] = live ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 template <int KS, bool BF>
@@ -830,7 +884,7 @@ int launch_fwd(const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
 }
 template <int KS, bool BF>
 int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF>), grid, dim3(NTHREADS), 0, st, a);
+  hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
   return 0;
 }
 
@@ -886,7 +940,7 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 20) == 0,
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 22) == 0,
                "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
@@ -912,6 +966,7 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   const bool bf = (mode >> 16) & 1;     // bit 16: bf16 matrix-core inputs
   const bool half = (mode >> 17) & 1;   // bit 17: 8-unit, 256-thread workgroups, two per CU
   const int map = (mode >> 18) & 3;     // bits 18..19: block id -> stream assignment (speed only)
+  const int opt = (mode >> 20) & 3;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -927,10 +982,10 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   const bool fits = G > 0;
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
-  a.map = map; a.nby = nby;
+  a.map = map; a.nby = nby; a.opt = opt;
   const int nblocks = NUG * nby * 2;
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
-  SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));  // status word + flags
+  SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));  // per-launch status word + flags (not the sticky word)
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T;
     dispatch_fwd(L.KS, bf, a, half, nblocks, st);
@@ -947,17 +1002,20 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
 extern "C" int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs, const float* c0,
                            const int32_t* lens, float* dgx, float* dh0, float* dc0, void* ws, int T, int B, int H,
                            int mode, sk_stream_t stream) {
-  return sk_lstm_bwd_state(dy, nullptr, nullptr, whh, gates, cs, c0, lens, dgx, dh0, dc0, ws, T, B, H, mode, stream);
+  return sk_lstm_bwd_state(dy, nullptr, nullptr, whh, gates, cs, c0, lens, dgx, dh0, dc0, nullptr, nullptr, ws, T, B, H,
+                           mode, stream);
 }
 
 extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const float* whh,
                                  const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
-                                 float* dh0, float* dc0, void* ws, int T, int B, int H, int mode, sk_stream_t stream) {
+                                 float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
+                                 int mode, sk_stream_t stream) {
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
   if (rc) return rc;
   const int gmin = (mode >> 8) & 0xff;
   const bool bf = (mode >> 16) & 1;
+  const int map = (mode >> 18) & 3;  // as sk_lstm_fwd; flag replication was measured here too (7.59 -> 7.50 us/step) and not kept
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -965,6 +1023,7 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   BwdArgs a;
   a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens;
   a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0; a.dhn = dhn; a.dcn = dcn;
+  a.dbias = dbias;
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
@@ -973,9 +1032,11 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   const bool fits = G > 0;
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
+  a.map = map; a.nby = nby;
   dim3 grid((unsigned)L.KS, (unsigned)nby, 2);
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_bwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
-  SK_CHECK_HIP(hipMemsetAsync(base, 0, L.xbuf, st));
+  SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));
+  if (dbias) SK_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)L.NBG * 8 * H * sizeof(float), st));  // rows >= grid y stay 0
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;
     dispatch_bwd(L.KS, bf, a, grid, st);
@@ -990,24 +1051,20 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
       dispatch_bwd(L.KS, bf, a, grid, st);
     }
   }
+  if (dg_first) hipLaunchKernelGGL(first_dg_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, st, dgx, lens, dg_first, T, B, H);
   SK_CHECK_LAUNCH("sk_lstm_bwd");
   return SK_OK;
 }
 
-extern "C" int sk_lstm_status(const void* ws, sk_stream_t stream) {
+extern "C" int sk_lstm_status(void* ws, sk_stream_t stream) {
   SK_CHECK_ARG(ws, "sk_lstm_status: null workspace");
   unsigned v = 0;
   SK_CHECK_HIP(hipMemcpyAsync(&v, ws, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
   SK_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
-  if (v != 0) return sk_fail(SK_ETIMEOUT, "sk_lstm: a workgroup's bounded wait timed out (grid not co-resident?)");
-  return SK_OK;
-}
-
-extern "C" int sk_lstm_hprev(const float* y, const float* h0, const int32_t* lens, float* hprev, int T, int B, int H,
-                             sk_stream_t stream) {
-  SK_CHECK_ARG(y && h0 && lens && hprev && T > 0 && B > 0 && H > 0, "sk_lstm_hprev: bad arguments");
-  hipLaunchKernelGGL(hprev_kernel, dim3((unsigned)((int64_t)T * B * 2)), dim3(256), 0, (hipStream_t)stream, y, h0, lens,
-                     hprev, T, B, H);
-  SK_CHECK_LAUNCH("sk_lstm_hprev");
+  if (v != 0) {
+    SK_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(v), (hipStream_t)stream));  // reported once
+    return sk_fail(SK_ETIMEOUT, "sk_lstm: a workgroup's bounded wait timed out in a launch since the last check "
+                                "(grid not co-resident?)");
+  }
   return SK_OK;
 }

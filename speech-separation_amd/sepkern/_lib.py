@@ -13,7 +13,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEPKERN_LIB") or os.path.join(_HERE, "libsepkern.so")   # SEPKERN_LIB: diagnostic builds
 
-SK_VERSION = 100
+SK_VERSION = 101
 
 _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -31,9 +31,8 @@ PROTOTYPES = {
     "sk_lstm_workspace_bytes": (_sz, [_i, _i, _i]),
     "sk_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "sk_lstm_bwd_state": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "sk_lstm_bwd_state": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_status": (_i, [_p, _p]),
-    "sk_lstm_hprev": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "sk_bn_workspace_bytes": (_sz, [_i, _i]),
     "sk_bn_stats": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "sk_bn_update_running": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
@@ -52,7 +51,7 @@ PROTOTYPES = {
     "sk_att_update": (_i, [_p, _p, _p, _i64, _i, _i, _p]),
     "sk_att_update_bwd": (_i, [_p, _p, _p, _p, _i64, _i, _i, _p]),
     "sk_optim_workspace_bytes": (_sz, [_i64]),
-    "sk_grad_norm": (_i, [_p, _i64, _f, _p, _p, _p]),
+    "sk_grad_norm": (_i, [_p, _i64, _f, _p, _p, _p, _p]),
     "sk_clip_adam": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _i, _p]),
 }
 

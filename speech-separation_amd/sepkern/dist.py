@@ -97,3 +97,89 @@ def allreduce_bn_sums(dgamma, dbeta):
     if is_parallel():
         dist.all_reduce(both)
     return both[0].contiguous(), both[1].contiguous()
+
+
+# ----------------------------------------------------------------------------- replicas start identical
+def broadcast_model(model, src=0):
+    """Make every rank's replica bit-identical to rank `src`'s: parameters (the engine's flat buffer when the model
+    has one, else every parameter) and all buffers (BatchNorm running statistics, num_batches_tracked).  The
+    reference has one process and therefore no such step; without it ranks that drew their initial weights from
+    unseeded RNGs would apply the summed gradients to different parameters for ever."""
+    if not is_parallel():
+        return
+    flat = getattr(model, "flat_parameters", None)
+    if flat is not None:
+        dist.broadcast(flat()[0], src)
+    else:
+        for p in model.parameters():
+            dist.broadcast(p.data, src)
+    for b in model.buffers():
+        dist.broadcast(b, src)
+
+
+# ----------------------------------------------------------------------------- who trains on what, per epoch
+def balanced_deal(indices, lengths, world_):
+    """Deal the utterances of ONE global batch to `world_` ranks: equal counts (+-1) and near-equal total frames, so
+    that no rank's recurrence runs much longer than the others' (the slowest rank sets the step).  Longest first,
+    in boustrophedon order (0..W-1, W-1..0, ...).  Returns a list of `world_` index lists."""
+    order = sorted(indices, key=lambda i: (-lengths[i], i)) if lengths is not None else list(indices)
+    out = [[] for _ in range(world_)]
+    for k, i in enumerate(order):
+        lap, pos = divmod(k, world_)
+        out[pos if lap % 2 == 0 else world_ - 1 - pos].append(i)
+    return out
+
+
+class EpochShards:
+    """A batch sampler for torch's DataLoader: the batches of THIS rank for one epoch of data-parallel training.
+
+    Every epoch draws one permutation of the whole set from (seed, epoch) -- identical on all ranks --, cuts it into
+    global batches of world * batch_size utterances and deals each to the ranks with balanced_deal().  Every rank
+    therefore runs the SAME number of steps (the collectives inside a step always match), every utterance is used
+    once per epoch, and ranks exchange utterances from epoch to epoch.  A last global batch with fewer than `world`
+    utterances is topped up from the start of the permutation so that no rank is left without data (as torch's
+    DistributedSampler pads)."""
+
+    def __init__(self, n, batch_size, rank_, world_, lengths=None, seed=0, shuffle=True):
+        if n <= 0 or batch_size <= 0 or not 0 <= rank_ < world_:
+            raise ValueError("EpochShards: bad arguments")
+        self.n, self.bs, self.rank, self.world = int(n), int(batch_size), int(rank_), int(world_)
+        self.lengths = None if lengths is None else [int(v) for v in lengths]
+        if self.lengths is not None and len(self.lengths) != self.n:
+            raise ValueError("EpochShards: one length per utterance expected")
+        self.seed, self.shuffle, self.epoch = int(seed), bool(shuffle), 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        g = self.bs * self.world
+        return (self.n + g - 1) // g
+
+    def global_batches(self):
+        if self.shuffle:
+            gen = torch.Generator()
+            gen.manual_seed(self.seed * 1000003 + self.epoch)
+            perm = torch.randperm(self.n, generator=gen).tolist()
+        else:
+            perm = list(range(self.n))
+        g = self.bs * self.world
+        for k in range(len(self)):
+            chunk = perm[k * g:(k + 1) * g]
+            j = 0
+            while len(chunk) < self.world:          # fewer utterances than ranks: top up (wraps around)
+                chunk.append(perm[j % self.n])
+                j += 1
+            yield chunk
+
+    def __iter__(self):
+        for chunk in self.global_batches():
+            yield balanced_deal(chunk, self.lengths, self.world)[self.rank]
+
+
+def shard_indices_contiguous(n, rank_, world_):
+    """Evaluation sets (no collective inside the pass): a contiguous shard per rank, sizes differing by at most 1;
+    empty when there are more ranks than utterances."""
+    lo = (n * rank_) // world_
+    hi = (n * (rank_ + 1)) // world_
+    return list(range(lo, hi))

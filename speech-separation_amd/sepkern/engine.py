@@ -80,15 +80,24 @@ class Engine:
         self.layout = ParamLayout(in_dim, out_dim, hidden, layers)
         self.device = device
         self.flat = torch.zeros(self.layout.total, device=device)
-        self.grad = torch.zeros(self.layout.total, device=device)
+        # gradients + one trailing word: the recurrence's sticky status (sepkern/ops.lstm_sticky) is copied there at the
+        # end of every backward, so the data-parallel all-reduce of the buffer tells EVERY rank when any rank's
+        # persistent launch timed out, and the fused clip+Adam skips that step on the device (no host sync per step)
+        self.grad_full = torch.zeros(self.layout.total + 4, device=device)
+        self.grad = self.grad_full[:self.layout.total]
+        self.guard = self.grad_full[self.layout.total:self.layout.total + 1]
         self.running_mean = torch.zeros(2 * hidden, device=device)
         self.running_var = torch.ones(2 * hidden, device=device)
         self.eps, self.momentum = 1e-5, 0.1
         self.lstm_mode = int(os.environ.get("SEPKERN_LSTM_MODE", "0"))
         # forward recurrence geometry (speed only): "half,map" -- half=1: 8-unit / 256-thread workgroups, two per CU;
         # map 0..2: block id -> stream assignment (csrc/lstm.hip::decode_block)
-        fv = os.environ.get("SEPKERN_LSTM_FWD", "0,0").split(",")
-        self.fwd_half, self.fwd_map = bool(int(fv[0])), int(fv[1]) if len(fv) > 1 else 0
+        def variant(env, default):
+            v = [int(x) for x in os.environ.get(env, default).split(",")]
+            v += [0] * (4 - len(v))
+            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]))
+        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0")      # "half,map,poll1,repflags" (r02: 7.33 -> 6.67 us/step)
+        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0")      # (r02: 8.00 -> 7.59 us/step)
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one.
         # SEPKERN_OVERLAP=2 (default): the recurrence keeps its one-workgroup-per-CU grid and the GEMM blocks
         # become CO-RESIDENT on its CUs -- a persistent workgroup leaves >=124 VGPRs per SIMD lane and >=69 KB of
@@ -100,7 +109,6 @@ class Engine:
         self.overlap = self.overlap_mode in (1, 2)
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
-        self._calls = 0
 
     def p(self, name):
         return self.layout.view(self.flat, name)
@@ -112,11 +120,10 @@ class Engine:
         """model.zero_grad(): the next backward overwrites every gradient element, so nothing is memset."""
         self.grads_fresh = True
 
-    def _check_status(self, ws):
-        # a timed-out persistent launch leaves garbage: surface it (synchronises, so not every call)
-        self._calls += 1
-        if self._calls <= 4 or self._calls % 64 == 0 or os.environ.get("SEPKERN_CHECK") == "1":
-            ops.lstm_status(ws)
+    def check_status(self):
+        """Host-side check (synchronises): raises SepkernError if a persistent recurrence launch timed out since the
+        last check.  Training does not need it per step -- see `guard` -- drivers call it at epoch / checkpoint time."""
+        ops.lstm_status(ops.workspace(0, "lstm"))
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, lens, h0, c0, training, save, want_state=False):
@@ -148,10 +155,11 @@ class Engine:
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
             ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
                               hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
-                              T, B, H, self.lstm_mode, bf16=self.bf16, half=self.fwd_half, blockmap=self.fwd_map)
+                              T, B, H, self.lstm_mode | self.fwd_bits, bf16=self.bf16)
             saved.append((inp, gx, cs, y))
             inp, I = y, 2 * H
-        self._check_status(ws)
+        if not save:
+            ops.lstm_status(ws)          # inference: the caller copies the masks to the host next, a sync costs nothing
         y2d = inp.view(R, 2 * H)
         if training:
             mean = torch.empty(2 * H, device=dev)
@@ -239,12 +247,15 @@ class Engine:
             # with weight-gradient GEMMs in flight on the side stream: SEPKERN_OVERLAP=1 carries 2 batch groups per
             # workgroup (the recurrence on half the CUs, GEMMs on the rest); =2 leaves the recurrence as it is and
             # lets GEMM blocks co-reside on its CUs (it leaves 124 VGPRs per SIMD lane and 69 KB of LDS free)
-            mode = self.lstm_mode | ((2 << 8) if (overlap and self.overlap_mode == 1 and l < L - 1) else 0)
+            mode = self.lstm_mode | self.bwd_bits | ((2 << 8) if (overlap and self.overlap_mode == 1 and l < L - 1) else 0)
             sl = slice(2 * l, 2 * l + 2)
+            nbg = (B + 15) // 16
+            dbias = torch.empty(nbg, 8 * H, device=dev)      # by-products of the recurrence: bias-gradient partials ...
+            dg_first = torch.empty(2, B, 4 * H, device=dev)  # ... and the dG of the steps whose recurrent input is h0
             ws = ops.lstm_bwd(dy, whh, gates, cs, c0[sl], lens, dgx, dh0[sl] if want_dstate else None,
                               dc0[sl] if want_dstate else None, T, B, H, mode,
                               dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None,
-                              bf16=self.bf16)
+                              bf16=self.bf16, dbias=dbias, dg_first=dg_first)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, I, device=dev)
                 ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy_next, R, I, 8 * H, 8 * H, I, I, splitk=0,
@@ -256,24 +267,22 @@ class Engine:
                 stream.wait_stream(main)
             with torch.cuda.stream(stream):
                 tag = "side" if stream is not main else "main"
-                hprev = torch.empty(T, B, 2, H, device=dev)
-                ops.lstm_hprev(y, h0[2 * l:2 * l + 2], lens, hprev, T, B, H)
-                # dW_hh[d] = dgx[:, d]^T hprev[:, d]   (two directions as a batch of 2)
-                ops.gemm(dgx, hprev, self.g("weight_hh_l%d" % l), 4 * H, H, R, 8 * H, 2 * H, H, transA=True,
-                         accumulate=acc, batch=2, sA=4 * H, sB=H, sC=4 * H * H, splitk=0, ws_tag="gemm_" + tag, bf16=self.bf16)
+                # dW_hh[d] = sum_t dG_t^T h_prev(t): the layer output shifted by one step in time (+ the h0 steps)
+                ops.lstm_whh_grad(dgx, y, h0[sl], dg_first, self.g("weight_hh_l%d" % l), T, B, H, accumulate=acc,
+                                  bf16=self.bf16, ws_tag="gemm_" + tag)
                 # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
                 ops.gemm(dgx, inp, self.g("weight_ih_l%d" % l), 8 * H, I, R, 8 * H, I, I, transA=True, accumulate=acc,
                          splitk=0, ws_tag="gemm_" + tag, bf16=self.bf16)
                 db = torch.empty(8 * H, device=dev)
-                ops.colsum(dgx, R, 8 * H, 8 * H, db, ws_tag="bn_" + tag)
+                ops.colsum(dbias, nbg, 8 * H, 8 * H, db, ws_tag="bn_" + tag)       # a few rows: the kernel did the sums
                 put("bias_ih_l%d" % l, db.view(2, 4 * H))
                 put("bias_hh_l%d" % l, db.view(2, 4 * H))
-                keep += [hprev, db, dgx, inp, y]
+                keep += [db, dbias, dg_first, dgx, inp, y]
             if l > 0:
                 dy = dy_next
         if overlap:
             main.wait_stream(self.side)
         del keep
-        self._check_status(ws)
+        self.guard.copy_(ops.lstm_sticky(ws))      # int32 -> float: non-zero = this step's gradients are garbage
         self.grads_fresh = False
         return dx, dh0, dc0

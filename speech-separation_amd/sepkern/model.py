@@ -129,7 +129,12 @@ class SepDNNBase(nn.Module):
     return eng.flat, eng.grad
 
   def _allreduce_grads(self):
-    skdist.allreduce_grads(self._engine.grad)       # one RCCL collective over the whole gradient
+    skdist.allreduce_grads(self._engine.grad_full)  # one RCCL collective: every gradient + the status word
+
+  def check_status(self):
+    """Raise if a persistent recurrence launch timed out since the last check (host sync; epoch / checkpoint time)."""
+    if self._engine is not None:
+      self._engine.check_status()
 
   def init_hidden(self, batch_size):
     """h0, c0 ~ N(0,1), shape (2L, B, H), fresh for every batch (reference archs/uPIT.py:121-127)."""

@@ -66,7 +66,8 @@ def workspace(nbytes, tag="default"):
     key = (torch.cuda.current_device(), tag)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+        # zeroed: the LSTM workspace starts with a sticky status word that no launch clears (include/sepkern.h)
+        ws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
         _WS[key] = ws
     return ws
 
@@ -367,6 +368,11 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
+def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False):
+    """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..21)."""
+    return (0x20000 if half else 0) | ((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) | (0x200000 if repflags else 0)
+
+
 def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0):
     """bf16=True: W_hh and h_{t-1} enter the matrix cores rounded to bf16 (fp32 accumulate, fp32 state).
     half=True: 8-unit / 256-thread workgroups, two per CU (include/sepkern.h, mode bit 17); blockmap 0..2: which
@@ -379,27 +385,54 @@ def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=
     return ws
 
 
-def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=None, dcn=None, bf16=False):
+def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=None, dcn=None, bf16=False,
+             dbias=None, dg_first=None):
+    """dbias ((B+15)//16, 2, 4H) and dg_first (2, B, 4H): optional by-products (include/sepkern.h) from which the
+    caller gets the bias gradients and, with lstm_whh_grad, dW_hh without another pass over dgx."""
     ws = lstm_ws(T, B, H)
     mode = int(mode) | (0x10000 if bf16 else 0)
+    for t in (dbias, dg_first):
+        _chk(t)
     with _timed("lstm_bwd_kernel", 2.0 * T * B * 2 * 4 * H * H):
         _lib.call("sk_lstm_bwd_state", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
-                  _ptr(lens), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(ws), T, B, H, mode, _stream())
+                  _ptr(lens), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(dbias), _ptr(dg_first), _ptr(ws), T, B, H, mode,
+                  _stream())
     return ws
 
 
+def lstm_whh_grad(dgx, y, h0, dg_first, out, T, B, H, accumulate=False, bf16=False, ws_tag="gemm"):
+    """dW_hh (2,4H,H) [+]= sum_t dG_t^T h_{prev(t)} for both directions, WITHOUT materialising h_prev: the recurrent
+    input of step t is the layer's own output one step earlier in processing order, so
+      forward : dgx[1:, :, 0]^T  y[:-1, :, :H]   (rows past a sequence's end have dG = 0)
+      reverse : dgx[:-1, :, 1]^T y[1:, :, H:]    (y is 0 past the end, so the step at len-1 contributes nothing here)
+    as ONE batched GEMM over K = (T-1) B rows with per-direction operand offsets, plus the rank-B term of the steps
+    that start from h0: dg_first[d]^T h0[d] (lstm_bwd's by-product)."""
+    acc = accumulate
+    if T > 1:
+        A = dgx.view(-1)[B * 8 * H:]                     # direction 0 starts at t = 1; direction 1 at t = 0, +4H
+        gemm(A, y, out, 4 * H, H, (T - 1) * B, 8 * H, 2 * H, H, transA=True, accumulate=acc, batch=2,
+             sA=4 * H - B * 8 * H, sB=B * 2 * H + H, sC=4 * H * H, splitk=0, ws_tag=ws_tag, bf16=bf16)
+        acc = True
+    gemm(dg_first, h0, out, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=acc, batch=2, sA=B * 4 * H, sB=B * H,
+         sC=4 * H * H, ws_tag=ws_tag, bf16=bf16)
+
+
 def lstm_status(ws):
+    """Raises SepkernError (SK_ETIMEOUT) if a persistent launch on this workspace timed out since the last call."""
     _lib.call("sk_lstm_status", _ptr(ws), _stream())
 
 
-def lstm_hprev(y, h0, lens, hprev, T, B, H):
-    _lib.call("sk_lstm_hprev", _ptr(y), _ptr(h0), _ptr(lens), _ptr(hprev), T, B, H, _stream())
+def lstm_sticky(ws):
+    """The workspace's sticky status word as a 1-element int32 view (device side checks, no sync)."""
+    return ws[:4].view(torch.int32)
 
 
 # ----------------------------------------------------------------------------- optimizer
-def grad_norm(g, max_norm, scal):
+def grad_norm(g, max_norm, scal, guard=None):
+    """scal (4,) <- [norm, clip coefficient, skip this step, skipped so far]; guard: optional 1-element float tensor,
+    non-zero = do not apply this step (include/sepkern.h)."""
     ws = workspace(_lib.load().sk_optim_workspace_bytes(g.numel()), "optim")
-    _lib.call("sk_grad_norm", _ptr(g), g.numel(), float(max_norm), _ptr(scal), _ptr(ws), _stream())
+    _lib.call("sk_grad_norm", _ptr(g), g.numel(), float(max_norm), _ptr(guard), _ptr(scal), _ptr(ws), _stream())
 
 
 def clip_adam(p, g, m, v, scal, lr, beta1, beta2, eps, step):

@@ -24,17 +24,31 @@ class ClipAdam:
         if self._bound is None or self._bound.data_ptr() != p.data_ptr():
             self.m = torch.zeros_like(p)
             self.v = torch.zeros_like(p)
-            self.scal = torch.zeros(2, device=p.device)
+            self.scal = torch.zeros(4, device=p.device)     # [norm, clip coef, skip this step, steps skipped so far]
             self._bound = p
         return p, g
 
     def step(self):
-        """Returns the device tensor [total_norm, clip_coef] (no host sync)."""
+        """Returns the device tensor [total_norm, clip_coef, skipped, skipped_total] (no host sync).  A step whose
+        gradients are flagged untrusted by the engine's guard word (a timed-out recurrence launch on any rank)
+        changes neither the parameters nor the moments; skipped() / check() report it."""
         p, g = self._state()
         self.step_count += 1
-        ops.grad_norm(g, self.max_norm, self.scal)
+        eng = getattr(self.model, "_engine", None)
+        ops.grad_norm(g, self.max_norm, self.scal, guard=eng.guard if eng is not None else None)
         ops.clip_adam(p, g, self.m, self.v, self.scal, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
         return self.scal
+
+    def skipped(self):
+        """Number of optimizer steps skipped so far because their gradients were flagged (synchronises)."""
+        return int(self.scal[3].item()) if self.scal is not None else 0
+
+    def check(self):
+        n = self.skipped()
+        if n:
+            from ._lib import SepkernError
+            raise SepkernError("%d optimizer step(s) were skipped: a persistent BLSTM launch timed out "
+                               "(grid not co-resident?); try SEPKERN_LSTM_MODE=2" % n)
 
     def state_dict(self):
         self._state()

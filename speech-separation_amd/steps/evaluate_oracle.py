@@ -4,9 +4,10 @@ steps/evaluate_oracle.py:120-145; its segments branch does not run: `use_seg`/`r
 
 For every utterance of <data-dir>/wav.scp: STFT of the mixture and of each source on the GPU (sk_stft), the
 ideal ratio mask |S_i| / |M| (or the binary mask with --hard-mask), mask-apply + iSTFT on the GPU
-(sk_mask_istft), then the score.  The reference scores with mir_eval BSS-eval (absent); this writes SI-SDR
-(no permutation search, like the reference's compute_permutation=False) in the same files under
-<data-dir>/oracle_{soft,hard}_mask_eval/.
+(sk_mask_istft), then the score: BSS Eval SDR / SIR / SAR without permutation search (the reference calls
+mir_eval's bss_eval_sources with compute_permutation=False, steps/evaluate_oracle.py:118,143; here
+sepkern/bsseval.py) into {session,source}_{SDR,SIR,SAR}s.txt + *_stats.txt under
+<data-dir>/oracle_{soft,hard}_mask_eval/, and SI-SDR under its own SISDR names.
 """
 import argparse
 import glob
@@ -37,12 +38,12 @@ def main():
     raise ValueError("the HIP STFT kernels are built for --fft-dim 512 --step-size 128")
   import torch
   from sepkern import ops
+  from sepkern.bsseval import bss_eval_sources
   from sepkern.sisdr import si_sdr
+  from evaluate_sources import MetricFiles
   dir_out = args.data_dir + ("/oracle_hard_mask_eval/" if args.hard_mask else "/oracle_soft_mask_eval/")
   os.makedirs(dir_out, exist_ok=True)
-  sessF = open(dir_out + "session_SDRs.txt", 'w')
-  srcF = open(dir_out + "source_SDRs.txt", 'w')
-  allv = []
+  out = {m: MetricFiles(dir_out, m) for m in ("SDR", "SIR", "SAR", "SISDR")}
   with open(args.data_dir + "/wav.scp", 'r') as listF:
     for line in listF:
       reco_id, filename = line.rstrip().split(' ')
@@ -61,19 +62,15 @@ def main():
       else:
         masks = mags / mix_spec.abs().clamp_min(1e-20)
       wav, _ = ops.mask_istft([mix_spec], [[masks[i].contiguous() for i in range(num_src)]], want_pcm=False)
-      vals = []
-      for i in range(num_src):
-        est = wav[0][i].cpu().numpy().astype(np.float64)
-        ref = pcm[i + 1].cpu().numpy().astype(np.float64)[:len(est)] / 32768.0
-        vals.append(si_sdr(est, ref))
-      sessF.write(reco_id + ' ' + str(sum(vals) / num_src) + '\n')
-      srcF.write(reco_id + ''.join(' ' + str(v) for v in vals) + '\n')
-      allv += vals
-  sessF.close()
-  srcF.close()
-  with open(dir_out + "SDR_stats.txt", 'w') as outF:
-    v = np.array(allv)
-    outF.write("Mean:\t%s\nStd:\t%s\nMax:\t%s\nMin:\t%s\n" % (np.mean(v), np.std(v), np.amax(v), np.amin(v)))
+      ests = np.stack([wav[0][i].cpu().numpy().astype(np.float64) for i in range(num_src)])
+      refs = np.stack([pcm[i + 1].cpu().numpy().astype(np.float64)[:ests.shape[1]] / 32768.0 for i in range(num_src)])
+      sdr, sir, sar, _ = bss_eval_sources(refs, ests, compute_permutation=False)
+      out["SDR"].add(reco_id, sdr)
+      out["SIR"].add(reco_id, sir)
+      out["SAR"].add(reco_id, sar)
+      out["SISDR"].add(reco_id, [si_sdr(ests[i], refs[i]) for i in range(num_src)])
+  for files in out.values():
+    files.close()
 
 
 if __name__ == '__main__':

@@ -1,24 +1,26 @@
 #!/usr/bin/env python3
-"""Training driver: drop-in for the reference's steps/train_qsub.py (same positional arguments
-and options, same files written: intermediate_models/{init,NNN}.mdl, final.mdl,
-train_stats/{train,cv}_loss.txt with lines "EEE <loss>", plots).
+"""Training driver with the command line, file names and line formats of the reference's steps/train_qsub.py
+(:17-53 arguments; :73-76,105,138,144,150,155 files: intermediate_models/{init,NNN}.mdl, final.mdl,
+train_stats/{train,cv}_loss.txt with lines "EEE <loss>", train_stats/plots/...), so steps/qsub_train.sh can call
+it unchanged.  The step itself is the arch module's: compute_loss -> backward -> clip 0.25 -> Adam
+(steps/train_qsub.py:116-122); an epoch's loss is sum(loss * norm) / sum(norm) (:118-119,143); every 5th epoch
+runs the cross-validation set and writes a checkpoint (:124-152).
 
-Loop semantics follow steps/train_qsub.py:113-155: per batch compute_loss -> backward ->
-clip_grad_norm_(0.25) -> Adam(lr) step; epoch loss = sum(loss*norm)/sum(norm); CV pass and
-checkpoint when epoch % 5 == 4.  Differences, all on the host side:
-  * the per-batch loss/norm bookkeeping stays on the GPU (one sync per epoch instead of two per
-    step, steps/train_qsub.py:118-119);
-  * clip + Adam run fused over the flat parameter buffer (sepkern.optim.ClipAdam); --torch-optimizer
-    restores the reference's torch calls on the same parameters;
-  * launched under torch.distributed.run it trains data-parallel: utterances are sharded across
-    ranks, gradients all-reduced over RCCL inside backward, rank 0 writes the files;
-  * `np.float` (steps/train_qsub.py:60, gone from numpy) is float.
+What is organised differently here, on the host side only:
+  * the per-batch loss bookkeeping stays on the GPU: one host sync per epoch instead of two per step;
+  * clip + Adam run fused over the model's flat parameter buffer (sepkern.optim.ClipAdam; --torch-optimizer
+    restores the reference's torch calls on the same parameters);
+  * under torch.distributed.run (one process per GPU) it trains data-parallel: replicas are made identical by a
+    broadcast from rank 0, every epoch's utterances are dealt to the ranks in length-balanced global batches
+    (sepkern.dist.EpochShards: same step count on every rank), gradients are summed over RCCL inside backward,
+    the cross-validation set is sharded too, rank 0 writes the files;
+  * checkpoints also carry the optimizer state (NNN.opt), which the reference loses on resume (:107);
+  * a recurrence launch that timed out never reaches the weights (the fused optimizer skips that step on the
+    device) and is reported when the epoch ends.
 """
 import argparse
 import os
 import sys
-
-import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.abspath(os.path.join(HERE, ".."))
@@ -29,8 +31,11 @@ for p in (PKG, os.path.join(PKG, "tools"), os.path.join(PKG, "archs"), 'tools', 
 import torch
 from torch.utils.data import DataLoader, Subset
 
+CHECKPOINT_EVERY = 5          # steps/train_qsub.py:124,148: epoch % 5 == 4
+CLIP_NORM = 0.25              # steps/train_qsub.py:121
 
-def get_args():
+
+def get_args(argv=None):
   parser = argparse.ArgumentParser(description="""This script trains a separation neural network""")
   parser.add_argument("arch_file", metavar="arch-file", type=str, help="DNN architecture file")
   parser.add_argument("gpu_id", metavar="gpu-id", type=int, help="GPU ID")
@@ -39,7 +44,7 @@ def get_args():
   parser.add_argument("--cv-data-dir", type=str, help="Cross validation data directory", default="")
   parser.add_argument("--train-copy-location", type=str, help="Copy training data here for I/O purposes", default="")
   parser.add_argument("--model-config", type=str, help="Config file for DNN", default="")
-  parser.add_argument("--batch-size", type=int, help="Batch size", default=100)
+  parser.add_argument("--batch-size", type=int, help="Batch size (per GPU)", default=100)
   parser.add_argument("--start-epoch", type=int, help="Epoch to start from", default=0)
   parser.add_argument("--num-epochs", type=int, help="Total number of training epochs", default=200)
   parser.add_argument("--learning-rate", type=float, help="Learning rate", default=0.001)
@@ -50,155 +55,247 @@ def get_args():
                       help="read <data-dir>/wav.scp and compute the STFT features on the GPU inside the step "
                            "(arch must provide WavTrainSet) instead of loading feats_train.scp npz files")
   parser.add_argument("--seed", type=int, default=None, help="seed for weights, shuffling and h0/c0")
-  return parser.parse_args()
+  return parser.parse_args(argv)
 
 
-def load_losses(filename, loss_array):
-  with open(filename, 'r') as lossF:
-    for line in lossF:
-      split = line.rstrip().split()
-      loss_array[0].append(int(split[0]))
-      loss_array[1].append(float(split[1]))
+# ----------------------------------------------------------------------------------------------- files
+class RunDir:
+  """The files of one training run (layout of the reference, steps/train_qsub.py:73-76)."""
+
+  def __init__(self, dirout, writer):
+    self.models = dirout + '/intermediate_models/'
+    self.plots = dirout + '/train_stats/plots/'
+    self.final = dirout + '/final.mdl'
+    self.writer = writer                      # only rank 0 touches the disk
+    self.logs = {"train": LossLog(dirout + '/train_stats/train_loss.txt'),
+                 "cv": LossLog(dirout + '/train_stats/cv_loss.txt')}
+    if writer:
+      os.makedirs(self.models, exist_ok=True)
+      os.makedirs(self.plots, exist_ok=True)
+
+  def epoch_tag(self, epoch_number):
+    return str(epoch_number).zfill(3)
+
+  def model_file(self, epoch_number):
+    return self.models + self.epoch_tag(epoch_number) + '.mdl'
+
+  def optimizer_file(self, epoch_number):
+    return self.models + self.epoch_tag(epoch_number) + '.opt'
 
 
-def main():
-  args = get_args()
+class LossLog:
+  """train_loss.txt / cv_loss.txt: one line "EEE <loss>" per epoch (steps/train_qsub.py:138,144); the history is
+  kept as the [[epochs], [losses]] pair tools/plot.py:plot_loss takes."""
+
+  def __init__(self, path):
+    self.path, self.history, self.handle = path, [[], []], None
+
+  def reload(self):
+    with open(self.path) as f:
+      for line in f:
+        fields = line.split()
+        if len(fields) >= 2:
+          self.history[0].append(int(fields[0]))
+          self.history[1].append(float(fields[1]))      # the reference's np.float (:60) is gone from numpy
+
+  def record(self, epoch_number, value, write):
+    self.history[0].append(epoch_number)
+    self.history[1].append(value)
+    if write:
+      if self.handle is None:
+        self.handle = open(self.path, 'a')
+      self.handle.write(str(epoch_number).zfill(3) + ' ' + str(value) + '\n')
+      self.handle.flush()
+
+
+def read_model_conf(path):
+  """key=value per line; values stay strings, as SepDNN(**kwargs) expects (steps/train_qsub.py:87-91)."""
+  conf = {}
+  if path:
+    with open(path) as f:
+      for line in f:
+        if '=' in line:
+          key, value = line.rstrip().split('=', 1)
+          conf[key] = value
+  return conf
+
+
+# ----------------------------------------------------------------------------------------------- data
+def training_batches(m, args, rank, world):
+  """DataLoader over this rank's share of the training set, and the sampler to re-seed per epoch (or None).
+  One process: the reference's shuffled loader (steps/train_qsub.py:80-81).  Several: EpochShards."""
+  from sepkern import dist as skdist
+  dataset = m.WavTrainSet(args.data_dir) if args.wav_input else m.TrainSet(args.data_dir, args.train_copy_location)
+  seed = args.seed if args.seed is not None else 0
+  if world == 1:
+    gen = None
+    if args.seed is not None:
+      gen = torch.Generator()
+      gen.manual_seed(seed)
+    return DataLoader(dataset, batch_size=args.batch_size, shuffle=True, collate_fn=dataset.collator,
+                      num_workers=args.num_workers, generator=gen), None
+  counts = dataset.frame_counts() if hasattr(dataset, "frame_counts") else None
+  shards = skdist.EpochShards(len(dataset), args.batch_size, rank, world, lengths=counts, seed=seed)
+  return DataLoader(dataset, batch_sampler=shards, collate_fn=dataset.collator, num_workers=args.num_workers), shards
+
+
+def validation_batches(m, args, rank, world):
+  from sepkern import dist as skdist
+  if not args.cv_data_dir:
+    return None
+  dataset = m.WavTrainSet(args.cv_data_dir) if args.wav_input else m.TrainSet(args.cv_data_dir)
+  part = dataset if world == 1 else Subset(dataset, skdist.shard_indices_contiguous(len(dataset), rank, world))
+  if len(part) == 0:
+    return []                                    # more ranks than utterances: this rank only joins the final sum
+  return DataLoader(part, batch_size=args.batch_size, collate_fn=dataset.collator)
+
+
+# ----------------------------------------------------------------------------------------------- model
+def build_model(m, args, gpu, rank):
+  """SepDNN from the conf file on the GPU, identical on every rank, with its optimizer."""
   from sepkern import dist as skdist
   from sepkern.optim import ClipAdam
-  rank, world, local = skdist.init_from_env()
-  gpu = local if world > 1 else args.gpu_id
-  if rank == 0:
-    print("Using " + args.arch_file + " DNN architecture")
-  m = __import__(args.arch_file)
-
-  if rank == 0:
-    print("Using GPU", gpu)
-  torch.cuda.set_device(gpu)
   if args.seed is not None:
     torch.manual_seed(args.seed)
-
-  int_model_dir = args.dirout + '/intermediate_models/'
-  plot_dir = args.dirout + '/train_stats/plots/'
-  loss_file = args.dirout + '/train_stats/train_loss.txt'
-  cv_loss_file = args.dirout + '/train_stats/cv_loss.txt'
-  if rank == 0:
-    os.makedirs(int_model_dir, exist_ok=True)
-    os.makedirs(plot_dir, exist_ok=True)
-
-  print("loading datset")
-  if args.wav_input:
-    dataset = m.WavTrainSet(args.data_dir)
-  else:
-    dataset = m.TrainSet(args.data_dir, args.train_copy_location)
-  collate = dataset.collator
-  train_data = dataset if world == 1 else Subset(dataset, skdist.shard_indices(len(dataset), rank, world))
-  gen = torch.Generator()
-  gen.manual_seed((args.seed or 0) + rank)
-  dataloader = DataLoader(train_data, batch_size=args.batch_size, shuffle=True, collate_fn=collate,
-                          num_workers=args.num_workers, generator=gen if args.seed is not None else None)
-  if args.cv_data_dir:
-    cv_dataset = m.WavTrainSet(args.cv_data_dir) if args.wav_input else m.TrainSet(args.cv_data_dir)
-    cv_dataloader = DataLoader(cv_dataset, batch_size=args.batch_size, collate_fn=cv_dataset.collator)
-
-  print("initializing model")
-  kwargs = dict()
-  if args.model_config:
-    for line in open(args.model_config):
-      if '=' in line:
-        kwargs[line.split('=')[0]] = line.rstrip().split('=')[1]
-  model = m.SepDNN(gpu, **kwargs)
+  model = m.SepDNN(gpu, **read_model_conf(args.model_config))
   model.cuda()
+  if hasattr(model, "flat_parameters"):
+    model.flat_parameters()                      # bind the flat buffers before anything is broadcast or optimised
+  skdist.broadcast_model(model)                  # whatever RNG state each rank had
   if args.seed is not None:
     model.hidden_generator = torch.Generator(device="cuda")
-    model.hidden_generator.manual_seed(args.seed + 7919 * rank)
+    model.hidden_generator.manual_seed(args.seed + 7919 * rank)       # per-rank h0/c0 stream
   if args.torch_optimizer:
     optimizer = torch.optim.Adam(model.parameters(), lr=args.learning_rate)
   else:
-    optimizer = ClipAdam(model, lr=args.learning_rate, max_norm=0.25)
-  print("using lr=" + str(args.learning_rate))
+    optimizer = ClipAdam(model, lr=args.learning_rate, max_norm=CLIP_NORM)
+  return model, optimizer
 
-  epoch_losses = [[], []]
-  epoch_cv_losses = [[], []]
-  lossF = open(loss_file, 'a') if rank == 0 else None
-  cv_lossF = open(cv_loss_file, 'a') if (rank == 0 and args.cv_data_dir) else None
+
+def resume(model, optimizer, run, args):
+  model.load_state_dict(torch.load(run.model_file(args.start_epoch), map_location=lambda storage, loc: storage.cuda()))
+  if os.path.isfile(run.optimizer_file(args.start_epoch)):
+    optimizer.load_state_dict(torch.load(run.optimizer_file(args.start_epoch),
+                                         map_location=lambda storage, loc: storage.cuda()))
+  run.logs["train"].reload()
+  if args.cv_data_dir:
+    run.logs["cv"].reload()
+
+
+# ----------------------------------------------------------------------------------------------- passes
+def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
+  """One pass over this rank's batches.  Returns the device tensor [sum(loss * norm), sum(norm)] of the GLOBAL
+  epoch (all-reduced), still un-synchronised."""
+  acc = torch.zeros(2, device="cuda", dtype=torch.float64)
+  for batch in batches:
+    loss, norm = m.compute_loss(model, epoch, batch)
+    acc[0] += loss.detach().double() * norm.double()
+    # under data parallelism `norm` is already the global frame count: every rank adds its 1/world share
+    acc[1] += norm.double() / world
+    loss.backward()
+    if torch_clip:
+      torch.nn.utils.clip_grad_norm_(model.parameters(), CLIP_NORM)
+    optimizer.step()
+  if world > 1:
+    torch.distributed.all_reduce(acc)
+  return acc
+
+
+def validation_pass(m, model, batches, epoch, world, plot_dir):
+  """Eval-mode pass over this rank's shard of the CV set; no collective inside (the arch keeps its local norm
+  when not training).  Returns the global [sum(loss * norm), sum(norm)]."""
+  acc = torch.zeros(2, device="cuda", dtype=torch.float64)
+  model.eval()
+  with torch.no_grad():
+    for i, batch in enumerate(batches):
+      where = plot_dir if (i == 0 and plot_dir) else ""
+      loss, norm = m.compute_cv_loss(model, epoch, batch, where) if where else m.compute_cv_loss(model, epoch, batch)
+      acc[0] += loss.detach().double() * norm.double()
+      acc[1] += norm.double()
+  model.train()
+  if world > 1:
+    torch.distributed.all_reduce(acc)
+  return acc
+
+
+def report_failures(model, optimizer):
+  """Epoch boundary: surface a timed-out recurrence launch (host sync)."""
+  if hasattr(optimizer, "check"):
+    optimizer.check()
+  if hasattr(model, "check_status"):
+    model.check_status()
+
+
+def write_checkpoint(model, optimizer, run, epoch_number):
+  torch.save(model.state_dict(), run.model_file(epoch_number))
+  torch.save(optimizer.state_dict(), run.optimizer_file(epoch_number))
+  draw_losses(run, run.plots + 'epoch' + run.epoch_tag(epoch_number) + '/', epoch_number)
+
+
+def draw_losses(run, where, last_epoch_number):
+  try:
+    import plot
+  except ImportError:
+    return
+  train, cv = run.logs["train"].history, run.logs["cv"].history
+  if not train[0]:
+    return
+  os.makedirs(where, exist_ok=True)
+  plot.plot_loss(train, cv, where + 'Loss_' + run.epoch_tag(train[0][0]) + '-' + run.epoch_tag(last_epoch_number) + '.png')
+
+
+# ----------------------------------------------------------------------------------------------- main
+def main(argv=None):
+  args = get_args(argv)
+  from sepkern import dist as skdist
+  rank, world, local = skdist.init_from_env()
+  gpu = local if world > 1 else args.gpu_id
+  chief = rank == 0
+  if chief:
+    print("Using " + args.arch_file + " DNN architecture")
+    print("Using GPU", gpu, "of", world)
+  m = __import__(args.arch_file)
+  torch.cuda.set_device(gpu)
+
+  run = RunDir(args.dirout, chief)
+  train_batches, shards = training_batches(m, args, rank, world)
+  cv_batches = validation_batches(m, args, rank, world)
+  model, optimizer = build_model(m, args, gpu, rank)
+  if chief:
+    print("using lr=" + str(args.learning_rate))
 
   if args.start_epoch == 0:
-    if rank == 0:
-      torch.save(model.state_dict(), int_model_dir + 'init.mdl')
+    if chief:
+      torch.save(model.state_dict(), run.models + 'init.mdl')
   else:
-    model.load_state_dict(torch.load(int_model_dir + str(args.start_epoch).zfill(3) + '.mdl',
-                                     map_location=lambda storage, loc: storage.cuda()))
-    # beyond the reference (which restarts Adam's moments on resume, steps/train_qsub.py:107): optimizer state
-    opt_file = int_model_dir + str(args.start_epoch).zfill(3) + '.opt'
-    if os.path.isfile(opt_file):
-      optimizer.load_state_dict(torch.load(opt_file, map_location=lambda storage, loc: storage.cuda()))
-    load_losses(loss_file, epoch_losses)
-    if args.cv_data_dir:
-      load_losses(cv_loss_file, epoch_cv_losses)
+    resume(model, optimizer, run, args)
 
-  print("training")
   for epoch in range(args.start_epoch, args.num_epochs):
-    acc = torch.zeros(2, device="cuda", dtype=torch.float64)      # [sum(loss*norm), sum(norm)] of my shard
-    for i_batch, sample_batch in enumerate(dataloader):
-      loss, norm = m.compute_loss(model, epoch, sample_batch)
-      ld = loss.detach().double()
-      acc[0] += ld * norm.double()
-      acc[1] += norm.double() / world if world > 1 else norm.double()   # norm is already the global one under DP
-      loss.backward()
-      if args.torch_optimizer:
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 0.25)
-      optimizer.step()
-    if world > 1:
-      torch.distributed.all_reduce(acc)
-    epoch_loss, epoch_norm = float(acc[0]), float(acc[1])
-
-    if args.cv_data_dir and epoch % 5 == 4:
-      cv_acc = torch.zeros(2, device="cuda", dtype=torch.float64)
-      model.eval()
-      with torch.no_grad():
-        for i_batch_cv, sample_batch_cv in enumerate(cv_dataloader):
-          if i_batch_cv == 0 and rank == 0:
-            cv_loss, cv_norm = m.compute_cv_loss(model, epoch, sample_batch_cv, plot_dir + 'epoch' + str(epoch + 1).zfill(3))
-          else:
-            cv_loss, cv_norm = m.compute_cv_loss(model, epoch, sample_batch_cv)
-          cv_acc[0] += cv_loss.detach().double() * cv_norm.double()
-          cv_acc[1] += cv_norm.double()
-      model.train()
-      cv_val = float(cv_acc[0] / cv_acc[1])
-      if rank == 0:
-        print("For epoch: " + str(epoch + 1).zfill(3) + " cv set loss is: " + str(cv_val))
-        cv_lossF.write(str(epoch + 1).zfill(3) + ' ' + str(cv_val) + '\n')
-        cv_lossF.flush()
-      epoch_cv_losses[0].append(epoch + 1)
-      epoch_cv_losses[1].append(cv_val)
-
-    if rank == 0:
-      print("For epoch: " + str(epoch + 1).zfill(3) + " loss is: " + str(epoch_loss / epoch_norm))
-      lossF.write(str(epoch + 1).zfill(3) + ' ' + str(epoch_loss / epoch_norm) + '\n')
-      lossF.flush()
-    epoch_losses[0].append(epoch + 1)
-    epoch_losses[1].append(epoch_loss / epoch_norm)
-    if epoch % 5 == 4 and rank == 0:
-      print("Saving model for epoch " + str(epoch + 1).zfill(3))
-      torch.save(model.state_dict(), int_model_dir + str(epoch + 1).zfill(3) + '.mdl')
-      torch.save(optimizer.state_dict(), int_model_dir + str(epoch + 1).zfill(3) + '.opt')
-      try:
-        import plot
-        os.makedirs(plot_dir + 'epoch' + str(epoch + 1).zfill(3), exist_ok=True)
-        plot.plot_loss(epoch_losses, epoch_cv_losses, plot_dir + 'epoch' + str(epoch + 1).zfill(3) + '/Loss_' +
-                       str(epoch_losses[0][0]).zfill(3) + '-' + str(epoch + 1).zfill(3) + '.png')
-      except ImportError:
-        pass
+    number = epoch + 1
+    if shards is not None:
+      shards.set_epoch(epoch)
+    acc = train_epoch(m, model, optimizer, train_batches, epoch, world, args.torch_optimizer)
+    checkpoint = epoch % CHECKPOINT_EVERY == CHECKPOINT_EVERY - 1
+    if cv_batches is not None and checkpoint:
+      cv = validation_pass(m, model, cv_batches, epoch, world,
+                           run.plots + 'epoch' + run.epoch_tag(number) if chief else "")
+      cv_value = float(cv[0] / cv[1])
+      if chief:
+        print("For epoch: " + run.epoch_tag(number) + " cv set loss is: " + str(cv_value))
+      run.logs["cv"].record(number, cv_value, chief)
+    value = float(acc[0] / acc[1])                  # the epoch's one host sync
+    report_failures(model, optimizer)
+    if chief:
+      print("For epoch: " + run.epoch_tag(number) + " loss is: " + str(value))
+    run.logs["train"].record(number, value, chief)
+    if checkpoint and chief:
+      print("Saving model for epoch " + run.epoch_tag(number))
+      write_checkpoint(model, optimizer, run, number)
     sys.stdout.flush()
 
-  if rank == 0:
-    torch.save(model.state_dict(), args.dirout + '/final.mdl')
-    try:
-      import plot
-      plot.plot_loss(epoch_losses, epoch_cv_losses, plot_dir + 'Loss_' + str(epoch_losses[0][0]).zfill(3) + '-' +
-                     str(args.num_epochs).zfill(3) + '.png')
-    except (ImportError, IndexError):
-      pass
+  if chief:
+    torch.save(model.state_dict(), run.final)
+    draw_losses(run, run.plots, args.num_epochs)
   if world > 1:
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -6,7 +6,8 @@ or rounding-order level).
 
     python tools/lstm_bench.py [--bf16] [--T 400] [--B 32] [--H 896] [--rounds 7] [--fwd "0,0;1,0;1,2"] [--bwd "0;1"]
 
---fwd: list of "half,map" (sk_lstm_fwd mode bits 17 and 18..19); --bwd: list of backward variants (mode bits 17..).
+--fwd / --bwd: lists of "half,map,poll1,repflags" (sk_lstm_fwd / sk_lstm_bwd mode bits 17, 18..19, 20, 21; trailing
+fields default to 0); an optional 5th field is the minimum number of batch groups per workgroup (mode bits 8..15).
 """
 import argparse
 import os
@@ -26,8 +27,8 @@ def main():
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--H", type=int, default=896)
     ap.add_argument("--rounds", type=int, default=7)
-    ap.add_argument("--fwd", default="0,0;1,0;1,1;1,2;0,1")
-    ap.add_argument("--bwd", default="0")
+    ap.add_argument("--fwd", default="0,0;0,1;0,1,1;0,1,0,1;0,1,1,1")
+    ap.add_argument("--bwd", default="0,0;0,1;0,1,0,1")
     ap.add_argument("--ragged", action="store_true")
     a = ap.parse_args()
     T, B, H, bf = a.T, a.B, a.H, a.bf16
@@ -39,8 +40,17 @@ def main():
     if a.ragged:
         lens[1::3] = max(1, (5 * T) // 6)
     dy = torch.randn(T, B, 2 * H, device="cuda")
-    fwd_vars = [tuple(int(v) for v in s.split(",")) for s in a.fwd.split(";") if s]
-    bwd_vars = [int(s) for s in a.bwd.split(";") if s != ""]
+    def parse(spec):
+        out = []
+        for s in spec.split(";"):
+            if s:
+                v = [int(x) for x in s.split(",")]
+                out.append(tuple(v + [0] * (5 - len(v))))
+        return out
+    fwd_vars, bwd_vars = parse(a.fwd), parse(a.bwd)
+
+    def bits(var):
+        return ops.lstm_variant_bits(bool(var[0]), var[1], bool(var[2]), bool(var[3])) | (var[4] << 8)
 
     def run_fwd(var):
         g = gx.clone()
@@ -48,7 +58,7 @@ def main():
         hn, cn = torch.empty(2, B, H, device="cuda"), torch.empty(2, B, H, device="cuda")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, hn, cn, T, B, H, 1, bf16=bf, half=bool(var[0]), blockmap=var[1])
+        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, hn, cn, T, B, H, 1 | bits(var), bf16=bf)
         e1.record()
         torch.cuda.synchronize()
         ops.lstm_status(ws)
@@ -60,7 +70,7 @@ def main():
         dh0, dc0 = torch.empty(2, B, H, device="cuda"), torch.empty(2, B, H, device="cuda")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, lens, gg, dh0, dc0, T, B, H, 1 | (var << 17), bf16=bf)
+        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, lens, gg, dh0, dc0, T, B, H, 1 | bits(var), bf16=bf)
         e1.record()
         torch.cuda.synchronize()
         ops.lstm_status(ws)
@@ -89,11 +99,11 @@ def main():
     print("BLSTM recurrence, T=%d B=%d H=%d %s%s: us per step (median / min over %d rounds), max |diff| vs first variant"
           % (T, B, H, "bf16" if bf else "fp32", " ragged" if a.ragged else "", a.rounds))
     for v in fwd_vars:
-        print("  fwd half=%d map=%d : %7.3f / %7.3f   diff %.3g" % (v[0], v[1], 1e3 * statistics.median(tf[v]) / T,
-                                                                  1e3 * min(tf[v]) / T, df[v]))
+        print("  fwd half=%d map=%d poll1=%d rep=%d gmin=%d : %7.3f / %7.3f   diff %.3g"
+              % (v + (1e3 * statistics.median(tf[v]) / T, 1e3 * min(tf[v]) / T, df[v])))
     for v in bwd_vars:
-        print("  bwd variant %d     : %7.3f / %7.3f   diff %.3g" % (v, 1e3 * statistics.median(tb[v]) / T,
-                                                                  1e3 * min(tb[v]) / T, db[v]))
+        print("  bwd half=%d map=%d poll1=%d rep=%d gmin=%d : %7.3f / %7.3f   diff %.3g"
+              % (v + (1e3 * statistics.median(tb[v]) / T, 1e3 * min(tb[v]) / T, db[v])))
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@ NAMES_B = ["wait flags+barrier", "-", "matmul (DMA ring+MFMA+reduce)", "-", "cel
 
 
 def stamps(ws):
-    return ws[:256].view(torch.int64)[4:12].cpu().tolist()
+    return ws[256:512].view(torch.int64)[4:12].cpu().tolist()   # the per-launch control block
 
 
 def main():

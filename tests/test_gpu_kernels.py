@@ -327,21 +327,30 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
     np.testing.assert_allclose(hn.cpu().numpy(), hn_ref.detach().numpy(), **tol)
     np.testing.assert_allclose(cn.cpu().numpy(), cn_ref.detach().numpy(), **tol)
     dh0, dc0 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
-    ws = ops.lstm_bwd(dev(dy), whh, gx, cs, dev(c0), lens_d, gx, dh0, dc0, T, B, H, mode, dhn=dev(dhn), dcn=dev(dcn))
+    nbg = (B + 15) // 16
+    dbias = torch.full((nbg, 2, 4 * H), float("nan")).cuda()         # by-products: bias-gradient partials ...
+    dg_first = torch.full((2, B, 4 * H), float("nan")).cuda()        # ... and the dG of the steps that start from h0
+    ws = ops.lstm_bwd(dev(dy), whh, gx, cs, dev(c0), lens_d, gx, dh0, dc0, T, B, H, mode, dhn=dev(dhn), dcn=dev(dcn),
+                      dbias=dbias, dg_first=dg_first)
     ops.lstm_status(ws)
     gtol = dict(rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(dh0.cpu().numpy(), h0r.grad.numpy(), **gtol)
     np.testing.assert_allclose(dc0.cpu().numpy(), c0r.grad.numpy(), **gtol)
     dgx = gx.cpu().double().view(R, 2, 4 * H)
     assert torch.isfinite(dgx).all()
-    hprev = torch.empty(T, B, 2, H).cuda()
-    ops.lstm_hprev(y, dev(h0), lens_d, hprev, T, B, H)
-    hp = hprev.cpu().double().view(R, 2, H)
+    # dW_hh without a materialised h_prev: time-shifted product with the layer output + the h0 steps
+    dwhh = torch.full((2, 4 * H, H), float("nan")).cuda()
+    ops.lstm_whh_grad(gx, y, dev(h0), dg_first, dwhh, T, B, H)
+    dwhh2 = dwhh.clone()
+    ops.lstm_whh_grad(gx, y, dev(h0), dg_first, dwhh2, T, B, H, accumulate=True)
+    db = dbias.cpu().double().sum(0)                                  # (2, 4H)
     for d in range(2):
         w_ih_g, w_hh_g, b_ih_g, b_hh_g = (t.grad for t in wr[0][d])
         np.testing.assert_allclose((dgx[:, d].t() @ x.double().view(R, I)).numpy(), w_ih_g.numpy(), rtol=1e-4, atol=2e-5)
-        np.testing.assert_allclose((dgx[:, d].t() @ hp[:, d]).numpy(), w_hh_g.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(dwhh[d].cpu().numpy(), w_hh_g.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(dwhh2[d].cpu().numpy(), 2 * w_hh_g.numpy(), rtol=1e-4, atol=4e-5)
         np.testing.assert_allclose(dgx[:, d].sum(0).numpy(), b_ih_g.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(db[d].numpy(), b_ih_g.numpy(), rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(b_hh_g.numpy(), b_ih_g.numpy())
 
 

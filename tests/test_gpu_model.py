@@ -356,3 +356,44 @@ def test_data_parallel_sync_bn_equals_global_batch(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     c = np.load(nosync)
     assert np.linalg.norm(c["grad"].astype(np.float64) - b["grad"]) / np.linalg.norm(b["grad"]) > 1e-3
+
+
+def test_timed_out_recurrence_never_reaches_the_weights(arch):
+    """A persistent launch whose bounded wait gave up leaves garbage gradients.  Its sticky status word travels
+    behind the flat gradient to the fused clip+Adam, which skips the step on the device (no host sync per step);
+    the host learns of it from ClipAdam.check() / model.check_status()."""
+    from sepkern import ops
+    from sepkern._lib import SepkernError
+    from sepkern.optim import ClipAdam
+    torch.manual_seed(5)
+    H, L, B, T = 64, 2, 4, 9
+    model = arch.SepDNN(0, hidden_dim=str(H), num_layers=str(L))
+    model.cuda()
+    model.train()
+    opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
+    rng = np.random.default_rng(0)
+    samples = [{"mix": np.abs(rng.standard_normal((T, 257))).astype(np.float32),
+                "source1": np.abs(rng.standard_normal((T, 257))).astype(np.float32),
+                "source2": np.abs(rng.standard_normal((T, 257))).astype(np.float32)} for _ in range(B)]
+    batch = arch.Collator("mix")(samples)
+
+    def one_step():
+        loss, _ = arch.compute_loss(model, 0, batch)
+        loss.backward()
+        return opt.step()
+    one_step()
+    assert opt.skipped() == 0
+    before = model.flat_parameters()[0].clone()
+    m_before = opt.m.clone()
+    ws = ops.lstm_ws(T, B, H)
+    ops.lstm_sticky(ws).fill_(1)                      # what an aborting workgroup does (csrc/lstm.hip, wait_flags)
+    scal = one_step()
+    assert float(scal[2]) == 1.0 and opt.skipped() == 1
+    assert torch.equal(model.flat_parameters()[0], before) and torch.equal(opt.m, m_before)
+    with pytest.raises(SepkernError):
+        opt.check()
+    with pytest.raises(SepkernError):
+        model.check_status()                          # reports once and clears the word
+    model.check_status()
+    one_step()
+    assert opt.skipped() == 1 and not torch.equal(model.flat_parameters()[0], before)

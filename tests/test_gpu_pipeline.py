@@ -97,7 +97,7 @@ def test_recipe_steps_end_to_end(tmp_path):
             d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
             assert d.max() <= 1 and (d > 0).mean() < 5e-3
 
-    # ---- stage 4: scoring (SI-SDR in the reference's results-file formats, run_eval.sh:88-93)
+    # ---- stage 4: scoring (BSS Eval SDR/SIR/SAR in the reference's results files, run_eval.sh:88-93; SI-SDR beside them)
     run(os.path.join(STEPS, "evaluate_sources.py"), data, exp)
     st = open(os.path.join(exp, "results", "SDR_stats.txt")).read().splitlines()
     assert [l.split("\t")[0] for l in st] == ["Mean:", "Std:", "Max:", "Min:"] and np.isfinite(float(st[0].split("\t")[1]))
@@ -105,7 +105,12 @@ def test_recipe_steps_end_to_end(tmp_path):
     assert [l.split(' ')[0] for l in sess] == ids
     src = open(os.path.join(exp, "results", "source_SDRs.txt")).readline().split(' ')
     assert src[0] == ids[0] and len(src) == 3
-    assert os.path.isfile(os.path.join(exp, "results", "SDRi_stats.txt"))
+    for name in ("SIR_stats.txt", "SAR_stats.txt", "session_SIRs.txt", "source_SARs.txt", "SISDR_stats.txt", "SISDRi_stats.txt",
+                 "session_SISDRs.txt", "source_SISDRis.txt"):
+        assert os.path.isfile(os.path.join(exp, "results", name)), name
+    sdr0 = [float(v) for v in src[1:]]
+    si0 = [float(v) for v in open(os.path.join(exp, "results", "source_SISDRs.txt")).readline().split(' ')[1:]]
+    assert all(a >= b - 1e-6 for a, b in zip(sorted(sdr0), sorted(si0)))   # a 512-tap filter explains at least what a gain does
 
     # ---- oracle-mask upper bound through the same STFT -> mask -> iSTFT kernels (steps/evaluate_oracle.py)
     run(os.path.join(STEPS, "evaluate_oracle.py"), data)
