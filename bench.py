@@ -77,13 +77,13 @@ def make_batch(torch, ops, synth, B, T, S, rank):
     return feats[0], feats[1:], lens, pcms
 
 
-def cpu_baseline(H, L, S):
-    """The oracle's train step (same torch-CPU ops as the reference loop, steps/train_qsub.py:116-122)
-    on a bounded sample of the workload: same model, batch 8 x 100 frames."""
+def cpu_baseline(H, L, S, B, T, budget_s=240.0):
+    """The oracle's train step (same torch-CPU ops as the reference loop, steps/train_qsub.py:116-122: nn.LSTM,
+    BatchNorm1d, Linear, PIT-MSE, clip_grad_norm_, Adam) timed at the WORKLOAD'S OWN batch shape, B x T frames:
+    3 steps after a short warm-up on a small batch (thread pool, allocator), fewer only if `budget_s` runs out."""
     import numpy as np
     import torch
     from oracle import upit as OU
-    B, T = 8, 100
     torch.manual_seed(0)
     # the GPU box gives a 1-GPU job a 16-CPU share of a much larger host: os.cpu_count() would oversubscribe
     try:
@@ -95,23 +95,27 @@ def cpu_baseline(H, L, S):
     model = OU.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     rng = np.random.default_rng(0)
-    samples = []
-    for _ in range(B):
-        d = {"mix": np.abs(rng.standard_normal((T, 257))).astype(np.float32)}
-        for s in range(S):
-            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((T, 257))).astype(np.float32)
-        samples.append(d)
-    batch = OU.collate(samples)
-    OU.train_step(model, opt, batch, model.init_hidden(B))           # warm-up
+
+    def batch(nb, nt):
+        samples = []
+        for _ in range(nb):
+            d = {"mix": np.abs(rng.standard_normal((nt, 257))).astype(np.float32)}
+            for s in range(S):
+                d["source%d" % (s + 1)] = np.abs(rng.standard_normal((nt, 257))).astype(np.float32)
+            samples.append(d)
+        return OU.collate(samples)
+    OU.train_step(model, opt, batch(4, 20), model.init_hidden(4))        # warm-up, not the measured shape
+    full = batch(B, T)
     t0 = time.time()
     n = 0
-    while n < 3 or (time.time() - t0 < 10.0 and n < 20):
-        OU.train_step(model, opt, batch, model.init_hidden(B))
+    while n < 3 and (n == 0 or time.time() - t0 < budget_s * n / (n + 1)):
+        OU.train_step(model, opt, full, model.init_hidden(B))
         n += 1
     dt = time.time() - t0
     return {"value": round(n * B * T / dt, 1), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "oracle train step (torch-CPU nn.LSTM/BN/Linear + PIT-MSE + clip + Adam), same %dx%d model, "
-                      "batch %d x %d frames, %d steps after 1 warm-up" % (L, H, B, T, n)}
+            "seconds_per_step": round(dt / n, 2),
+            "sample": "oracle train step (torch-CPU nn.LSTM/BN/Linear + PIT-MSE + clip + Adam), same %dx%d model, the "
+                      "workload's own batch of %d x %d frames, %d steps after a small-batch warm-up" % (L, H, B, T, n)}
 
 
 def main():
@@ -176,15 +180,38 @@ def main():
         loss.backward()
         opt.step()
 
-    for i in range(args.warmup):
-        step()
-        torch.cuda.synchronize()
-        log("warm-up step %d done" % (i + 1))
+    def warm_up():
+        for i in range(args.warmup):
+            step()
+            torch.cuda.synchronize()
+            log("warm-up step %d done" % (i + 1))
+
+    warm_up()
+    # A persistent recurrence launch that could not keep its grid co-resident times out (bounded spins), flags the
+    # step through the gradient buffer -- on EVERY rank, the flag is all-reduced with the gradients -- and the fused
+    # optimizer skips it.  Then continue in this same process with one launch per step (never re-exec a process
+    # that has touched the GPU) and say so in the JSON; a second failure is fatal.
+    lstm_fallback = None
+    if opt.skipped() > 0:
+        log("a persistent recurrence launch timed out during warm-up: falling back to SEPKERN_LSTM_MODE=2")
+        try:
+            model.check_status()
+        except _lib.SepkernError:
+            pass
+        model._engine.lstm_mode = 2
+        lstm_fallback = "per-step launches (mode 2) after a timed-out persistent launch"
+        skipped_before = opt.skipped()
+        warm_up()
+        if opt.skipped() > skipped_before:
+            sys.exit("bench: the recurrence fails in per-step mode too")
+    skipped_before = opt.skipped()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     if not args.no_kernel_events:
         ops.PROF = {}
+    if world > 1:
+        skdist.TIMING = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -210,10 +237,24 @@ def main():
         prof_alone = ops.prof_summary()
         ops.PROF = None
         model._engine.overlap = True
+    if opt.skipped() > skipped_before:
+        sys.exit("bench: %d step(s) of the timed region were skipped (timed-out recurrence launch)" % (opt.skipped() - skipped_before))
+    dist_info = None
     if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        ar = skdist.TIMING or []
+        skdist.TIMING = None
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar) / max(1, len(ar))
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "ms_per_step_by_rank": [round(1000.0 * t / args.steps, 3) for t in per_rank],
+                     "allreduce_ms_per_step": round(ar_ms, 3), "allreduce_calls": len(ar),
+                     "allreduce_bytes": int(model._engine.grad_full.numel() * 4),
+                     "allreduce_busbw_GBs": round(2.0 * (world - 1) / world * model._engine.grad_full.numel() * 4 /
+                                                  (ar_ms * 1e-3) / 1e9, 1) if ar_ms > 0 else None}
+        dt = max(per_rank)
     final_loss = float(loss_acc[0] / loss_acc[1])
     if not (final_loss == final_loss) or final_loss <= 0:
         sys.exit("bench: loss is not finite/positive (%r)" % final_loss)
@@ -234,6 +275,10 @@ def main():
                    "parallelism": "dp%d" % world if world > 1 else "single",
                    "mean_loss": round(final_loss, 6)},
     }
+    if dist_info:
+        res["distributed"] = dist_info
+    if lstm_fallback:
+        res["lstm_fallback"] = lstm_fallback
     if prof:
         kname = "gemm_bf16_kernel" if args.dtype == "bf16" else "gemm_f32_kernel"
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
@@ -268,12 +313,12 @@ def main():
         else:
             P = sum(2 * 4 * H * ((257 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257 * S
         res["step_tflops"] = round(6.0 * P * frames_per_step / world / (dt / args.steps) / 1e12, 2)
-        res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / PEAK_F32_MFMA_TFLOPS, 4)  # vs the fp32 peak
+        res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / peak, 4)   # the compute dtype's dense MFMA peak
     if args.aux and rank == 0:
         res["aux"] = aux_kernels(torch, ops, pcms, mix, T, B, S)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (bounded sample)")
-        res["cpu_baseline"] = cpu_baseline(H, L, S)
+        res["cpu_baseline"] = cpu_baseline(H, L, S, B, T)
         log("CPU baseline done: %s frames/s on %d threads" % (res["cpu_baseline"]["value"], res["cpu_baseline"]["cores"]))
     if rank == 0:
         print(json.dumps(res), flush=True)
@@ -281,14 +326,30 @@ def main():
         dist.destroy_process_group()
 
 
+def kernel_source_id():
+    """sha256 over the HIP sources the library is built from: ties a PMC pass to the code it measured (the GPU box has
+    no .git, so a commit id cannot be read there)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(PKG, "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".inc")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3
     --pmc FETCH_SIZE / WRITE_SIZE in separate runs of this same bench, gfx950 read correction applied) -- the
-    counters cannot be collected from inside this process, so the figure is the one measured by those runs,
-    or None when the file holds nothing for this kernel."""
+    counters cannot be collected from inside this process.  The file records the id of the kernel sources it was
+    measured on (and the commit); when that differs from the sources of THIS run the figure is stale: None."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes"]
+            doc = json.load(f)
+        if doc.get("kernel_source_id") != kernel_source_id():
+            return None
+        return doc["kernels"][kernel]["hbm_bytes"]
     except (OSError, KeyError, ValueError):
         return None
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 101
+#define SK_VERSION 102
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -93,6 +93,20 @@ int sk_gemm_bf16_splitk(const float* A, const float* B, float* C, const float* b
                         int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
                         int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws,
                         sk_stream_t stream);
+
+/* bf16 operands IN MEMORY, both K-contiguous ("NT"): C[M,N] = act(A[M,K] B[N,K]^T + bias (+ C)), A and B bf16
+ * (row-major, leading dimensions lda, ldb in elements), C / bias / slabs fp32.  The form every product of the bf16
+ * configuration is brought to by writing bf16 copies of the operands (sk_cast_bf16, or sk_cast_bf16_t where the
+ * product needs the transpose).  Requirements: K % 64 == 0 (pad the copies with zero columns), lda, ldb, sA, sB
+ * multiples of 8, A and B 16-byte aligned; rows are read up to K.  M and N are arbitrary.  splitk / ws / batch /
+ * accumulate / act as sk_gemm_f32_splitk. */
+int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                    int ldc, int accumulate, int act, int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias,
+                    int splitk, void* ws, sk_stream_t stream);
+/* dst[r][c] = bf16(src[r][c]) (round to nearest even) for c < C, 0 for C <= c < ld_dst; ld_dst % 8 == 0. */
+int sk_cast_bf16(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream);
+/* dst[c][r] = bf16(src[r][c]) for r < R, 0 for R <= r < ld_dst: the transposed copy, (C, ld_dst) row-major. */
+int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream);
 
 /* ---------------------------------------------------------------- BLSTM recurrence
  * One bidirectional LSTM layer's time recurrence (the part of nn.LSTM, reference

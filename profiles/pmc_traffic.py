@@ -18,6 +18,21 @@ KEYS = ("gemm_f32_kernel", "gemm_bf16_kernel", "lstm_fwd_kernel", "lstm_bwd_kern
         "pit_bwd", "bn_apply", "bn_bwd", "splitk_reduce", "colred", "sumsq")
 
 
+def kernel_source_id(root):
+    """The same id bench.py computes: sha256 over the HIP sources, so a stale file is recognised at run time."""
+    sys.path.insert(0, root)
+    import bench
+    return bench.kernel_source_id()
+
+
+def git_sha(root):
+    import subprocess
+    try:
+        return subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], text=True).strip()
+    except (OSError, subprocess.CalledProcessError):
+        return None
+
+
 def main():
     tag = sys.argv[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,7 +54,8 @@ def main():
     doc = {"_comment": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, profiles/collect.sh) "
                        "over `python3 bench.py [--dtype bf16] --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events` on one "
                        "MI355X; per-launch averages; FETCH_SIZE doubled per MI355X_MICROARCH.md; memory-side requests of "
-                       "the L2s (Infinity-Cache hits included).", "tag": tag, "kernels": res}
+                       "the L2s (Infinity-Cache hits included).", "tag": tag, "kernels": res,
+           "kernel_source_id": kernel_source_id(root), "git_sha": git_sha(root)}
     json.dump(doc, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
     for k, v in sorted(res.items()):
         print("%-18s n=%3d  fetch x2 %8.1f MB  write %8.1f MB" % (k, v["launches"], v["fetch_bytes_x2"] / 1e6, v["write_bytes"] / 1e6))

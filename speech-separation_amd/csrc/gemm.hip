@@ -400,6 +400,208 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs g) {
 
 }  // namespace bf
 
+// ------------------------------------------------------------------------------------------------------
+// bf16 operands IN MEMORY (r02).  C[M,N] = act(A[M,K] * B[N,K]^T + bias (+ C)) with A and B stored as bf16, both
+// K-contiguous ("NT"): the producers of the operands (sk_cast_bf16 / sk_cast_bf16_t; weights once per step) write
+// bf16 copies -- transposed where the product needs it, so that every product of the network is this one form --
+// and the GEMM moves half the bytes per operand element through L2 -> LDS, which is what capped the kernel above
+// (fp32 operands rounded on the way into LDS: one ds_read_b128 per MFMA and 2x the L2 traffic).
+// Tile 256 x BN (BN = 256 or 128), K step 64, 8 waves as 2 (M) x 4 (N), wave tile 128 x BN/4 = 8 x BN/64 MFMA tiles
+// of v_mfma_f32_16x16x32_bf16; operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging), two
+// LDS buffers, one barrier per K step: the DMA of step k+1 flies under the MFMAs of step k.
+// LDS image of a tile (rows of 64 bf16 = 128 B = 8 chunks of 16 B): chunk c of row r sits at
+//     256 * (r >> 1) + 16 * ((8 * (r & 1) + c) ^ ((r >> 1) & 7))
+// i.e. two tile rows share a 256-B bank row and the 16 slots of a bank row are XOR-rotated by the bank-row index, so
+// the 16 rows x one chunk that a ds_read_b128 fragment read touches fall into 16 different slots.  LDS-DMA writes
+// LDS lane-linearly, so the permutation is applied to the per-lane SOURCE address (cdna_hip_programming.md rule 21).
+namespace bf2 {
+
+constexpr int BM = 256, BK = 64, NT = 512;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Args {
+  const __bf16* A;
+  const __bf16* B;
+  float* C;
+  const float* bias;
+  int M, N, K, lda, ldb, ldc;
+  int accumulate, act;
+  int tilesN;
+  int splitk, kchunk;  // K range of slice y: [y * kchunk, min(K, (y + 1) * kchunk)), kchunk a multiple of BK
+  float* slabs;
+  int64_t sA, sB, sC, sbias;
+};
+
+// byte offset of (row r, 16-byte chunk c) in a tile image
+__device__ __forceinline__ int img(int r, int c) { return ((r >> 1) << 8) + (((((r & 1) << 3) | c) ^ ((r >> 1) & 7)) << 4); }
+
+// One 1 KB piece (8 tile rows) of an operand tile: which (row, chunk) lane `lane` must fetch so that the lane-linear
+// LDS write of the DMA produces the image above.
+__device__ __forceinline__ void piece_src(int piece, int lane, int& row, int& chunk) {
+  const int r2 = piece * 4 + (lane >> 4);  // bank row = tile row pair
+  const int v = (lane & 15) ^ (r2 & 7);
+  row = 2 * r2 + (v >> 3);
+  chunk = v & 7;
+}
+
+template <int BN>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(Args g) {
+  constexpr int TM = 8, TN = BN / 64;            // MFMA tiles per wave
+  constexpr int PA = BM / 8 / 8, PB = BN / 8 / 8;  // 1 KB pieces per wave per K step (A: 4, B: 4 or 2)
+  constexpr int ABYTES = BM * BK * 2, BBYTES = BN * BK * 2;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * (ABYTES + BBYTES)];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 2, wn = w & 3;
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
+    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+  }
+  int m0, n0;
+  {
+    const int tilesM = gridDim.x / g.tilesN, per = GROUP_M * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GROUP_M;
+    const int gsz = min(GROUP_M, tilesM - first);
+    m0 = (first + rem2 % gsz) * BM;
+    n0 = (rem2 / gsz) * BN;
+  }
+  const int z = blockIdx.z, ks = blockIdx.y;
+  const __bf16* A = g.A + z * g.sA;
+  const __bf16* B = g.B + z * g.sB;
+  const bool partial = g.splitk > 1;
+  float* C = partial ? g.slabs + ((int64_t)z * g.splitk + ks) * g.M * g.N : g.C + z * g.sC;
+  const int ldc = partial ? g.N : g.ldc;
+  const float* bias = (g.bias && !partial) ? g.bias + z * g.sbias : nullptr;
+  const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / BK;
+
+  // per-lane DMA sources (rows past the matrix edge are clamped: their products land in rows/cols never stored)
+  const __bf16* srcA[PA];
+  const __bf16* srcB[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    int r, c;
+    piece_src(w * PA + i, lane, r, c);
+    srcA[i] = A + (int64_t)min(m0 + r, g.M - 1) * g.lda + kbeg + c * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    int r, c;
+    piece_src(w * PB + i, lane, r, c);
+    srcB[i] = B + (int64_t)min(n0 + r, g.N - 1) * g.ldb + kbeg + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* a = lds + buf * (ABYTES + BBYTES);
+    char* b = a + ABYTES;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(a + (w * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + kt * BK),
+                                       (__attribute__((address_space(3))) void*)(b + (w * PB + i) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: lane holds row (lane & 15) of a 16-row tile, 8 consecutive k at chunk (lane >> 4) + 4 * kstep;
+  // a tile further down adds 16 rows = 2048 B (the rotation repeats every 16 rows), kstep 1 flips slot bit 2 (^ 64 B)
+  const int fa = img(wm * 128 + (lane & 15), lane >> 4);
+  const int fb = img(wn * (BN / 4) + (lane & 15), lane >> 4);
+
+  if (nk > 0) stage(0, 0);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step kt have landed ...
+    __syncthreads();                                   // ... and everybody's; all reads of the other buffer are done
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* a = lds + cur * (ABYTES + BBYTES);
+    const char* b = a + ABYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + ((fa ^ (s << 6)) + i * 2048));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(b + ((fb ^ (s << 6)) + j * 2048));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    cur ^= 1;
+  }
+
+  // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * (BN / 4) + j * 16 + (lane & 15);
+    if (col >= g.N) continue;
+    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 128 + i * 16 + 4 * (lane >> 4) + r;
+        if (row < g.M) {
+          float* cp = C + (int64_t)row * ldc + col;
+          float v = acc[i][j][r] + bv;
+          if (!partial) {
+            if (g.accumulate) v += *cp;
+            if (g.act == 1) v = sk_sigmoid(v);
+          }
+          *cp = v;
+        }
+      }
+  }
+}
+
+// fp32 (R, C) -> bf16 copy with leading dimension ldd >= C, columns C..ldd-1 zero (row-major), RNE
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, int R, int C, int lds_, __bf16* __restrict__ dst,
+                                                   int ldd) {
+  const int64_t n8 = (int64_t)R * (ldd / 8);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / (ldd / 8)), c = (int)(i % (ldd / 8)) * 8;
+    const float* s = src + (int64_t)r * lds_ + c;
+    bf16x8 v;
+    if (c + 8 <= C && ((lds_ & 3) == 0) && (((uintptr_t)src & 15) == 0)) {
+      const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
+      v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
+      v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)(c + e < C ? s[e] : 0.f);
+    }
+    *reinterpret_cast<bf16x8*>(dst + (int64_t)r * ldd + c) = v;
+  }
+}
+
+// fp32 (R, C) -> TRANSPOSED bf16 copy dst[c][r], leading dimension ldd >= R, columns R..ldd-1 zero.  64 x 64 tiles
+// through LDS: coalesced reads along C, coalesced writes along R.
+__global__ __launch_bounds__(256) void cast_t_kernel(const float* __restrict__ src, int R, int C, int lds_, __bf16* __restrict__ dst,
+                                                     int ldd) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? src[(int64_t)(r0 + r) * lds_ + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < C && r0 + r < ldd) dst[(int64_t)(c0 + c) * ldd + r0 + r] = (__bf16)tile[r][c];
+  }
+}
+
+}  // namespace bf2
+
 // C = act(sum_ks slabs[z][ks] + bias (+ C)), slices added in fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   const int z = blockIdx.z;
@@ -533,4 +735,72 @@ extern "C" int sk_gemm_bf16_splitk(const float* A, const float* B, float* C, con
                            int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
   return gemm_launch(true, A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, accumulate, act, batch, sA, sB, sC,
                      sbias, splitk, ws, stream);
+}
+
+// ---------------------------------------------------------------- bf16 operands in memory (NT form)
+extern "C" int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda,
+                               int ldb, int ldc, int accumulate, int act, int batch, int64_t sA, int64_t sB, int64_t sC,
+                               int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
+  SK_CHECK_ARG(A && B && C, "sk_gemm_bf16_nt: null pointer");
+  SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm_bf16_nt: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  SK_CHECK_ARG(K % bf2::BK == 0, "sk_gemm_bf16_nt: K = %d must be a multiple of %d (pad the bf16 copies with zero columns)", K, bf2::BK);
+  SK_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0,
+               "sk_gemm_bf16_nt: leading dimensions / batch strides must cover K and be multiples of 8 elements");
+  SK_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sk_gemm_bf16_nt: operands must be 16-byte aligned");
+  SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm_bf16_nt: bad splitk %d / missing workspace", splitk);
+  SK_CHECK_ARG(act == 0 || act == 1, "sk_gemm_bf16_nt: unknown activation %d", act);
+  bf2::Args g;
+  g.A = (const __bf16*)A; g.B = (const __bf16*)B; g.C = C; g.bias = bias;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.accumulate = accumulate; g.act = act;
+  g.sA = sA; g.sB = sB; g.sC = sC; g.sbias = sbias;
+  g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), bf2::BK) * bf2::BK);
+  splitk = (int)sk_cdiv(K, g.kchunk);
+  g.splitk = splitk;
+  g.slabs = (float*)ws;
+  // 256-wide column tiles unless N is small enough that they would leave most of the chip idle
+  const int64_t tiles256 = sk_cdiv(M, bf2::BM) * sk_cdiv(N, 256) * splitk * batch;
+  const bool wide = (N % 256 == 0 || N > 1024) && tiles256 >= 2 * 256;
+  const int bn = wide ? 256 : 128;
+  g.tilesN = (int)sk_cdiv(N, bn);
+  const int64_t tiles = sk_cdiv(M, bf2::BM) * g.tilesN;
+  SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm_bf16_nt: too many tiles");
+  dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
+  hipStream_t st = (hipStream_t)stream;
+  if (wide)
+    hipLaunchKernelGGL((bf2::gemm_bf16_nt_kernel<256>), grid, dim3(bf2::NT), 0, st, g);
+  else
+    hipLaunchKernelGGL((bf2::gemm_bf16_nt_kernel<128>), grid, dim3(bf2::NT), 0, st, g);
+  SK_CHECK_LAUNCH("sk_gemm_bf16_nt");
+  if (splitk > 1) {
+    GemmArgs r;
+    r.A = nullptr; r.B = nullptr; r.C = C; r.bias = bias;
+    r.M = M; r.N = N; r.K = K; r.lda = 0; r.ldb = 0; r.ldc = ldc;
+    r.accumulate = accumulate; r.act = act; r.vecA = r.vecB = 0; r.tilesN = g.tilesN;
+    r.splitk = splitk; r.kchunk = g.kchunk; r.slabs = (float*)ws;
+    r.sA = 0; r.sB = 0; r.sC = sC; r.sbias = sbias;
+    const int64_t quads = sk_cdiv((int64_t)M * N, 4);
+    const unsigned nb = (unsigned)(sk_cdiv(quads, 256) > 2048 ? 2048 : sk_cdiv(quads, 256));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb, 1, (unsigned)batch), dim3(256), 0, st, r);
+    SK_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return SK_OK;
+}
+
+extern "C" int sk_cast_bf16(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream) {
+  SK_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C && ld_dst % 8 == 0 && ((uintptr_t)dst % 16) == 0,
+               "sk_cast_bf16: bad arguments");
+  const int64_t n8 = (int64_t)R * (ld_dst / 8);
+  const unsigned nb = (unsigned)(sk_cdiv(n8, 256) > 4096 ? 4096 : sk_cdiv(n8, 256));
+  hipLaunchKernelGGL(bf2::cast_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, R, C, ld_src, (__bf16*)dst, ld_dst);
+  SK_CHECK_LAUNCH("sk_cast_bf16");
+  return SK_OK;
+}
+
+extern "C" int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream) {
+  SK_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= R, "sk_cast_bf16_t: bad arguments");
+  dim3 grid((unsigned)sk_cdiv(ld_dst, 64), (unsigned)sk_cdiv(C, 64));
+  hipLaunchKernelGGL(bf2::cast_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, R, C, ld_src, (__bf16*)dst, ld_dst);
+  SK_CHECK_LAUNCH("sk_cast_bf16_t");
+  return SK_OK;
 }

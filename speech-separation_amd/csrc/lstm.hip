@@ -242,6 +242,7 @@ constexpr int GMAX = 8;
 //   map 2: as 1 for pairs of streams: XCD group g hosts streams 2g and 2g+1, the first half of every XCD's run one
 //          stream and the second half the other (two workgroups that share a CU then belong to different streams).
 __device__ __forceinline__ void decode_block(int L, int NUG, int nby, int map, int& ug, int& by, int& dir) {
+  map &= 3;
   const int S = nby * 2, total = NUG * S;
   int stream, u;
   const int x = L & 7, j = L >> 3, per_xcd = total >> 3;
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   __syncthreads();
   SK_STAMP_DECL
 
+  if (a.opt & 4) __builtin_amdgcn_s_setprio(3);  // option: win issue arbitration against co-resident GEMM waves
   bool aborted = false;
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? T - 1 - s : s;
@@ -715,6 +717,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   SK_STAMP_DECL
 
   if (owner) *reinterpret_cast<f32x4*>(&st_db[oi][0]) = f32x4{0.f, 0.f, 0.f, 0.f};  // read and written by the same lane only
+  if (a.map & 4) __builtin_amdgcn_s_setprio(3);  // option (bit 2 of the map field): raised static wave priority
   bool aborted = false;
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
@@ -940,7 +943,7 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 22) == 0,
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 23) == 0,
                "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
@@ -966,7 +969,8 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   const bool bf = (mode >> 16) & 1;     // bit 16: bf16 matrix-core inputs
   const bool half = (mode >> 17) & 1;   // bit 17: 8-unit, 256-thread workgroups, two per CU
   const int map = (mode >> 18) & 3;     // bits 18..19: block id -> stream assignment (speed only)
-  const int opt = (mode >> 20) & 3;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD
+  const int opt = (mode >> 20) & 7;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD;
+                                        // bit 22: raised static wave priority
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -1015,7 +1019,9 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   if (rc) return rc;
   const int gmin = (mode >> 8) & 0xff;
   const bool bf = (mode >> 16) & 1;
-  const int map = (mode >> 18) & 3;  // as sk_lstm_fwd; flag replication was measured here too (7.59 -> 7.50 us/step) and not kept
+  // block map as sk_lstm_fwd (+4: raised static wave priority, mode bit 22); flag replication was measured here too
+  // (7.59 -> 7.50 us/step) and not kept
+  const int map = ((mode >> 18) & 3) | (((mode >> 22) & 1) << 2);
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;

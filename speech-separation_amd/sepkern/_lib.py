@@ -13,7 +13,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEPKERN_LIB") or os.path.join(_HERE, "libsepkern.so")   # SEPKERN_LIB: diagnostic builds
 
-SK_VERSION = 101
+SK_VERSION = 102
 
 _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -28,6 +28,9 @@ PROTOTYPES = {
     "sk_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sk_gemm_f32_splitk": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "sk_gemm_bf16_splitk": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
+    "sk_gemm_bf16_nt": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
+    "sk_cast_bf16": (_i, [_p, _i, _i, _i, _p, _i, _p]),
+    "sk_cast_bf16_t": (_i, [_p, _i, _i, _i, _p, _i, _p]),
     "sk_lstm_workspace_bytes": (_sz, [_i, _i, _i]),
     "sk_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

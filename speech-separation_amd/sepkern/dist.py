@@ -65,10 +65,21 @@ def global_norm(lens, feat_dim):
     return t
 
 
+# bench.py: TIMING = [] makes allreduce_grads record a (start, end) HIP-event pair per call on the current stream
+TIMING = None
+
+
 def allreduce_grads(flat_grad):
     """Sum the flat gradient buffer over ranks in place (one collective over xGMI)."""
     if is_parallel():
-        dist.all_reduce(flat_grad)
+        if TIMING is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(flat_grad)
+            e1.record()
+            TIMING.append((e0, e1))
+        else:
+            dist.all_reduce(flat_grad)
     return flat_grad
 
 

@@ -125,6 +125,69 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
                   int(transB), int(accumulate), int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws), _stream())
 
 
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def cast_bf16(x2d, ld=None, out=None):
+    """bf16 copy of an fp32 (R, C) matrix (row stride x2d.stride(0)), leading dimension ld >= C (default: C rounded
+    up to 64), extra columns zero.  Returns the (R, ld) bfloat16 tensor."""
+    _chk(x2d)
+    R, Cc = x2d.shape
+    ld = pad_to(Cc, 64) if ld is None else ld
+    if out is None:
+        out = torch.empty(R, ld, dtype=torch.bfloat16, device=x2d.device)
+    _lib.call("sk_cast_bf16", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(out), ld, _stream())
+    return out
+
+
+def cast_bf16_t(x2d, ld=None, out=None):
+    """TRANSPOSED bf16 copy (C, ld) of an fp32 (R, C) matrix, ld >= R (default: R rounded up to 64, plus 64 zero
+    columns so that a product may start a few rows in and still read zeros past the end)."""
+    _chk(x2d)
+    R, Cc = x2d.shape
+    ld = pad_to(R, 64) + 64 if ld is None else ld
+    if out is None:
+        out = torch.empty(Cc, ld, dtype=torch.bfloat16, device=x2d.device)
+    _lib.call("sk_cast_bf16_t", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(out), ld, _stream())
+    return out
+
+
+def gemm_bf16_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, accumulate=False, act=0, batch=1, sA=0, sB=0, sC=0,
+                 sbias=0, splitk=1, ws_tag="gemm"):
+    """Cout[M,N] = act(A[M,K] B[N,K]^T + bias (+ Cout)) with A, B bfloat16 tensors (K-contiguous, K % 64 == 0)."""
+    _chk(A, torch.bfloat16)
+    _chk(B, torch.bfloat16)
+    _chk(Cout)
+    _chk(bias)
+    if splitk == 0:
+        splitk = pick_splitk_bf16(M, N, K, batch)
+    ws = None
+    if splitk > 1:
+        ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
+    with _timed("gemm_bf16_nt_kernel", 2.0 * M * N * K * batch):
+        _lib.call("sk_gemm_bf16_nt", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(accumulate),
+                  int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws), _stream())
+
+
+def pick_splitk_bf16(M, N, K, batch=1):
+    """K slices for the 256 x 256-tile bf16 kernel (one block per CU): enough blocks to fill the chip about twice,
+    slices of at least 1024."""
+    global _NUM_CUS
+    if _NUM_CUS is None:
+        _NUM_CUS = device_info()[0]
+    tiles = ((M + 255) // 256) * ((N + 255) // 256) * batch
+    best, best_t = 1, None
+    for s in range(1, 17):
+        if K // s < 1024 and s > 1:
+            break
+        rounds = -(-(tiles * s) // _NUM_CUS)
+        t = rounds / s + (0.0 if s == 1 else 0.02 * s)       # time ~ rounds x K/s, plus the slab round trip
+        if best_t is None or t < best_t * 0.98:
+            best, best_t = s, t
+    return best
+
+
 # ----------------------------------------------------------------------------- STFT / iSTFT
 def _i64(vals, device):
     return torch.tensor(vals, dtype=torch.int64, device=device)
@@ -368,9 +431,10 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
-def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False):
-    """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..21)."""
-    return (0x20000 if half else 0) | ((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) | (0x200000 if repflags else 0)
+def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, prio=False):
+    """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..22)."""
+    return ((0x20000 if half else 0) | ((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) |
+            (0x200000 if repflags else 0) | (0x400000 if prio else 0))
 
 
 def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0):

@@ -186,7 +186,7 @@ def resume(model, optimizer, run, args):
 def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
   """One pass over this rank's batches.  Returns the device tensor [sum(loss * norm), sum(norm)] of the GLOBAL
   epoch (all-reduced), still un-synchronised."""
-  acc = torch.zeros(2, device="cuda", dtype=torch.float64)
+  acc = torch.zeros(2, device=next(model.parameters()).device, dtype=torch.float64)
   for batch in batches:
     loss, norm = m.compute_loss(model, epoch, batch)
     acc[0] += loss.detach().double() * norm.double()
@@ -204,7 +204,7 @@ def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
 def validation_pass(m, model, batches, epoch, world, plot_dir):
   """Eval-mode pass over this rank's shard of the CV set; no collective inside (the arch keeps its local norm
   when not training).  Returns the global [sum(loss * norm), sum(norm)]."""
-  acc = torch.zeros(2, device="cuda", dtype=torch.float64)
+  acc = torch.zeros(2, device=next(model.parameters()).device, dtype=torch.float64)
   model.eval()
   with torch.no_grad():
     for i, batch in enumerate(batches):

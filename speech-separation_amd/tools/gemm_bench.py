@@ -23,7 +23,37 @@ SHAPES = [  # name, M, N, K, transA, transB, batch, splitk
 ]
 
 
+def bench_nt():
+    """The bf16-operands-in-memory kernel (sk_gemm_bf16_nt) on the same products, every one in NT form."""
+    S3 = 771
+    shapes = [("fwd  L1/2", R, 8 * H, 2 * H, 1, 1), ("fwd  L0 K=257->320", R, 8 * H, 320, 1, 1), ("fwd  lin N=771", R, S3, 2 * H, 1, 1),
+              ("dgrad L1/2", R, 2 * H, 8 * H, 1, 1), ("dgrad lin K=771->832", R, 2 * H, 832, 1, 1),
+              ("wgrad Wih", 8 * H, 2 * H, R, 1, 0), ("wgrad Whh batch2", 4 * H, H, R, 2, 0), ("wgrad Wih0 N=257", 8 * H, F, R, 1, 0),
+              ("wgrad lin M=771", S3, 2 * H, R, 1, 0), ("square 4096", 4096, 4096, 4096, 1, 1), ("square 8192", 8192, 8192, 8192, 1, 1)]
+    for name, M, N, K, batch, sk in shapes:
+        A = (torch.randn(M * batch, K, device="cuda")).bfloat16()
+        B = (torch.randn(N * batch, K, device="cuda")).bfloat16()
+        C = torch.empty(batch, M, N, device="cuda")
+        used = ops.pick_splitk_bf16(M, N, K, batch) if sk == 0 else sk
+        kw = dict(batch=batch, sA=M * K, sB=N * K, sC=M * N, splitk=used)
+        for _ in range(2):
+            ops.gemm_bf16_nt(A, B, C, M, N, K, K, K, N, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = 10
+        e0.record()
+        for _ in range(n):
+            ops.gemm_bf16_nt(A, B, C, M, N, K, K, K, N, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        print("NT %-22s M=%6d N=%5d K=%6d b=%d splitk=%2d  %8.3f ms  %7.1f TFLOP/s" %
+              (name, M, N, K, batch, used, ms, 2.0 * M * N * K * batch / ms / 1e9), flush=True)
+
+
 def main():
+    if "--nt" in sys.argv:
+        return bench_nt()
     bf16 = "--bf16" in sys.argv
     for name, M, N, K, tA, tB, batch, sk in SHAPES:
         A = torch.randn((K, M * batch) if tA else (M, K), device="cuda")

@@ -5,6 +5,7 @@ fall monotonically-ish and stay finite, in fp32 and in bf16 arithmetic, with the
 import contextlib
 import os
 import sys
+import time
 
 import torch
 
@@ -19,10 +20,10 @@ from sepkern.optim import ClipAdam  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    for dt in ("fp32", "bf16"):
+    for dtype in ("fp32", "bf16"):
         torch.manual_seed(0)
         with contextlib.redirect_stdout(sys.stderr):
-            model = uPIT.SepDNN(0, num_spk="2", hidden_dim="896", num_layers="3", dtype=dt)
+            model = uPIT.SepDNN(0, num_spk="2", hidden_dim="896", num_layers="3", dtype=dtype)
         model.cuda()
         model.train()
         model.hidden_generator = torch.Generator(device="cuda")
@@ -30,15 +31,25 @@ def main():
         opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
         mix, srcs, lens, _ = bench.make_batch(torch, ops, synth, 32, 400, 2, 0)
         out = []
+        acc = torch.zeros(1, device="cuda")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
         for i in range(steps):
             loss, norm = uPIT.compute_loss_padded(model, mix, srcs, lens)
             loss.backward()
             opt.step()
             if i % 20 == 0 or i == steps - 1:
-                out.append("%d:%.5f" % (i, float(loss)))
+                out.append((i, loss.detach().clone()))          # no host sync inside the timed loop
+        torch.cuda.synchronize()
+        secs = time.perf_counter() - t0
         v = float(loss)
         assert v == v and v > 0
-        print("%s  loss by step  %s" % (dt, "  ".join(out)), flush=True)
+        opt.check()
+        frames = int(lens.sum().item()) * steps
+        print("%s  loss by step  %s" % (dtype, "  ".join("%d:%.5f" % (i, float(l)) for i, l in out)), flush=True)
+        # the bench times 20 steps (0.8 s); this is the same step sustained for `steps` steps (clocks settle)
+        print("%s  sustained: %d steps in %.2f s = %.3f ms/step = %.1f frames/s" % (dtype, steps, secs, 1e3 * secs / steps,
+                                                                             frames / secs), flush=True)
 
 
 if __name__ == "__main__":

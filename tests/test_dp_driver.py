@@ -1,0 +1,134 @@
+"""Host logic of data-parallel training (steps/train_qsub.py + sepkern/dist.py) on CPU over gloo, with a CPU stand-in
+arch (tests/_cpu_arch.py): replicas are broadcast from rank 0, every rank runs the same number of steps on
+length-balanced shards, the epoch loss / CV loss / weights equal a single process on the same global batches."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+TESTS = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_epoch_shards_cover_the_set_with_equal_steps_and_balanced_frames():
+    sys.path.insert(0, PKG)
+    from sepkern import dist as skdist
+    rng = np.random.default_rng(0)
+    for n, bs, world in ((201, 100, 2), (64, 4, 8), (3, 100, 4), (37, 5, 3), (16, 2, 1)):
+        lengths = [int(v) for v in rng.integers(190, 500, n)]
+        shards = [skdist.EpochShards(n, bs, r, world, lengths=lengths, seed=7) for r in range(world)]
+        for epoch in (0, 1):
+            per_rank = []
+            for s in shards:
+                s.set_epoch(epoch)
+                per_rank.append(list(s))
+            steps = {len(b) for b in per_rank}
+            assert steps == {len(shards[0])} == {-(-n // (bs * world))}          # same step count on every rank
+            seen = [i for b in per_rank for step in b for i in step]
+            assert set(seen) == set(range(n))                                     # every utterance, every epoch
+            assert len(seen) - n == max(0, world - (n - (len(shards[0]) - 1) * bs * world))   # top-up only when short
+            for k in range(len(shards[0])):
+                sizes = [len(per_rank[r][k]) for r in range(world)]
+                assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1 and max(sizes) <= bs
+                if min(sizes) >= 4:
+                    frames = [sum(lengths[i] for i in per_rank[r][k]) for r in range(world)]
+                    assert max(frames) <= 1.15 * min(frames)                     # the slowest rank sets the step
+        a, b = shards[0], shards[0]
+        a.set_epoch(0)
+        e0 = list(a)
+        b.set_epoch(1)
+        assert n < 8 or list(b) != e0                                             # reshuffled between epochs
+    assert skdist.shard_indices_contiguous(3, 3, 4) == [] or skdist.shard_indices_contiguous(3, 3, 4) == [2]
+    got = sorted(i for r in range(4) for i in skdist.shard_indices_contiguous(3, r, 4))
+    assert got == [0, 1, 2]                                                       # one rank gets an empty CV shard
+
+
+def _worker(rank, world, port, n, bs, q):
+    for p in (ROOT, PKG, TESTS, os.path.join(PKG, "steps")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    import _cpu_arch as m
+    import train_qsub as drv
+    from sepkern import dist as skdist
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                          LOCAL_RANK=str(rank), SEPKERN_DIST_BACKEND="gloo")
+        skdist.init_from_env()
+    m.configure(n, 3)
+    torch.manual_seed(1000 + 77 * rank)                  # NO common seed: every rank draws different initial weights
+    model = m.SepDNN(0)
+    model.train()
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    skdist.broadcast_model(model)
+    opt = m.SummingAdam(model, 1e-2)
+    ds = m.TrainSet("train")
+    # rank r of `world` with per-rank batch bs == one process with batch bs * world on the same global batches
+    shards = skdist.EpochShards(len(ds), bs if world > 1 else bs * q["ref_world"], rank, world,
+                                lengths=ds.frame_counts(), seed=5)
+    loader = torch.utils.data.DataLoader(ds, batch_sampler=shards, collate_fn=ds.collator)
+    losses = []
+    for epoch in range(2):
+        shards.set_epoch(epoch)
+        acc = drv.train_epoch(m, model, opt, loader, epoch, world, False)
+        losses.append(float(acc[0] / acc[1]))
+    cv_ds = m.TrainSet("cv")
+    idx = skdist.shard_indices_contiguous(len(cv_ds), rank, world)
+    cv_batches = torch.utils.data.DataLoader(torch.utils.data.Subset(cv_ds, idx), batch_size=3,
+                                             collate_fn=cv_ds.collator) if idx else []
+    cv = drv.validation_pass(m, model, cv_batches, 1, world, "")
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    q["out"].put((rank, losses, float(cv[0] / cv[1]), flat.numpy(), float((before - flat).abs().max())))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run(world, n, bs, ref_world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, bs, {"out": out, "ref_world": ref_world}))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world,n,bs,exact", [(2, 23, 5, True), (4, 13, 2, True), (2, 21, 5, False), (4, 11, 2, False)])
+def test_dp_training_equals_single_process_on_the_same_global_batches(world, n, bs, exact):
+    """The last global batch is short in every case -- 23 = 2*10 + 3 and 13 = 8 + 5 deal unequal shard sizes; 21 and 11
+    leave fewer utterances than ranks, which are topped up (one utterance is then seen twice in that epoch, so only
+    "every rank runs the same steps and ends with identical weights" is asserted there).  4 ranks over an
+    11..13-utterance CV set with batch 3 run different numbers of CV batches."""
+    dp = _run(world, n, bs, world)
+    for rank, losses, cv, flat, moved in dp:
+        np.testing.assert_array_equal(flat, dp[0][3])                 # replicas identical, without any common seed
+        assert np.all(np.isfinite(losses)) and (rank == 0 or moved > 0)
+    # the single process draws the weights rank 0 drew (seed 1000 + 77 * 0)
+    one = _run(1, n, bs, world)[0]
+    for rank, losses, cv, flat, moved in dp:
+        if exact:
+            np.testing.assert_allclose(losses, one[1], rtol=2e-5)
+            np.testing.assert_allclose(cv, one[2], rtol=1e-5)         # CV loss is NOT divided by the world size
+            np.testing.assert_allclose(flat, one[3], rtol=2e-3, atol=2e-5)
+        else:
+            np.testing.assert_allclose(losses, one[1], rtol=5e-2)     # same data but for the duplicated utterance

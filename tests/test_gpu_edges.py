@@ -1,5 +1,6 @@
 """Edge cases (minimal and ragged sizes, ties, segments) and size-independent properties at BASELINE's full
-configuration (3x896, 2 speakers, batch 32 x 400 frames), where the oracle is too slow to run."""
+configuration (3x896, 2 speakers, batch 32 x 400 frames).  The HIP-vs-oracle comparison at that size is in
+tests/test_gpu_fullsize.py."""
 import itertools
 import os
 import subprocess

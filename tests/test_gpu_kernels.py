@@ -405,3 +405,57 @@ def test_lstm_layer_bf16_matches_bf16_oracle(ops, mode, T, B, H, I, lens):
     assert torch.isfinite(dgx).all()
     for d in range(2):
         close(dgx[:, d].sum(0), wr[0][d][2].grad, "db dir %d" % d)     # column sums of dG = bias gradient
+
+
+# ----------------------------------------------------------------------------- bf16 operands in memory (r02)
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 200, 257), (1000, 771, 1792), (513, 1300, 320), (50, 7168, 128)])
+def test_gemm_bf16_nt_equals_fp64_product_of_rounded_operands(ops, M, N, K):
+    """sk_cast_bf16 + sk_gemm_bf16_nt: bf16 x bf16 products are exact in fp32, so against the fp64 product of the
+    ROUNDED operands only the fp32 accumulation order differs (the fp32 kernel's tolerance).  Ragged M / N (clamped
+    edge tiles), K padded to 64 with zero columns, bias + sigmoid epilogue."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    Ab, Bb = ops.cast_bf16(dev(A)), ops.cast_bf16(dev(B))
+    Kp = Ab.shape[1]
+    assert Kp % 64 == 0 and Kp >= K and Ab.dtype == torch.bfloat16
+    np.testing.assert_array_equal(Ab[:, :K].float().cpu().numpy(), A.bfloat16().float().numpy())   # RNE, as torch rounds
+    assert float(Ab[:, K:].float().abs().sum()) == 0.0
+    C = torch.full((M, N), float("nan")).cuda()
+    ops.gemm_bf16_nt(Ab, Bb, C, M, N, Kp, Kp, Kp, N, bias=dev(bias))
+    ref = A.bfloat16().double() @ B.bfloat16().double().t() + bias.double()
+    err = float((C.cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    ops.gemm_bf16_nt(Ab, Bb, C, M, N, Kp, Kp, Kp, N, bias=dev(bias), act=1)
+    np.testing.assert_allclose(C.cpu().numpy(), torch.sigmoid(ref).float().numpy(), atol=2e-6)
+
+
+def test_gemm_bf16_nt_splitk_batch_accumulate_and_transposed_copy(ops):
+    """The weight-gradient form: A and B are TRANSPOSED bf16 copies (sk_cast_bf16_t) of (R, M) and (R, N) matrices,
+    K = R split into slabs, a batch of 2 with strides, accumulation into C; bitwise reproducible."""
+    g = torch.Generator().manual_seed(7)
+    R, M, N = 1000, 300, 140
+    X, Y = torch.randn(R, 2 * M, generator=g), torch.randn(R, 2 * N, generator=g)
+    Xt, Yt = ops.cast_bf16_t(dev(X)), ops.cast_bf16_t(dev(Y))
+    ld = Xt.shape[1]
+    assert Xt.shape == (2 * M, ld) and ld % 64 == 0 and ld >= R + 64
+    np.testing.assert_array_equal(Xt[:, :R].float().cpu().numpy(), X.t().bfloat16().float().numpy())
+    assert float(Xt[:, R:].float().abs().sum()) == 0.0
+    C0 = torch.randn(2, M, N, generator=g)
+    Kp = ops.pad_to(R, 64)
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        ops.gemm_bf16_nt(Xt, Yt, C, M, N, Kp, ld, ld, N, accumulate=True, batch=2, sA=M * ld, sB=N * ld, sC=M * N, splitk=3)
+        outs.append(C.clone())
+    assert torch.equal(outs[0], outs[1])
+    for z in range(2):
+        ref = C0[z].double() + X[:, z * M:(z + 1) * M].bfloat16().double().t() @ Y[:, z * N:(z + 1) * N].bfloat16().double()
+        err = float((outs[0][z].cpu().double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (z, err)
+    # a product that starts B rows into the copies still sees zeros past the end (the time-shifted dW_hh product)
+    C = torch.zeros(M, N).cuda()
+    off = 32
+    ops.gemm_bf16_nt(Xt[:, off:], Yt, C, M, N, Kp, ld, ld, N)
+    ref = X[off:, :M].bfloat16().double().t() @ Y[:R - off, :N].bfloat16().double()
+    assert float((C.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
