@@ -72,6 +72,10 @@ class Engine:
         # gradients) rounds both operands to bf16 on the way into the matrix cores and accumulates in fp32;
         # parameters, activations, cell state, gradients, BatchNorm, the loss and Adam stay fp32.
         self.precision, self.bf16 = precision, precision == "bf16"
+        # bf16 products read bf16 COPIES of their operands (sk_cast_bf16 / sk_cast_bf16_t, transposed where the product
+        # needs it so that every product is the one NT form of sk_gemm_bf16_nt); SEPKERN_BF16_NT=0 keeps the r01 kernel
+        # that reads fp32 operands and rounds them on the way into LDS (same arithmetic, half the speed)
+        self.nt = self.bf16 and os.environ.get("SEPKERN_BF16_NT", "1") == "1"
         # data-parallel runs only: BatchNorm over the GLOBAL batch instead of per rank (sepkern/dist.py)
         self.sync_bn = bool(sync_bn) or os.environ.get("SEPKERN_SYNC_BN", "0") == "1"
         if hidden % 4 != 0 or hidden > 1024:
@@ -125,6 +129,62 @@ class Engine:
         last check.  Training does not need it per step -- see `guard` -- drivers call it at epoch / checkpoint time."""
         ops.lstm_status(ops.workspace(0, "lstm"))
 
+    # ------------------------------------------------------------------ the three kinds of product
+    # fp32: the fp32 MFMA kernel on the fp32 tensors.  bf16: sk_gemm_bf16_nt on bf16 copies; `cache` (one dict per
+    # pass) holds the copies already made, keyed by (kind, id of the fp32 tensor), and keeps them alive.
+    @staticmethod
+    def _copy(cache, kind, t2d):
+        key = (kind, t2d.data_ptr(), tuple(t2d.shape))
+        if key not in cache:
+            cache[key] = ops.cast_bf16(t2d) if kind == "row" else ops.cast_bf16_t(t2d)
+        return cache[key]
+
+    def _proj(self, cache, inp2d, w, out2d, bias, act=0):
+        """out (R, N) = act(inp (R, K) w (N, K)^T + bias)."""
+        R, K = inp2d.shape
+        N = w.shape[0]
+        if not self.nt:
+            ops.gemm(inp2d, w, out2d, R, N, K, inp2d.stride(0), K, N, transB=True, bias=bias, act=act, bf16=self.bf16)
+            return
+        a, b = self._copy(cache, "row", inp2d), self._copy(cache, "row", w)
+        ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act)
+
+    def _dgrad(self, cache, dout2d, w, out2d, ws_tag):
+        """out (R, K) = dout (R, N) w (N, K)."""
+        R, N = dout2d.shape
+        K = w.shape[1]
+        if not self.nt:
+            ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=0, ws_tag=ws_tag, bf16=self.bf16)
+            return
+        a, bt = self._copy(cache, "row", dout2d), self._copy(cache, "t", w)      # w^T: (K, N padded)
+        ops.gemm_bf16_nt(a, bt, out2d, R, K, a.shape[1], a.shape[1], bt.shape[1], K, splitk=0, ws_tag=ws_tag)
+
+    def _wgrad(self, cache, dout2d, inp2d, gw, acc, ws_tag):
+        """gw (N, K) [+]= dout (R, N)^T inp (R, K)."""
+        R, N = dout2d.shape
+        K = inp2d.shape[1]
+        if not self.nt:
+            ops.gemm(dout2d, inp2d, gw, N, K, R, N, inp2d.stride(0), K, transA=True, accumulate=acc, splitk=0,
+                     ws_tag=ws_tag, bf16=self.bf16)
+            return
+        at, bt = self._copy(cache, "t", dout2d), self._copy(cache, "t", inp2d)    # (N, R padded), (K, R padded)
+        ops.gemm_bf16_nt(at, bt, gw, N, K, ops.pad_to(R, 64), at.shape[1], bt.shape[1], K, accumulate=acc, splitk=0,
+                         ws_tag=ws_tag)
+
+    def _whh_grad(self, cache, dgx2d, y2d, h0, dg_first, gw, T, B, acc, ws_tag):
+        """dW_hh (2,4H,H) [+]= sum_t dG_t^T h_prev(t) (ops.lstm_whh_grad); in bf16 from the transposed copies: the time
+        shift is an offset of B columns into one of them, and the copies end in >= 64 zero columns."""
+        H = self.H
+        if not (self.nt and T > 1 and B % 8 == 0):
+            ops.lstm_whh_grad(dgx2d, y2d, h0, dg_first, gw, T, B, H, accumulate=acc, bf16=self.bf16, ws_tag=ws_tag)
+            return
+        at, bt = self._copy(cache, "t", dgx2d), self._copy(cache, "t", y2d)       # (8H, ld), (2H, ld)
+        ld = at.shape[1]
+        ops.gemm_bf16_nt(at.view(-1)[B:], bt, gw, 4 * H, H, ops.pad_to((T - 1) * B, 64), ld, ld, H, accumulate=acc, batch=2,
+                         sA=4 * H * ld - B, sB=H * ld + B, sC=4 * H * H, splitk=0, ws_tag=ws_tag)
+        ops.gemm(dg_first, h0, gw, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=True, batch=2, sA=B * 4 * H, sB=B * H,
+                 sC=4 * H * H, ws_tag=ws_tag, bf16=True)
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, lens, h0, c0, training, save, want_state=False):
         """x (T,B,in_dim) fp32, lens int32 (B) on device, h0/c0 (2L,B,H) ->
@@ -138,6 +198,7 @@ class Engine:
         x = x.contiguous()
         dev = x.device
         saved = []
+        cache = {}
         inp, I = x, I0
         ws = None
         hn = torch.empty(2 * L, B, H, device=dev) if want_state else None
@@ -150,7 +211,7 @@ class Engine:
             bsum = torch.empty(8 * H, device=dev)
             ops.colsum(self.flat[off_ih:], 2, 8 * H, 8 * H, bsum)
             gx = torch.empty(T, B, 2, 4 * H, device=dev)
-            ops.gemm(inp, wih, gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum, bf16=self.bf16)
+            self._proj(cache, inp.view(R, I), wih.view(8 * H, I), gx.view(R, 8 * H), bsum)
             y = torch.empty(T, B, 2 * H, device=dev)
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
             ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
@@ -174,8 +235,7 @@ class Engine:
         xbn = torch.empty(R, 2 * H, device=dev)
         ops.bn_apply(y2d, mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
         mask = torch.empty(T, B, O, device=dev)
-        ops.gemm(xbn, self.p("lin.weight"), mask, R, O, 2 * H, 2 * H, 2 * H, O, transB=True,
-                 bias=self.p("lin.bias"), act=1, bf16=self.bf16)
+        self._proj(cache, xbn, self.p("lin.weight"), mask.view(R, O), self.p("lin.bias"), act=1)
         ctx = None
         if save:
             ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, mask=mask, lens=lens, h0=h0, c0=c0,
@@ -210,16 +270,17 @@ class Engine:
         keep = []                                        # tensors used on the side stream stay alive until the join
         dz = torch.empty_like(dmask)
         ops.sigmoid_bwd(dmask, ctx["mask"], dz)
+        cache = {}                                       # bf16 operand copies of this pass (see _copy)
+        dz2d = dz.view(R, O)
         dxbn = torch.empty(R, 2 * H, device=dev)
-        ops.gemm(dz, self.p("lin.weight"), dxbn, R, 2 * H, O, O, 2 * H, 2 * H, bf16=self.bf16)
+        self._dgrad(cache, dz2d, self.p("lin.weight"), dxbn, "gemm")
         # the Linear layer's own gradients are needed by nobody before clip+Adam: side stream, next to the top
         # layer's recurrence
         stream = self.side if overlap else main
         if stream is not main:
             stream.wait_stream(main)
         with torch.cuda.stream(stream):
-            ops.gemm(dz, ctx["xbn"], self.g("lin.weight"), O, 2 * H, R, O, 2 * H, 2 * H, transA=True, accumulate=acc,
-                     splitk=0, ws_tag="gemm_side" if overlap else "gemm", bf16=self.bf16)
+            self._wgrad(cache, dz2d, ctx["xbn"], self.g("lin.weight"), acc, "gemm_side" if overlap else "gemm")
             ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc, ws_tag="bn_side" if overlap else "bn")
             keep.append(dz)
         del dz
@@ -258,21 +319,22 @@ class Engine:
                               bf16=self.bf16, dbias=dbias, dg_first=dg_first)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, I, device=dev)
-                ops.gemm(dgx, self.p("weight_ih_l%d" % l), dy_next, R, I, 8 * H, 8 * H, I, I, splitk=0,
-                         ws_tag="gemm_dgrad", bf16=self.bf16)
+                self._dgrad(cache, dgx.view(R, 8 * H), self.p("weight_ih_l%d" % l).view(8 * H, I), dy_next, "gemm_dgrad")
                 if l == 0:
                     dx = dy_next.view(T, B, I)
             stream = self.side if (overlap and l > 0) else main
             if stream is not main:
                 stream.wait_stream(main)
+            elif overlap:
+                main.wait_stream(self.side)      # layer 0 reuses operand copies the side stream made for layer 1
             with torch.cuda.stream(stream):
                 tag = "side" if stream is not main else "main"
                 # dW_hh[d] = sum_t dG_t^T h_prev(t): the layer output shifted by one step in time (+ the h0 steps)
-                ops.lstm_whh_grad(dgx, y, h0[sl], dg_first, self.g("weight_hh_l%d" % l), T, B, H, accumulate=acc,
-                                  bf16=self.bf16, ws_tag="gemm_" + tag)
+                self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, self.g("weight_hh_l%d" % l),
+                               T, B, acc, "gemm_" + tag)
                 # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
-                ops.gemm(dgx, inp, self.g("weight_ih_l%d" % l), 8 * H, I, R, 8 * H, I, I, transA=True, accumulate=acc,
-                         splitk=0, ws_tag="gemm_" + tag, bf16=self.bf16)
+                self._wgrad(cache, dgx.view(R, 8 * H), inp.view(R, I), self.g("weight_ih_l%d" % l).view(8 * H, I), acc,
+                            "gemm_" + tag)
                 db = torch.empty(8 * H, device=dev)
                 ops.colsum(dbias, nbg, 8 * H, 8 * H, db, ws_tag="bn_" + tag)       # a few rows: the kernel did the sums
                 put("bias_ih_l%d" % l, db.view(2, 4 * H))
@@ -282,7 +344,7 @@ class Engine:
                 dy = dy_next
         if overlap:
             main.wait_stream(self.side)
-        del keep
+        del keep, cache
         self.guard.copy_(ops.lstm_sticky(ws))      # int32 -> float: non-zero = this step's gradients are garbage
         self.grads_fresh = False
         return dx, dh0, dc0

@@ -427,7 +427,7 @@ def test_gemm_bf16_nt_equals_fp64_product_of_rounded_operands(ops, M, N, K):
     err = float((C.cpu().double() - ref).abs().max() / ref.abs().max())
     assert err < 2e-6, err
     ops.gemm_bf16_nt(Ab, Bb, C, M, N, Kp, Kp, Kp, N, bias=dev(bias), act=1)
-    np.testing.assert_allclose(C.cpu().numpy(), torch.sigmoid(ref).float().numpy(), atol=2e-6)
+    np.testing.assert_allclose(C.cpu().numpy(), torch.sigmoid(ref).float().numpy(), atol=2e-5)   # pre-activations of O(sqrt(K))
 
 
 def test_gemm_bf16_nt_splitk_batch_accumulate_and_transposed_copy(ops):
