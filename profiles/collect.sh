@@ -10,8 +10,10 @@ python3 $R/bench.py > $O/bench_$tag.json 2> $O/bench_$tag.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_${tag}_trace.json 2> $O/prof_${tag}_trace.err || exit 2
 for dt in f32 bf16; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_${tag}_${dt}_$c -- python3 $R/bench.py --dtype $dt --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2> $O/prof_${tag}_${dt}_$c.err || exit 3
+    spk=2; [ $dt = bf16 ] && spk=3      # BASELINE configs[3]: the bf16 configuration has 3 speakers
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/prof_${tag}_${dt}_$c -- python3 $R/bench.py --dtype $dt --num-spk $spk --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2> $O/prof_${tag}_${dt}_$c.err || exit 3
   done
 done
-python3 $R/bench.py --dtype bf16 --no-cpu-baseline > $O/bench_${tag}_bf16.json 2> $O/bench_${tag}_bf16.err || exit 4
+python3 $R/bench.py --dtype bf16 --num-spk 3 --steps 20 --no-cpu-baseline > $O/bench_${tag}_bf16.json 2> $O/bench_${tag}_bf16.err || exit 4
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${tag}_bf16_trace -- python3 $R/bench.py --dtype bf16 --num-spk 3 --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_${tag}_bf16_trace.json 2> $O/prof_${tag}_bf16_trace.err || exit 5
 echo collected $tag

@@ -14,8 +14,9 @@ import json
 import os
 import sys
 
-KEYS = ("gemm_f32_kernel", "gemm_bf16_kernel", "lstm_fwd_kernel", "lstm_bwd_kernel", "clip_adam", "pit_pair",
-        "pit_bwd", "bn_apply", "bn_bwd", "splitk_reduce", "colred", "sumsq")
+KEYS = ("gemm_f32_kernel", "gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "cast_t_kernel", "lstm_fwd_kernel",
+        "lstm_bwd_kernel", "clip_adam", "pit_pair", "pit_bwd", "bn_apply", "bn_bwd", "splitk_reduce", "colred", "sumsq")
+BF16_ONLY = ("gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "cast_t_kernel")
 
 
 def kernel_source_id(root):
@@ -43,7 +44,7 @@ def main():
                               recursive=True)
             for r in csv.DictReader(open(files[0])):
                 for k in KEYS:
-                    if k in r["Kernel_Name"] and (dt == "f32" or k == "gemm_bf16_kernel"):
+                    if k in r["Kernel_Name"] and (dt == "f32" or k in BF16_ONLY):
                         acc[k][c].append(float(r["Counter_Value"]))
     res = {}
     for k, e in acc.items():
