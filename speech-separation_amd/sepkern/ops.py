@@ -80,6 +80,7 @@ def device_info():
 
 # ----------------------------------------------------------------------------- GEMM
 _NUM_CUS = None
+_SPLITK_MAX = int(__import__('os').environ.get('SEPKERN_SPLITK_MAX', '32'))   # diagnostic: cap the K slices
 
 
 def pick_splitk(M, N, K, batch=1):
@@ -92,11 +93,11 @@ def pick_splitk(M, N, K, batch=1):
         _NUM_CUS = device_info()[0]
     cus = _NUM_CUS
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
-    if tiles >= 16 * cus or K < 2048:
+    if tiles >= 16 * cus or K < 2048 or _SPLITK_MAX == 1:
         return 1
     work = 2.0 * M * N * K * batch / 140e12                      # seconds at the kernel's un-quantised rate
     best, best_t = 1, None
-    for s in range(1, 33):
+    for s in range(1, min(33, _SPLITK_MAX + 1)):
         if K // s < 512:
             break
         per_cu = tiles * s / cus

@@ -130,10 +130,10 @@ def training_batches(m, args, rank, world):
   if world == 1:
     gen = None
     if args.seed is not None:
-      gen = torch.Generator()
+      gen = torch.Generator()                    # re-seeded per epoch by reseed_epoch(): a resumed run shuffles alike
       gen.manual_seed(seed)
     return DataLoader(dataset, batch_size=args.batch_size, shuffle=True, collate_fn=dataset.collator,
-                      num_workers=args.num_workers, generator=gen), None
+                      num_workers=args.num_workers, generator=gen), gen
   counts = dataset.frame_counts() if hasattr(dataset, "frame_counts") else None
   shards = skdist.EpochShards(len(dataset), args.batch_size, rank, world, lengths=counts, seed=seed)
   return DataLoader(dataset, batch_sampler=shards, collate_fn=dataset.collator, num_workers=args.num_workers), shards
@@ -170,6 +170,17 @@ def build_model(m, args, gpu, rank):
   else:
     optimizer = ClipAdam(model, lr=args.learning_rate, max_norm=CLIP_NORM)
   return model, optimizer
+
+
+def reseed_epoch(args, rank, epoch, order, model):
+  """With --seed, everything random in an epoch (utterance order, the per-batch h0/c0 of archs/uPIT.py:121-127) is a
+  function of (seed, rank, epoch) alone, so `--start-epoch N` continues exactly where an uninterrupted run would be."""
+  if hasattr(order, "set_epoch"):
+    order.set_epoch(epoch)                       # sepkern.dist.EpochShards
+  elif isinstance(order, torch.Generator):
+    order.manual_seed(args.seed * 1000003 + epoch)
+  if args.seed is not None and getattr(model, "hidden_generator", None) is not None:
+    model.hidden_generator.manual_seed(args.seed * 1000003 + 7919 * rank + 104729 * (epoch + 1))
 
 
 def resume(model, optimizer, run, args):
@@ -272,8 +283,7 @@ def main(argv=None):
 
   for epoch in range(args.start_epoch, args.num_epochs):
     number = epoch + 1
-    if shards is not None:
-      shards.set_epoch(epoch)
+    reseed_epoch(args, rank, epoch, shards, model)
     acc = train_epoch(m, model, optimizer, train_batches, epoch, world, args.torch_optimizer)
     checkpoint = epoch % CHECKPOINT_EVERY == CHECKPOINT_EVERY - 1
     if cv_batches is not None and checkpoint:

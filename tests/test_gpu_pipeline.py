@@ -119,12 +119,39 @@ def test_recipe_steps_end_to_end(tmp_path):
     hard = float(open(os.path.join(data, "oracle_hard_mask_eval", "SDR_stats.txt")).readline().split("\t")[1])
     trained = float(st[0].split("\t")[1])
     assert soft > trained + 3 and hard > trained + 3 and soft > 5      # ideal masks bound a 5-epoch toy model from above
+    # ... and against the CPU oracle of the same computation (reference steps/evaluate_oracle.py:120-145): STFT of the
+    # mixture and the sources, ideal ratio mask, mask-apply + iSTFT (oracle/stft.py), BSS Eval without permutation
+    from sepkern.bsseval import bss_eval_sources
+    lines = open(os.path.join(data, "oracle_soft_mask_eval", "source_SDRs.txt")).read().splitlines()
+    assert [l.split(' ')[0] for l in lines] == ids
+    for i in (0, len(ids) - 1):
+        pcm = [OS.pcm16_to_float(scipy.io.wavfile.read(os.path.join(wavroot, d, ids[i] + ".wav"))[1]) for d in ("mix", "s1", "s2")]
+        mix_spec = OS.stft(pcm[0])
+        mags = [np.abs(OS.stft(p)) for p in pcm[1:]]
+        ests = np.stack([OS.istft(mix_spec * (m / np.maximum(np.abs(mix_spec), 1e-20))) for m in mags])
+        refs = np.stack([p[:ests.shape[1]] for p in pcm[1:]])
+        sdr, _, _, _ = bss_eval_sources(refs.astype(np.float64), ests.astype(np.float64), compute_permutation=False)
+        got = [float(v) for v in lines[i].split(' ')[1:]]
+        np.testing.assert_allclose(got, sdr, atol=0.02)                # dB; fp32 kernels vs the fp64-accumulating oracle
 
-    # ---- resume from epoch 5 with the optimizer state saved next to the checkpoint
+    # ---- resume from epoch 5 with the optimizer state saved next to the checkpoint: with --seed the continued run
+    # ends on EXACTLY the weights of an uninterrupted 6-epoch run (deterministic kernels, Adam moments restored,
+    # shuffling and h0/c0 re-seeded per epoch) -- the reference restarts Adam on resume (steps/train_qsub.py:107)
     assert os.path.isfile(os.path.join(exp, "intermediate_models", "005.opt"))
     out = run(os.path.join(STEPS, "train_qsub.py"), "uPIT", "0", data, exp, "--model-config", os.path.join(exp, "conf"),
               "--batch-size", "4", "--num-epochs", "6", "--start-epoch", "5", "--seed", "1")
     assert "For epoch: 006 loss is:" in out
+    exp2 = os.path.join(root, "exp", "uPIT_syn_straight")
+    os.makedirs(exp2)
+    run(os.path.join(STEPS, "train_qsub.py"), "uPIT", "0", data, exp2, "--model-config", os.path.join(exp, "conf"),
+        "--batch-size", "4", "--num-epochs", "6", "--seed", "1")
+    a = torch.load(os.path.join(exp, "final.mdl"), map_location="cpu")
+    b = torch.load(os.path.join(exp2, "final.mdl"), map_location="cpu")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    l5 = open(os.path.join(exp, "train_stats", "train_loss.txt")).read().splitlines()
+    l6 = open(os.path.join(exp2, "train_stats", "train_loss.txt")).read().splitlines()
+    assert l5 == l6 and len(l6) == 6
 
 
 def test_wav_input_pipeline_equals_npz_pipeline(tmp_path):
