@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 102
+#define SK_VERSION 103
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -113,12 +113,15 @@ int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld
  * archs/uPIT.py:115,132, that cannot be batched over time), with packed-sequence semantics
  * on padded input: for row b the state is frozen and y is 0 at t >= lens[b]; the reverse
  * direction starts from (h0,c0) at t = lens[b]-1.
- *   gx    (T,B,2,4H)  input projections x*W_ih^T + b_ih + b_hh for both directions
+ *   gx    (T,B,2,4H)  input projections x*W_ih^T + b_ih + b_hh for both directions, GATE-INTERLEAVED: within a
+ *                     direction's 4H values, element 4u + g is gate g (i,f,g,o) of hidden unit u -- the four gates
+ *                     of a cell are one 16-byte access (torch keeps the rows of W_ih gate-major, g H + u:
+ *                     sk_gate_rows reorders a weight matrix / bias once so that a plain GEMM produces this layout)
  *   whh   (2,4H,H)    recurrent weights (torch layout, gate rows i,f,g,o)
  *   h0,c0 (2,B,H)     initial state of this layer;  hn,cn (2,B,H) final state (may be NULL)
  *   y     (T,B,2H)    layer output [fwd | bwd]
- *   gates (T,B,2,4H)  post-activation i,f,g,o and cs (T,B,2,H) cell states, saved for the
- *                     backward pass (both NULL for inference)
+ *   gates (T,B,2,4H)  post-activation i,f,g,o (gate-interleaved like gx) and cs (T,B,2,H) cell states, saved
+ *                     for the backward pass (both NULL for inference)
  *   ws    workspace of sk_lstm_workspace_bytes(); zeroed by the call itself
  * mode (low byte): 0 auto, 1 persistent (one launch, flag-synchronised time loop), 2 one launch per step.
  * mode >> 8: minimum number of 16-row batch groups a workgroup carries (0/1 = as few as fit): a larger
@@ -128,7 +131,7 @@ int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float*
                 float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
                 int T, int B, int H, int mode, sk_stream_t stream);
 /* Backward of the recurrence.  dy (T,B,2H) is the gradient of the layer output; produces
- * dgx (T,B,2,4H) = gradient of the gate pre-activations (zero at padded positions), from which
+ * dgx (T,B,2,4H) = gradient of the gate pre-activations (gate-interleaved like gx; zero at padded positions), from which
  * the caller forms dW_ih, dW_hh, db and dx with sk_gemm_f32 / sk_colsum, and dh0/dc0 (2,B,H; may
  * be NULL).  y is the forward output (h_t), used for nothing but is kept for symmetry. */
 int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs,
@@ -146,6 +149,11 @@ int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const flo
 int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
                       const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
                       float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, sk_stream_t stream);
+/* Reorder the rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g H + u inside each block of 4H
+ * rows) and the gate-interleaved order of gx / gates / dgx (row 4u + g).  back = 0: dst[4u+g] = src[gH+u] (weights,
+ * biases -> interleaved); back = 1: dst[gH+u] (+)= src[4u+g] (weight gradients back to the parameter order,
+ * optionally accumulating).  dbias of sk_lstm_bwd_state is already gate-major. */
+int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int back, int accumulate, sk_stream_t stream);
 /* Word 0 of the workspace is a STICKY status word: a launch whose bounded spin gave up sets it (no launch clears
  * it; allocate the workspace zeroed).  Its address can be handed to sk_grad_norm as `guard` (as a float: any
  * non-zero bit pattern counts) so that a failed launch never reaches the weights, without a host sync per step.

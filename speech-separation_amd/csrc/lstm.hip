@@ -367,12 +367,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       const unsigned* const myflags = flags0 + (size_t)flag_replica(a.opt) * rep_stride;
       SK_STAMP(7);
       // 1. this step's input-projection terms (independent of the recurrence: issue early)
-      float gxv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (cellok) {
-        const float* gp = a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) gxv[g] = gp[(size_t)g * H];
-      }
+      float4 gxv = make_float4(0.f, 0.f, 0.f, 0.f);  // gate-interleaved layout: i,f,g,o of a cell are one 16-byte access
+      if (cellok) gxv = *reinterpret_cast<const float4*>(a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit);
       // 2./3. h_{s-1} image (16 rows x HP) -> LDS.  Each consumer wave waits for the flags of exactly the unit
       // groups whose 1 KB pieces it pulls and starts its LDS-DMAs as soon as those are up -- no workgroup
       // barrier in between.  fp32: all 8 waves pull (56 pieces); bf16 (28 pieces, latency-bound): only the four
@@ -463,10 +459,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
         // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
         float c_reg = st_c[gi][oi], h_reg = st_h[gi][oi];
-        const float gi_ = fast_sigmoid(acc[0] + gxv[0]);
-        const float gf = fast_sigmoid(acc[1] + gxv[1]);
-        const float gg = fast_tanh(acc[2] + gxv[2]);
-        const float go = fast_sigmoid(acc[3] + gxv[3]);
+        const float gi_ = fast_sigmoid(acc[0] + gxv.x);
+        const float gf = fast_sigmoid(acc[1] + gxv.y);
+        const float gg = fast_tanh(acc[2] + gxv.z);
+        const float go = fast_sigmoid(acc[3] + gxv.w);
         const float c_new = gf * c_reg + gi_ * gg;
         const float h_new = go * fast_tanh(c_new);
         valid = cellok && t < len_b;
@@ -509,11 +505,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       if (cellok) {
         a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = y_out;
         if (a.gates && valid) {
-          float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
-          gp[0] = acc[0];
-          gp[(size_t)H] = acc[1];
-          gp[(size_t)2 * H] = acc[2];
-          gp[(size_t)3 * H] = acc[3];
+          *reinterpret_cast<f32x4*>(a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit) = acc;
           a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit] = c_out;
         }
       }
@@ -735,11 +727,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       // 1. saved activations of this cell (independent of the recurrence: issue early)
       float gi_ = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cprev = 0.f, dyv = 0.f;
       if (valid) {
-        const float* gp = a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
-        gi_ = gp[0];
-        gf = gp[(size_t)H];
-        gg = gp[(size_t)2 * H];
-        go = gp[(size_t)3 * H];
+        const float4 gv = *reinterpret_cast<const float4*>(a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit);
+        gi_ = gv.x;
+        gf = gv.y;
+        gg = gv.z;
+        go = gv.w;
         ct = a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit];
         const int tp = dir ? t + 1 : t - 1;
         const bool has_prev = dir ? (t + 1 < len_b) : (t > 0);
@@ -803,11 +795,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
       // 5. ... then the bulk store of the step (dgx, zero at padded positions)
       if (cellok) {
-        float* dp = a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + unit;
-        dp[0] = dpre[0];
-        dp[(size_t)H] = dpre[1];
-        dp[(size_t)2 * H] = dpre[2];
-        dp[(size_t)3 * H] = dpre[3];
+        *reinterpret_cast<f32x4*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit) = dpre;
       }
       SK_STAMP(6);
     }
@@ -875,6 +863,31 @@ __global__ __launch_bounds__(256) void first_dg_kernel(const float* __restrict__
   float4* dst = reinterpret_cast<float4*>(out + ((size_t)dir * B + b) * 4 * H);
   const bool live = len >= 1;
   for (int i = threadIdx.x; i < H; i += 256) dst[i] = live ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// Rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g*H + u inside each block of 4H rows: the
+// order of weight_ih / weight_hh / bias rows, gates i,f,g,o) and the recurrence's gate-interleaved order (row 4u + g).
+//   back == 0: dst[4u + g] = src[g H + u]            (weights and biases -> the order gx / gates / dgx are kept in)
+//   back == 1: dst[g H + u] (+)= src[4u + g]         (weight gradients -> the order of the parameter tensors)
+__global__ __launch_bounds__(256) void gate_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int H,
+                                                        int C, int back, int accumulate) {
+  const int rows4 = 4 * H;
+  const int blk = blockIdx.x / rows4, r = blockIdx.x % rows4;        // r: interleaved index 4u + g
+  const size_t ri = (size_t)blk * rows4 + r, rg = (size_t)blk * rows4 + (size_t)(r & 3) * H + (r >> 2);
+  const float* s = src + (back ? ri : rg) * C;
+  float* d = dst + (back ? rg : ri) * C;
+  if ((C & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+      float4 v = *reinterpret_cast<const float4*>(s + c);
+      if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4*>(d + c);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+      }
+      *reinterpret_cast<float4*>(d + c) = v;
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) d[c] = accumulate ? d[c] + s[c] : s[c];
+  }
 }
 
 template <int KS, bool BF>
@@ -963,6 +976,7 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   SK_CHECK_ARG(gx && whh && h0 && c0 && lens && y && ws, "sk_lstm_fwd: null pointer");
   SK_CHECK_ARG((gates == nullptr) == (cs == nullptr), "sk_lstm_fwd: gates and cs must be given together");
   SK_CHECK_ARG(((uintptr_t)h0 % 16) == 0, "sk_lstm_fwd: h0 must be 16-byte aligned");
+  SK_CHECK_ARG(((uintptr_t)gx % 16) == 0 && ((uintptr_t)gates % 16) == 0, "sk_lstm_fwd: gx / gates must be 16-byte aligned");
   int rc = check_common("sk_lstm_fwd", T, B, H, whh, mode);
   if (rc) return rc;
   const int gmin = (mode >> 8) & 0xff;  // bits 8..15: minimum batch groups per workgroup (frees CUs for concurrent kernels)
@@ -1015,6 +1029,7 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
                                  float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
                                  int mode, sk_stream_t stream) {
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
+  SK_CHECK_ARG(((uintptr_t)gates % 16) == 0 && ((uintptr_t)dgx % 16) == 0, "sk_lstm_bwd: gates / dgx must be 16-byte aligned");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
   if (rc) return rc;
   const int gmin = (mode >> 8) & 0xff;
@@ -1072,5 +1087,14 @@ extern "C" int sk_lstm_status(void* ws, sk_stream_t stream) {
     return sk_fail(SK_ETIMEOUT, "sk_lstm: a workgroup's bounded wait timed out in a launch since the last check "
                                 "(grid not co-resident?)");
   }
+  return SK_OK;
+}
+
+extern "C" int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int back, int accumulate,
+                            sk_stream_t stream) {
+  SK_CHECK_ARG(src && dst && src != dst && nblk > 0 && H > 0 && C > 0, "sk_gate_rows: bad arguments");
+  hipLaunchKernelGGL(gate_rows_kernel, dim3((unsigned)(nblk * 4 * H)), dim3(256), 0, (hipStream_t)stream, src, dst, H, C,
+                     back, accumulate);
+  SK_CHECK_LAUNCH("sk_gate_rows");
   return SK_OK;
 }

@@ -210,14 +210,18 @@ class Engine:
             off_ih, _ = self.layout.blocks["bias_ih_l%d" % l]
             bsum = torch.empty(8 * H, device=dev)
             ops.colsum(self.flat[off_ih:], 2, 8 * H, 8 * H, bsum)
+            # the recurrence keeps i,f,g,o of a cell adjacent (one 16-byte access per cell and step instead of four
+            # H-strided ones): reorder the rows of W_ih and of the bias once, the GEMM then writes gx in that order
+            wih_gi = ops.gate_rows(wih.view(8 * H, I), H)
+            bsum = ops.gate_rows(bsum, H)
             gx = torch.empty(T, B, 2, 4 * H, device=dev)
-            self._proj(cache, inp.view(R, I), wih.view(8 * H, I), gx.view(R, 8 * H), bsum)
+            self._proj(cache, inp.view(R, I), wih_gi, gx.view(R, 8 * H), bsum)
             y = torch.empty(T, B, 2 * H, device=dev)
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
             ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
                               hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
                               T, B, H, self.lstm_mode | self.fwd_bits, bf16=self.bf16)
-            saved.append((inp, gx, cs, y))
+            saved.append((inp, gx, cs, y, wih_gi))
             inp, I = y, 2 * H
         if not save:
             ops.lstm_status(ws)          # inference: the caller copies the masks to the host next, a sync costs nothing
@@ -301,7 +305,7 @@ class Engine:
         dc0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
         dx = None
         for l in range(L - 1, -1, -1):
-            inp, gates, cs, y = ctx["saved"][l]
+            inp, gates, cs, y, wih_gi = ctx["saved"][l]
             I = I0 if l == 0 else 2 * H
             whh = self.p("weight_hh_l%d" % l)
             dgx = gates                                  # overwritten in place, cell by cell
@@ -319,7 +323,7 @@ class Engine:
                               bf16=self.bf16, dbias=dbias, dg_first=dg_first)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, I, device=dev)
-                self._dgrad(cache, dgx.view(R, 8 * H), self.p("weight_ih_l%d" % l).view(8 * H, I), dy_next, "gemm_dgrad")
+                self._dgrad(cache, dgx.view(R, 8 * H), wih_gi, dy_next, "gemm_dgrad")
                 if l == 0:
                     dx = dy_next.view(T, B, I)
             stream = self.side if (overlap and l > 0) else main
@@ -330,16 +334,19 @@ class Engine:
             with torch.cuda.stream(stream):
                 tag = "side" if stream is not main else "main"
                 # dW_hh[d] = sum_t dG_t^T h_prev(t): the layer output shifted by one step in time (+ the h0 steps)
-                self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, self.g("weight_hh_l%d" % l),
-                               T, B, acc, "gemm_" + tag)
+                # (rows come out gate-interleaved, like dgx: sk_gate_rows puts them back into the parameters' order)
+                gw_hh = torch.empty(2, 4 * H, H, device=dev)
+                self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, gw_hh, T, B, False, "gemm_" + tag)
+                ops.gate_rows(gw_hh, H, back=True, out=self.g("weight_hh_l%d" % l), accumulate=acc)
                 # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
-                self._wgrad(cache, dgx.view(R, 8 * H), inp.view(R, I), self.g("weight_ih_l%d" % l).view(8 * H, I), acc,
-                            "gemm_" + tag)
+                gw_ih = torch.empty(8 * H, I, device=dev)
+                self._wgrad(cache, dgx.view(R, 8 * H), inp.view(R, I), gw_ih, False, "gemm_" + tag)
+                ops.gate_rows(gw_ih, H, back=True, out=self.g("weight_ih_l%d" % l), accumulate=acc)
                 db = torch.empty(8 * H, device=dev)
                 ops.colsum(dbias, nbg, 8 * H, 8 * H, db, ws_tag="bn_" + tag)       # a few rows: the kernel did the sums
                 put("bias_ih_l%d" % l, db.view(2, 4 * H))
                 put("bias_hh_l%d" % l, db.view(2, 4 * H))
-                keep += [db, dbias, dg_first, dgx, inp, y]
+                keep += [db, dbias, dg_first, dgx, inp, y, gw_hh, gw_ih]
             if l > 0:
                 dy = dy_next
         if overlap:

@@ -482,6 +482,29 @@ def lstm_whh_grad(dgx, y, h0, dg_first, out, T, B, H, accumulate=False, bf16=Fal
          sC=4 * H * H, ws_tag=ws_tag, bf16=bf16)
 
 
+def gate_rows(src, H, back=False, out=None, accumulate=False):
+    """Reorder rows of a (nblk * 4H, C) fp32 matrix (or (nblk * 4H,) vector) between torch's gate-major order and the
+    gate-interleaved order of gx / gates / dgx (include/sepkern.h, sk_gate_rows)."""
+    _chk(src)
+    s2 = src.reshape(-1, 1) if src.dim() == 1 else src.reshape(-1, src.shape[-1])
+    if not s2.is_contiguous():
+        raise _lib.SepkernError("gate_rows needs a contiguous matrix")
+    nblk = s2.shape[0] // (4 * H)
+    if out is None:
+        out = torch.empty_like(src)
+    _lib.call("sk_gate_rows", _ptr(s2), _ptr(out), nblk, H, s2.shape[1], int(back), int(accumulate), _stream())
+    return out
+
+
+def gates_interleaved(t, H, back=False):
+    """(..., 4H) gate-major <-> gate-interleaved along the LAST axis, by torch view/permute (tests and tools: the
+    product path gets the interleaved order for free from reordered weight rows)."""
+    shape = t.shape
+    if back:
+        return t.reshape(shape[:-1] + (H, 4)).transpose(-1, -2).reshape(shape).contiguous()
+    return t.reshape(shape[:-1] + (4, H)).transpose(-1, -2).reshape(shape).contiguous()
+
+
 def lstm_status(ws):
     """Raises SepkernError (SK_ETIMEOUT) if a persistent launch on this workspace timed out since the last call."""
     _lib.call("sk_lstm_status", _ptr(ws), _stream())

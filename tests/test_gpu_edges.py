@@ -42,7 +42,9 @@ def test_lstm_minimal_and_ragged_shapes(ops, T, B, H, lens):
     bsum = torch.stack([w[0][d][2] + w[0][d][3] for d in range(2)]).reshape(-1).cuda()
     for mode in (1, 2):
         gx = torch.empty(T, B, 2, 4 * H).cuda()
-        ops.gemm(x.cuda(), wih, gx, T * B, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum)
+        # gx in the recurrence's gate-interleaved order: reordered weight rows / bias, plain GEMM
+        ops.gemm(x.cuda(), ops.gate_rows(wih.view(8 * H, I), H), gx, T * B, 8 * H, I, I, I, 8 * H, transB=True,
+                 bias=ops.gate_rows(bsum, H))
         y = torch.full((T, B, 2 * H), float("nan")).cuda()
         hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
         ws = ops.lstm_fwd(gx, whh, h0.cuda(), c0.cuda(), torch.tensor(lens, dtype=torch.int32).cuda(), y, None, None, hn, cn,

@@ -316,7 +316,8 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
     bsum = torch.stack([w[0][d][2] + w[0][d][3] for d in range(2)]).reshape(-1).cuda()
     R = T * B
     gx = torch.empty(T, B, 2, 4 * H).cuda()
-    ops.gemm(dev(x), wih, gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum)
+    # gx in the recurrence's gate-interleaved order (4u + g): reordered rows of W_ih and of the bias, plain GEMM
+    ops.gemm(dev(x), ops.gate_rows(wih.view(8 * H, I), H), gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=ops.gate_rows(bsum, H))
     y = torch.full((T, B, 2 * H), float("nan")).cuda()
     cs = torch.empty(T, B, 2, H).cuda()
     hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
@@ -336,13 +337,13 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
     gtol = dict(rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(dh0.cpu().numpy(), h0r.grad.numpy(), **gtol)
     np.testing.assert_allclose(dc0.cpu().numpy(), c0r.grad.numpy(), **gtol)
-    dgx = gx.cpu().double().view(R, 2, 4 * H)
+    dgx = ops.gates_interleaved(gx.view(R, 2, 4 * H), H, back=True).cpu().double()      # back to torch's gate-major order
     assert torch.isfinite(dgx).all()
     # dW_hh without a materialised h_prev: time-shifted product with the layer output + the h0 steps
-    dwhh = torch.full((2, 4 * H, H), float("nan")).cuda()
-    ops.lstm_whh_grad(gx, y, dev(h0), dg_first, dwhh, T, B, H)
-    dwhh2 = dwhh.clone()
-    ops.lstm_whh_grad(gx, y, dev(h0), dg_first, dwhh2, T, B, H, accumulate=True)
+    dwhh_gi = torch.full((2, 4 * H, H), float("nan")).cuda()
+    ops.lstm_whh_grad(gx, y, dev(h0), dg_first, dwhh_gi, T, B, H)
+    dwhh = ops.gate_rows(dwhh_gi, H, back=True)                       # rows come out interleaved, like dgx
+    dwhh2 = ops.gate_rows(dwhh_gi, H, back=True, out=dwhh.clone(), accumulate=True)
     db = dbias.cpu().double().sum(0)                                  # (2, 4H)
     for d in range(2):
         w_ih_g, w_hh_g, b_ih_g, b_hh_g = (t.grad for t in wr[0][d])
@@ -380,7 +381,8 @@ def test_lstm_layer_bf16_matches_bf16_oracle(ops, mode, T, B, H, I, lens):
     bsum = torch.stack([w[0][d][2] + w[0][d][3] for d in range(2)]).reshape(-1).cuda()
     R = T * B
     gx = torch.empty(T, B, 2, 4 * H).cuda()
-    ops.gemm(dev(x), wih, gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=bsum, bf16=True)
+    ops.gemm(dev(x), ops.gate_rows(wih.view(8 * H, I), H), gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=ops.gate_rows(bsum, H),
+             bf16=True)
     y = torch.full((T, B, 2 * H), float("nan")).cuda()
     cs = torch.empty(T, B, 2, H).cuda()
     hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
@@ -401,7 +403,7 @@ def test_lstm_layer_bf16_matches_bf16_oracle(ops, mode, T, B, H, I, lens):
         assert err < 3e-3, (what, err)
     close(dh0.cpu(), h0r.grad, "dh0")
     close(dc0.cpu(), c0r.grad, "dc0")
-    dgx = gx.cpu().view(R, 2, 4 * H)
+    dgx = ops.gates_interleaved(gx.view(R, 2, 4 * H), H, back=True).cpu()
     assert torch.isfinite(dgx).all()
     for d in range(2):
         close(dgx[:, d].sum(0), wr[0][d][2].grad, "db dir %d" % d)     # column sums of dG = bias gradient
