@@ -50,6 +50,14 @@ __device__ __forceinline__ bf16x8 pack8(const float4& a, const float4& b) {
 __device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((((k >> 3) & 3) * 16 + b) << 3) + (k & 7); }
 
 constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
+// Poll cadence (units of 64 clocks, s_sleep): a poll is a write-through-coherent load that competes with the CU's own
+// publish traffic and with everybody's flag lines; diagnostic builds vary it (make -C csrc variant NAME=.. DEFS=..)
+#ifndef SK_POLL_SLEEP
+#define SK_POLL_SLEEP 1
+#endif
+#ifndef SK_POLL_DELAY
+#define SK_POLL_DELAY 0
+#endif
 constexpr int NTHREADS = 512;
 constexpr int NREP = 8;  // flag replicas (one per XCD label) when replication is on
 
@@ -107,6 +115,7 @@ struct FwdArgs {
   int T, B, H, NBG, G, s_begin, s_end;
   int map, nby;  // block id -> (unit group, batch-group block, direction) assignment (speed only), grid y extent
   int opt;       // bit 0: one polling wave per workgroup; bit 1: flags replicated per XCD label
+  int poll_delay;  // single poller: first poll of a step not before own flag store + poll_delay x 0.1 us (wait_flags)
 };
 
 struct BwdArgs {
@@ -128,7 +137,7 @@ struct BwdArgs {
   unsigned* ctrl;
   unsigned* sticky;
   int T, B, H, NBG, G, s_begin, s_end, final_mm;
-  int map, nby;
+  int map, nby, poll_delay;
 };
 
 // Flag replication (opt bit 1): every producer raises its flag in NREP copies with ONE store instruction (NREP lanes,
@@ -144,8 +153,18 @@ __device__ __forceinline__ void raise_flag(unsigned* flags0, size_t rep_stride, 
 }
 
 // Wave 0 waits until every flag of its (direction, batch group) has reached `target`.
-__device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigned target, unsigned* ctrl, int lane) {
+// `not_before` (100 MHz ticks, 0 = none): the first poll is held back until that time.  All workgroups of a stream publish
+// at about the same moment, so polls issued right after one's own flag store only queue on the flag lines in front of
+// everybody's flag STORES (and in the CU's own memory queue): measured at H = 896, B = 32, a forward step takes 6.61 us
+// with immediate polling and 6.10 us with the first poll ~0.45 us later (bf16: 3.89 -> 3.19 us at ~0.7 us); later
+// than that the hold-back adds itself to the step.  The caller passes its own flag-store time plus a fixed allowance.
+__device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigned target, unsigned* ctrl, int lane,
+                                           long long not_before = 0) {
   const long long t0 = wall_clock64();
+  if (SK_POLL_DELAY > 0) __builtin_amdgcn_s_sleep(SK_POLL_DELAY);
+  if (not_before) {
+    while (wall_clock64() - not_before < 0) __builtin_amdgcn_s_sleep(1);
+  }
   for (unsigned it = 0;; ++it) {
     bool ok = true;
     for (int i = lane; i < n; i += 64) ok = ok && (__hip_atomic_load(flags + i, SK_RLX, SK_AGENT) >= target);
@@ -160,7 +179,7 @@ __device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigne
         return false;
       }
     }
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(SK_POLL_SLEEP);
   }
 }
 
@@ -180,7 +199,7 @@ __device__ __forceinline__ bool wait_flags_sel(const unsigned* flags, int idx, u
         return false;
       }
     }
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(SK_POLL_SLEEP);
   }
 }
 
@@ -280,6 +299,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   __shared__ __attribute__((aligned(16))) float hs[16 * HP];  // B-operand image of h_{s-1}: [k/4][16 rows][4]
   __shared__ __attribute__((aligned(16))) float red[MT][64][4];
   __shared__ float st_c[GMAX][64 * MT], st_h[GMAX][64 * MT];  // per-group cell state of the owner lanes
+  __shared__ long long st_tpub[GMAX];                         // wave 0: when this workgroup raised the group's flag
   __shared__ int s_abort;
 
   int ug, by, dir;
@@ -376,7 +396,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       // the split costs 2 % in fp32 and gains 1.5 % in bf16).
       if ((a.opt & 1) && s > a.s_begin && s > 0) {
         // option: ONE polling wave per workgroup (8x fewer pollers on the flag lines, one more barrier)
-        if (w == 0 && !wait_flags(myflags, NUG, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
+        if (w == 0 && !wait_flags(myflags, NUG, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL) &&
+            lane == 0)
+          s_abort = 1;
         __syncthreads();
       }
       if (s == 0) {
@@ -501,6 +523,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       }
       __syncthreads();
       raise_flag(flags0 + ug, rep_stride, a.opt, tid, (unsigned)(s + 1));
+      if (tid == 0) st_tpub[gi] = wall_clock64();  // read back by this same wave when it polls for the next step
       // 7. ... then the bulk stores of the step, off the critical path
       if (cellok) {
         a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = y_out;
@@ -643,6 +666,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   __shared__ float red[8][16][17];
   __shared__ float st_carry[GMAX][256], st_dc[GMAX][256];  // per-group recurrent state of the owner lanes
   __shared__ __attribute__((aligned(16))) float st_db[256][4];  // owner lanes: running sum of their cells' dG (bias gradient)
+  __shared__ long long st_tpub[GMAX];  // wave 0: when this workgroup raised the group's flag (see wait_flags)
   __shared__ int s_abort;
 
   int ug, by, dir;
@@ -744,7 +768,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
         // one wave polls for the whole workgroup: letting every wave wait for just the unit groups of its own
         // eighth of k' (no barrier before the product) measured SLOWER here (fp32 9.4 -> 10.0 ms, bf16 5.6 -> 5.9)
         if (s > a.s_begin && w == 0) {
-          if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane) && lane == 0) s_abort = 1;
+          if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL) && lane == 0)
+            s_abort = 1;
         }
         __syncthreads();
         if (s_abort) {
@@ -792,7 +817,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
         SK_STAMP(5);
       }
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+      if (tid == 0) {
+        __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+        st_tpub[gi] = wall_clock64();
+      }
       // 5. ... then the bulk store of the step (dgx, zero at padded positions)
       if (cellok) {
         *reinterpret_cast<f32x4*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit) = dpre;
@@ -956,7 +984,7 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 23) == 0,
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 28) == 0,
                "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
@@ -985,6 +1013,7 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   const int map = (mode >> 18) & 3;     // bits 18..19: block id -> stream assignment (speed only)
   const int opt = (mode >> 20) & 7;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD;
                                         // bit 22: raised static wave priority
+  int poll_delay = (mode >> 23) & 31;  // bits 23..27: FwdArgs::poll_delay, units of 0.1 us; 0 = choose, 31 = none
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -1000,8 +1029,12 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   const bool fits = G > 0;
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
-  a.map = map; a.nby = nby; a.opt = opt;
   const int nblocks = NUG * nby * 2;
+  // hold-back of the first poll after one's own flag store (wait_flags): 0.8 us on a full grid, 0.4 us on a small one
+  // (fewer flag stores to land); measured optimum for H 896/1024 (0.8) and H 256/300 (0.4), no effect at 2x600 / B = 100
+  if (poll_delay == 0) poll_delay = nblocks >= 128 ? 8 : 4;
+  if (poll_delay == 31) poll_delay = 0;
+  a.map = map; a.nby = nby; a.opt = opt; a.poll_delay = poll_delay;
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));  // per-launch status word + flags (not the sticky word)
   if (mode == 1 || (mode == 0 && fits)) {
@@ -1037,6 +1070,7 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   // block map as sk_lstm_fwd (+4: raised static wave priority, mode bit 22); flag replication was measured here too
   // (7.59 -> 7.50 us/step) and not kept
   const int map = ((mode >> 18) & 3) | (((mode >> 22) & 1) << 2);
+  int poll_delay = (mode >> 23) & 31;  // as sk_lstm_fwd; 0 = none here until measured otherwise
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -1053,7 +1087,8 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   const bool fits = G > 0;
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
-  a.map = map; a.nby = nby;
+  if (poll_delay == 31) poll_delay = 0;
+  a.map = map; a.nby = nby; a.poll_delay = poll_delay;
   dim3 grid((unsigned)L.KS, (unsigned)nby, 2);
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_bwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));

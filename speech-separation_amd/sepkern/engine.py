@@ -98,8 +98,8 @@ class Engine:
         # map 0..2: block id -> stream assignment (csrc/lstm.hip::decode_block)
         def variant(env, default):
             v = [int(x) for x in os.environ.get(env, default).split(",")]
-            v += [0] * (5 - len(v))
-            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]))
+            v += [0] * (6 - len(v))
+            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5])
         self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0")      # "half,map,poll1,repflags,prio" (r02: 7.33 -> 6.67 us/step)
         self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0")      # (r02: 8.00 -> 7.59 us/step)
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one.

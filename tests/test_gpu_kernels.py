@@ -461,3 +461,50 @@ def test_gemm_bf16_nt_splitk_batch_accumulate_and_transposed_copy(ops):
     ops.gemm_bf16_nt(Xt[:, off:], Yt, C, M, N, Kp, ld, ld, N)
     ref = X[off:, :M].bfloat16().double().t() @ Y[:R - off, :N].bfloat16().double()
     assert float((C.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize("T,B,H,lens", [(9, 32, 896, [9] * 20 + [7] * 8 + [2] * 4), (7, 40, 600, [7] * 17 + [5] * 20 + [1] * 3),
+                                        (6, 16, 64, [6] * 10 + [3] * 6)])
+def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H, lens):
+    """The speed-only variants of the persistent recurrence (include/sepkern.h, mode bits 17..27: 8-unit workgroups, block
+    -> stream maps, one polling wave, replicated flags, poll hold-back) change which workgroup computes what and how the
+    hand-off is signalled, never the arithmetic: outputs equal the default's bit for bit."""
+    g = torch.Generator().manual_seed(H + T)
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+
+    def fwd(bits):
+        gg = gx.clone()
+        y = torch.zeros(T, B, 2 * H).cuda()
+        cs = torch.zeros(T, B, 2, H).cuda()
+        hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
+        ws = ops.lstm_fwd(gg, whh, h0, c0, lens_d, y, gg, cs, hn, cn, T, B, H, 1 | bits)
+        ops.lstm_status(ws)
+        return y, gg, cs, hn, cn
+
+    def bwd(bits, saved):
+        y, gates, cs, _, _ = saved
+        gg = gates.clone()
+        dh0, dc0 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
+        dbias = torch.empty((B + 15) // 16, 2, 4 * H).cuda()
+        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, lens_d, gg, dh0, dc0, T, B, H, 1 | bits, dbias=dbias)
+        ops.lstm_status(ws)
+        return gg, dh0, dc0, dbias
+
+    valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
+    ref = fwd(ops.lstm_variant_bits(False, 0, False, False, False, 31))                # r01 geometry, no hold-back
+    for variant in [(False, 1, True, False, False, 0), (False, 1, True, True, False, 8), (False, 2, False, False, False, 31),
+                    (True, 0, False, False, False, 31), (True, 2, True, True, False, 4)]:
+        out = fwd(ops.lstm_variant_bits(*variant))
+        for a, b in zip(out, ref):
+            if a.dim() == 4 and a.shape[-1] == 4 * H:                                # gates: defined at valid steps only
+                a, b = a[valid], b[valid]
+            assert torch.equal(a, b), variant
+    bref = bwd(ops.lstm_variant_bits(False, 0, False, False, False, 31), ref)
+    for variant in [(False, 1, False, False, False, 31), (False, 2, False, False, False, 6)]:
+        out = bwd(ops.lstm_variant_bits(*variant), ref)
+        for a, b in zip(out, bref):
+            assert torch.equal(a, b), variant
