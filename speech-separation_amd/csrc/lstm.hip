@@ -60,6 +60,7 @@ constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 #endif
 constexpr int NTHREADS = 512;
 constexpr int NREP = 8;  // flag replicas (one per XCD label) when replication is on
+constexpr int FSPREAD = 32;  // option: one flag per 128-byte line (stride in dwords) instead of 32 flags per line
 
 #define SK_RLX __ATOMIC_RELAXED
 #define SK_AGENT __HIP_MEMORY_SCOPE_AGENT
@@ -87,7 +88,7 @@ inline WsLayout ws_layout(int B, int H, bool bf = false) {
   w.sticky = 0;  // word 0: set by any launch whose bounded wait gave up; cleared only by sk_lstm_status
   w.ctrl = 256;  // per-launch status word (+ diagnostic stamps); zeroed with the flags by every call
   w.flags = 512;
-  const size_t nflags = NREP * 2 * (size_t)w.NBG * 2 * w.KS;  // up to 2 KS unit groups, NREP replicas
+  const size_t nflags = (size_t)FSPREAD * 2 * w.NBG * 2 * w.KS;  // up to 2 KS unit groups; NREP replicas or one flag per line
   w.xbuf = w.flags + sk_align(nflags * 4, 256);
   const size_t xbytes = 2 * 2 * (size_t)w.NBG * Hp * 64 * 4;  // backward exchange is the larger one
   w.state = w.xbuf + sk_align(xbytes, 256);
@@ -159,7 +160,7 @@ __device__ __forceinline__ void raise_flag(unsigned* flags0, size_t rep_stride, 
 // with immediate polling and 6.10 us with the first poll ~0.45 us later (bf16: 3.89 -> 3.19 us at ~0.7 us); later
 // than that the hold-back adds itself to the step.  The caller passes its own flag-store time plus a fixed allowance.
 __device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigned target, unsigned* ctrl, int lane,
-                                           long long not_before = 0) {
+                                           long long not_before = 0, int fs = 1) {
   const long long t0 = wall_clock64();
   if (SK_POLL_DELAY > 0) __builtin_amdgcn_s_sleep(SK_POLL_DELAY);
   if (not_before) {
@@ -167,7 +168,7 @@ __device__ __forceinline__ bool wait_flags(const unsigned* flags, int n, unsigne
   }
   for (unsigned it = 0;; ++it) {
     bool ok = true;
-    for (int i = lane; i < n; i += 64) ok = ok && (__hip_atomic_load(flags + i, SK_RLX, SK_AGENT) >= target);
+    for (int i = lane; i < n; i += 64) ok = ok && (__hip_atomic_load(flags + (size_t)i * fs, SK_RLX, SK_AGENT) >= target);
     if (__all(ok)) return true;
     if ((it & 63u) == 63u) {
       if (__hip_atomic_load(ctrl, SK_RLX, SK_AGENT) != 0u) return false;  // another workgroup gave up
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   __syncthreads();
   SK_STAMP_DECL
 
-  if (a.opt & 4) __builtin_amdgcn_s_setprio(3);  // option: win issue arbitration against co-resident GEMM waves
+  const int fs = (a.opt & 4) ? FSPREAD : 1;  // option: every flag in a 128-byte line of its own (flag stores do not serialise on a line)
   bool aborted = false;
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? T - 1 - s : s;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
       const size_t rep_stride = (size_t)2 * NBG * NUG;
-      unsigned* const flags0 = a.flags + (size_t)(dir * NBG + bg) * NUG;  // replica 0 of this stream's flags
+      unsigned* const flags0 = a.flags + (size_t)(dir * NBG + bg) * NUG * fs;  // replica 0 of this stream's flags
       const unsigned* const myflags = flags0 + (size_t)flag_replica(a.opt) * rep_stride;
       SK_STAMP(7);
       // 1. this step's input-projection terms (independent of the recurrence: issue early)
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       // the split costs 2 % in fp32 and gains 1.5 % in bf16).
       if ((a.opt & 1) && s > a.s_begin && s > 0) {
         // option: ONE polling wave per workgroup (8x fewer pollers on the flag lines, one more barrier)
-        if (w == 0 && !wait_flags(myflags, NUG, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL) &&
+        if (w == 0 && !wait_flags(myflags, NUG, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL, fs) &&
             lane == 0)
           s_abort = 1;
         __syncthreads();
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
           } else {
             const int piece = wq + NCW * (lane / PP);
             const int idx = (lane < PP * ((NCH + NCW - 1) / NCW) && piece < NCH) ? piece * PP + lane % PP : -1;
-            ok = wait_flags_sel(myflags, idx, (unsigned)s, a.ctrl, lane);
+            ok = wait_flags_sel(myflags, idx < 0 ? idx : idx * fs, (unsigned)s, a.ctrl, lane);
             if (!ok && lane == 0) s_abort = 1;
           }
         }
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         c_out = c_new;
       }
       __syncthreads();
-      raise_flag(flags0 + ug, rep_stride, a.opt, tid, (unsigned)(s + 1));
+      raise_flag(flags0 + (size_t)ug * fs, rep_stride, a.opt, tid, (unsigned)(s + 1));
       if (tid == 0) st_tpub[gi] = wall_clock64();  // read back by this same wave when it polls for the next step
       // 7. ... then the bulk stores of the step, off the critical path
       if (cellok) {
@@ -733,7 +734,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
   SK_STAMP_DECL
 
   if (owner) *reinterpret_cast<f32x4*>(&st_db[oi][0]) = f32x4{0.f, 0.f, 0.f, 0.f};  // read and written by the same lane only
-  if (a.map & 4) __builtin_amdgcn_s_setprio(3);  // option (bit 2 of the map field): raised static wave priority
   bool aborted = false;
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
@@ -745,7 +745,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       const int len_b = (b < B) ? a.lens[b] : 0;
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
-      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+      const int fs = (a.map & 4) ? FSPREAD : 1;  // option (bit 2 of the map field): one flag per 128-byte line
+      unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS * fs;
       SK_STAMP(7);
       const bool valid = cellok && t < len_b;
       // 1. saved activations of this cell (independent of the recurrence: issue early)
@@ -768,7 +769,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
         // one wave polls for the whole workgroup: letting every wave wait for just the unit groups of its own
         // eighth of k' (no barrier before the product) measured SLOWER here (fp32 9.4 -> 10.0 ms, bf16 5.6 -> 5.9)
         if (s > a.s_begin && w == 0) {
-          if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL) && lane == 0)
+          if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL, fs) && lane == 0)
             s_abort = 1;
         }
         __syncthreads();
@@ -818,7 +819,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       }
       __syncthreads();
       if (tid == 0) {
-        __hip_atomic_store(myflags + ug, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+        __hip_atomic_store(myflags + (size_t)ug * fs, (unsigned)(s + 1), SK_RLX, SK_AGENT);
         st_tpub[gi] = wall_clock64();
       }
       // 5. ... then the bulk store of the step (dgx, zero at padded positions)
@@ -859,9 +860,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       // gradient wrt the initial state: one more product with the last published dG (s_end == T)
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
-      const unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS;
+      const int fs = (a.map & 4) ? FSPREAD : 1;
+      const unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS * fs;
       if (T > a.s_begin && w == 0) {
-        if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane) && lane == 0) s_abort = 1;
+        if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane, 0LL, fs) && lane == 0) s_abort = 1;
       }
       __syncthreads();
       if (s_abort) return;
@@ -1011,8 +1013,9 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   const bool bf = (mode >> 16) & 1;     // bit 16: bf16 matrix-core inputs
   const bool half = (mode >> 17) & 1;   // bit 17: 8-unit, 256-thread workgroups, two per CU
   const int map = (mode >> 18) & 3;     // bits 18..19: block id -> stream assignment (speed only)
-  const int opt = (mode >> 20) & 7;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD;
-                                        // bit 22: raised static wave priority
+  int opt = (mode >> 20) & 7;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD;
+                                        // bit 22: one flag per 128-byte line
+  if (opt & 4) opt &= ~2;              // one flag per line: no replicas on top (the flag block is sized for either)
   int poll_delay = (mode >> 23) & 31;  // bits 23..27: FwdArgs::poll_delay, units of 0.1 us; 0 = choose, 31 = none
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
@@ -1067,7 +1070,7 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   if (rc) return rc;
   const int gmin = (mode >> 8) & 0xff;
   const bool bf = (mode >> 16) & 1;
-  // block map as sk_lstm_fwd (+4: raised static wave priority, mode bit 22); flag replication was measured here too
+  // block map as sk_lstm_fwd (+4: one flag per 128-byte line, mode bit 22); flag replication was measured here too
   // (7.59 -> 7.50 us/step) and not kept
   const int map = ((mode >> 18) & 3) | (((mode >> 22) & 1) << 2);
   int poll_delay = (mode >> 23) & 31;  // as sk_lstm_fwd; 0 = none here until measured otherwise

@@ -100,8 +100,11 @@ class Engine:
             v = [int(x) for x in os.environ.get(env, default).split(",")]
             v += [0] * (6 - len(v))
             return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5])
-        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0")      # "half,map,poll1,repflags,prio" (r02: 7.33 -> 6.67 us/step)
-        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0")      # (r02: 8.00 -> 7.59 us/step)
+        # "half,map,poll1,repflags,spread,delay" (DESIGN.md 5b).  Forward: streams dealt to XCD groups, one polling wave,
+        # first poll held back (delay 0 = the library's choice); r02: 7.33 -> 6.0 us/step in fp32, 4.0 -> 3.0 in bf16, where
+        # one flag per 128-byte line is worth another 5 %.  Backward: the XCD map only (8.00 -> 7.25; it polls later anyway).
+        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0" if self.bf16 else "0,1,1,0,0,0")
+        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31")
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one.
         # SEPKERN_OVERLAP=2 (default): the recurrence keeps its one-workgroup-per-CU grid and the GEMM blocks
         # become CO-RESIDENT on its CUs -- a persistent workgroup leaves >=124 VGPRs per SIMD lane and >=69 KB of

@@ -432,11 +432,11 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
-def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, prio=False, poll_delay=0):
+def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0):
     """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..23);
     poll_delay: the forward kernel's polling wave holds its first poll of a step back adaptively."""
     return ((0x20000 if half else 0) | ((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) |
-            (0x200000 if repflags else 0) | (0x400000 if prio else 0) | ((int(poll_delay) & 31) << 23))
+            (0x200000 if repflags else 0) | (0x400000 if spread else 0) | ((int(poll_delay) & 31) << 23))
 
 
 def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0):

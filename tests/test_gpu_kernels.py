@@ -497,14 +497,15 @@ def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H,
     valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
     ref = fwd(ops.lstm_variant_bits(False, 0, False, False, False, 31))                # r01 geometry, no hold-back
     for variant in [(False, 1, True, False, False, 0), (False, 1, True, True, False, 8), (False, 2, False, False, False, 31),
-                    (True, 0, False, False, False, 31), (True, 2, True, True, False, 4)]:
+                    (True, 0, False, False, False, 31), (True, 2, True, True, False, 4), (False, 1, True, False, True, 0),
+                    (False, 0, False, False, True, 31)]:
         out = fwd(ops.lstm_variant_bits(*variant))
         for a, b in zip(out, ref):
             if a.dim() == 4 and a.shape[-1] == 4 * H:                                # gates: defined at valid steps only
                 a, b = a[valid], b[valid]
             assert torch.equal(a, b), variant
     bref = bwd(ops.lstm_variant_bits(False, 0, False, False, False, 31), ref)
-    for variant in [(False, 1, False, False, False, 31), (False, 2, False, False, False, 6)]:
+    for variant in [(False, 1, False, False, False, 31), (False, 2, False, False, False, 6), (False, 1, False, False, True, 0)]:
         out = bwd(ops.lstm_variant_bits(*variant), ref)
         for a, b in zip(out, bref):
             assert torch.equal(a, b), variant
