@@ -307,9 +307,9 @@ def main():
             ach1 = fl1 / (ms1 * 1e-3) / 1e12
             res["roofline"]["standalone"] = {
                 "achieved": round(ach1, 2), "frac": round(ach1 / peak, 4), "avg_launch_ms": round(ms1 / n1, 4),
-                "note": "same launches in an untimed pass of 2 steps with co-scheduling off: in the timed region 4 "
-                        "weight-gradient launches per step run co-resident with the next recurrence on its CUs, which "
-                        "shortens the step and lengthens the launches it overlaps"}
+                "note": "same launches in an untimed pass of 2 steps with co-scheduling off: in the timed region the "
+                        "weight-gradient launches of every layer but the first run co-resident with the next recurrence "
+                        "on its CUs, which shortens the step and lengthens the launches it overlaps"}
         res["kernels"] = {k: {"launches_per_step": v[0] // args.steps, "ms_per_step": round(v[1] / args.steps, 3),
                               "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in prof.items()}
         # whole-step figure against the same roofline: 6 x MACs per frame

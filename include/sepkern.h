@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 103
+#define SK_VERSION 104
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -152,8 +152,11 @@ int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const
 /* Reorder the rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g H + u inside each block of 4H
  * rows) and the gate-interleaved order of gx / gates / dgx (row 4u + g).  back = 0: dst[4u+g] = src[gH+u] (weights,
  * biases -> interleaved); back = 1: dst[gH+u] (+)= src[4u+g] (weight gradients back to the parameter order,
- * optionally accumulating).  dbias of sk_lstm_bwd_state is already gate-major. */
-int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int back, int accumulate, sk_stream_t stream);
+ * optionally accumulating).  Rows are ld_src / ld_dst floats apart (>= C); without `accumulate`, columns C..ld_dst-1
+ * of the destination are zeroed, so a copy with a padded leading dimension (257 -> 260: 16-byte aligned rows for
+ * the GEMMs) is made in the same pass.  dbias of sk_lstm_bwd_state is already gate-major. */
+int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int ld_src, int ld_dst, int back, int accumulate,
+                 sk_stream_t stream);
 /* Word 0 of the workspace is a STICKY status word: a launch whose bounded spin gave up sets it (no launch clears
  * it; allocate the workspace zeroed).  Its address can be handed to sk_grad_norm as `guard` (as a float: any
  * non-zero bit pattern counts) so that a failed launch never reaches the weights, without a host sync per step.

@@ -52,6 +52,12 @@ __device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((
 constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 // Poll cadence (units of 64 clocks, s_sleep): a poll is a write-through-coherent load that competes with the CU's own
 // publish traffic and with everybody's flag lines; diagnostic builds vary it (make -C csrc variant NAME=.. DEFS=..)
+#ifndef SK_BF_NSB
+#define SK_BF_NSB 4
+#endif
+#ifndef SK_BF_DEPTH
+#define SK_BF_DEPTH 2
+#endif
 #ifndef SK_POLL_SLEEP
 #define SK_POLL_SLEEP 1
 #endif
@@ -561,10 +567,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
 template <int KS, bool BF>
 struct BwdCfg {
   static constexpr int NQ = BF ? KS / 4 : KS / 2;         // 1 KB chunks per wave (16 k' each in fp32, 32 in bf16)
-  static constexpr int NSB = BF ? 4 : 8;                  // sub-blocks per step (ring = 2 sub-blocks per wave; fp32: 8 keeps
+  static constexpr int NSB = BF ? SK_BF_NSB : 8;          // sub-blocks per step (ring = 2 sub-blocks per wave; fp32: 8 keeps
                                                           // the workgroup at 91 KB of LDS, bf16 measured faster with 4)
   static constexpr int SB = (NQ + NSB - 1) / NSB;         // chunks per sub-block (last may be short)
-  static constexpr int DEPTH = BF ? 2 : 3;                // sub-blocks in flight per wave (ring slots)
+  static constexpr int DEPTH = BF ? SK_BF_DEPTH : 3;      // sub-blocks in flight per wave (ring slots)
   static constexpr int cnt(int sb) { return (sb * SB >= NQ) ? 0 : ((sb + 1) * SB <= NQ ? SB : NQ - sb * SB); }
 };
 
@@ -900,13 +906,13 @@ __global__ __launch_bounds__(256) void first_dg_kernel(const float* __restrict__
 //   back == 0: dst[4u + g] = src[g H + u]            (weights and biases -> the order gx / gates / dgx are kept in)
 //   back == 1: dst[g H + u] (+)= src[4u + g]         (weight gradients -> the order of the parameter tensors)
 __global__ __launch_bounds__(256) void gate_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int H,
-                                                        int C, int back, int accumulate) {
+                                                        int C, int ld_src, int ld_dst, int back, int accumulate) {
   const int rows4 = 4 * H;
   const int blk = blockIdx.x / rows4, r = blockIdx.x % rows4;        // r: interleaved index 4u + g
   const size_t ri = (size_t)blk * rows4 + r, rg = (size_t)blk * rows4 + (size_t)(r & 3) * H + (r >> 2);
-  const float* s = src + (back ? ri : rg) * C;
-  float* d = dst + (back ? rg : ri) * C;
-  if ((C & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+  const float* s = src + (back ? ri : rg) * ld_src;
+  float* d = dst + (back ? rg : ri) * ld_dst;
+  if (((C | ld_src | ld_dst) & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
     for (int c = threadIdx.x * 4; c < C; c += 1024) {
       float4 v = *reinterpret_cast<const float4*>(s + c);
       if (accumulate) {
@@ -918,6 +924,8 @@ __global__ __launch_bounds__(256) void gate_rows_kernel(const float* __restrict_
   } else {
     for (int c = threadIdx.x; c < C; c += 256) d[c] = accumulate ? d[c] + s[c] : s[c];
   }
+  if (!accumulate)  // padding columns of a destination with a wider leading dimension read as zero
+    for (int c = C + threadIdx.x; c < ld_dst; c += 256) d[c] = 0.f;
 }
 
 template <int KS, bool BF>
@@ -1128,11 +1136,12 @@ extern "C" int sk_lstm_status(void* ws, sk_stream_t stream) {
   return SK_OK;
 }
 
-extern "C" int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int back, int accumulate,
-                            sk_stream_t stream) {
-  SK_CHECK_ARG(src && dst && src != dst && nblk > 0 && H > 0 && C > 0, "sk_gate_rows: bad arguments");
+extern "C" int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int ld_src, int ld_dst, int back,
+                            int accumulate, sk_stream_t stream) {
+  SK_CHECK_ARG(src && dst && src != dst && nblk > 0 && H > 0 && C > 0 && ld_src >= C && ld_dst >= C,
+               "sk_gate_rows: bad arguments");
   hipLaunchKernelGGL(gate_rows_kernel, dim3((unsigned)(nblk * 4 * H)), dim3(256), 0, (hipStream_t)stream, src, dst, H, C,
-                     back, accumulate);
+                     ld_src, ld_dst, back, accumulate);
   SK_CHECK_LAUNCH("sk_gate_rows");
   return SK_OK;
 }

@@ -13,7 +13,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEPKERN_LIB") or os.path.join(_HERE, "libsepkern.so")   # SEPKERN_LIB: diagnostic builds
 
-SK_VERSION = 103
+SK_VERSION = 104
 
 _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -36,7 +36,7 @@ PROTOTYPES = {
     "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_bwd_state": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_status": (_i, [_p, _p]),
-    "sk_gate_rows": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "sk_gate_rows": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "sk_bn_workspace_bytes": (_sz, [_i, _i]),
     "sk_bn_stats": (_i, [_p, _i, _i, _p, _p, _p, _p]),
     "sk_bn_update_running": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),

@@ -215,16 +215,23 @@ class Engine:
             ops.colsum(self.flat[off_ih:], 2, 8 * H, 8 * H, bsum)
             # the recurrence keeps i,f,g,o of a cell adjacent (one 16-byte access per cell and step instead of four
             # H-strided ones): reorder the rows of W_ih and of the bias once, the GEMM then writes gx in that order
-            wih_gi = ops.gate_rows(wih.view(8 * H, I), H)
+            # ... and in the same pass pads an input width that is no multiple of 4 (F = 257 -> 260) with zero columns,
+            # so that the rows of both operands of the layer-0 products are 16-byte aligned (float4 fetches)
+            Ip = ops.pad_to(I, 4)
+            inp2d = inp.view(R, I)
+            if Ip != I:
+                inp2d = torch.zeros(R, Ip, device=dev)
+                inp2d[:, :I] = inp.view(R, I)
+            wih_gi = ops.gate_rows(wih.view(8 * H, I), H, out=torch.empty(8 * H, Ip, device=dev), cols=I)
             bsum = ops.gate_rows(bsum, H)
             gx = torch.empty(T, B, 2, 4 * H, device=dev)
-            self._proj(cache, inp.view(R, I), wih_gi, gx.view(R, 8 * H), bsum)
+            self._proj(cache, inp2d, wih_gi, gx.view(R, 8 * H), bsum)
             y = torch.empty(T, B, 2 * H, device=dev)
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
             ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
                               hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
                               T, B, H, self.lstm_mode | self.fwd_bits, bf16=self.bf16)
-            saved.append((inp, gx, cs, y, wih_gi))
+            saved.append((inp2d, gx, cs, y, wih_gi))
             inp, I = y, 2 * H
         if not save:
             ops.lstm_status(ws)          # inference: the caller copies the masks to the host next, a sync costs nothing
@@ -308,8 +315,9 @@ class Engine:
         dc0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
         dx = None
         for l in range(L - 1, -1, -1):
-            inp, gates, cs, y, wih_gi = ctx["saved"][l]
+            inp, gates, cs, y, wih_gi = ctx["saved"][l]          # inp: (R, I padded to a multiple of 4)
             I = I0 if l == 0 else 2 * H
+            Ip = inp.shape[1]
             whh = self.p("weight_hh_l%d" % l)
             dgx = gates                                  # overwritten in place, cell by cell
             # with weight-gradient GEMMs in flight on the side stream: SEPKERN_OVERLAP=1 carries 2 batch groups per
@@ -325,10 +333,10 @@ class Engine:
                               dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None,
                               bf16=self.bf16, dbias=dbias, dg_first=dg_first)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
-                dy_next = torch.empty(R, I, device=dev)
+                dy_next = torch.empty(R, Ip, device=dev)
                 self._dgrad(cache, dgx.view(R, 8 * H), wih_gi, dy_next, "gemm_dgrad")
                 if l == 0:
-                    dx = dy_next.view(T, B, I)
+                    dx = (dy_next if Ip == I else dy_next[:, :I].contiguous()).view(T, B, I)
             stream = self.side if (overlap and l > 0) else main
             if stream is not main:
                 stream.wait_stream(main)
@@ -342,9 +350,9 @@ class Engine:
                 self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, gw_hh, T, B, False, "gemm_" + tag)
                 ops.gate_rows(gw_hh, H, back=True, out=self.g("weight_hh_l%d" % l), accumulate=acc)
                 # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
-                gw_ih = torch.empty(8 * H, I, device=dev)
-                self._wgrad(cache, dgx.view(R, 8 * H), inp.view(R, I), gw_ih, False, "gemm_" + tag)
-                ops.gate_rows(gw_ih, H, back=True, out=self.g("weight_ih_l%d" % l), accumulate=acc)
+                gw_ih = torch.empty(8 * H, Ip, device=dev)
+                self._wgrad(cache, dgx.view(R, 8 * H), inp, gw_ih, False, "gemm_" + tag)
+                ops.gate_rows(gw_ih, H, back=True, out=self.g("weight_ih_l%d" % l).view(8 * H, I), accumulate=acc, cols=I)
                 db = torch.empty(8 * H, device=dev)
                 ops.colsum(dbias, nbg, 8 * H, 8 * H, db, ws_tag="bn_" + tag)       # a few rows: the kernel did the sums
                 put("bias_ih_l%d" % l, db.view(2, 4 * H))

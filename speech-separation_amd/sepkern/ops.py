@@ -483,17 +483,20 @@ def lstm_whh_grad(dgx, y, h0, dg_first, out, T, B, H, accumulate=False, bf16=Fal
          sC=4 * H * H, ws_tag=ws_tag, bf16=bf16)
 
 
-def gate_rows(src, H, back=False, out=None, accumulate=False):
+def gate_rows(src, H, back=False, out=None, accumulate=False, cols=None):
     """Reorder rows of a (nblk * 4H, C) fp32 matrix (or (nblk * 4H,) vector) between torch's gate-major order and the
-    gate-interleaved order of gx / gates / dgx (include/sepkern.h, sk_gate_rows)."""
+    gate-interleaved order of gx / gates / dgx (include/sepkern.h, sk_gate_rows).  src / out may have leading dimensions
+    larger than the `cols` logical columns (default: the narrower of the two)."""
     _chk(src)
     s2 = src.reshape(-1, 1) if src.dim() == 1 else src.reshape(-1, src.shape[-1])
-    if not s2.is_contiguous():
-        raise _lib.SepkernError("gate_rows needs a contiguous matrix")
+    if s2.stride(-1) != 1:
+        raise _lib.SepkernError("gate_rows needs unit-stride rows")
     nblk = s2.shape[0] // (4 * H)
     if out is None:
         out = torch.empty_like(src)
-    _lib.call("sk_gate_rows", _ptr(s2), _ptr(out), nblk, H, s2.shape[1], int(back), int(accumulate), _stream())
+    o2 = out.reshape(-1, 1) if out.dim() == 1 else out.reshape(-1, out.shape[-1])
+    C_ = min(s2.shape[1], o2.shape[1]) if cols is None else cols
+    _lib.call("sk_gate_rows", _ptr(s2), _ptr(o2), nblk, H, C_, s2.stride(0), o2.stride(0), int(back), int(accumulate), _stream())
     return out
 
 
