@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 104
+#define SK_VERSION 105
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -130,6 +130,15 @@ size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
                 int T, int B, int H, int mode, sk_stream_t stream);
+/* The same for processing steps [s_begin, s_end) only (0 <= s_begin < s_end <= T; the forward direction works on
+ * t = s, the reverse one on t = T-1-s): a sequence may be advanced by several calls on the SAME workspace, with no
+ * other recurrence call in between -- the state travels through the workspace; hn / cn are written by the call that
+ * ends at T.  After a call that ends at s_end < T, y[t] is final for t < s_end in the forward half and for
+ * t >= T - s_end in the reverse half: the caller can start consuming those rows (the next layer's input projection)
+ * while a second call finishes the sequence. */
+int sk_lstm_fwd_range(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
+                      float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
+                      int T, int B, int H, int mode, int s_begin, int s_end, sk_stream_t stream);
 /* Backward of the recurrence.  dy (T,B,2H) is the gradient of the layer output; produces
  * dgx (T,B,2,4H) = gradient of the gate pre-activations (gate-interleaved like gx; zero at padded positions), from which
  * the caller forms dW_ih, dW_hh, db and dx with sk_gemm_f32 / sk_colsum, and dh0/dc0 (2,B,H; may

@@ -1011,7 +1011,14 @@ extern "C" size_t sk_lstm_workspace_bytes(int T, int B, int H) {
 extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                            float* y, float* gates, float* cs, float* hn, float* cn, void* ws, int T, int B, int H,
                            int mode, sk_stream_t stream) {
+  return sk_lstm_fwd_range(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, ws, T, B, H, mode, 0, T, stream);
+}
+
+extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float* h0, const float* c0,
+                                 const int32_t* lens, float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
+                                 int T, int B, int H, int mode, int s_begin, int s_end, sk_stream_t stream) {
   SK_CHECK_ARG(gx && whh && h0 && c0 && lens && y && ws, "sk_lstm_fwd: null pointer");
+  SK_CHECK_ARG(s_begin >= 0 && s_begin < s_end && s_end <= T, "sk_lstm_fwd: bad step range [%d, %d) of %d", s_begin, s_end, T);
   SK_CHECK_ARG((gates == nullptr) == (cs == nullptr), "sk_lstm_fwd: gates and cs must be given together");
   SK_CHECK_ARG(((uintptr_t)h0 % 16) == 0, "sk_lstm_fwd: h0 must be 16-byte aligned");
   SK_CHECK_ARG(((uintptr_t)gx % 16) == 0 && ((uintptr_t)gates % 16) == 0, "sk_lstm_fwd: gx / gates must be 16-byte aligned");
@@ -1049,10 +1056,10 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));  // per-launch status word + flags (not the sticky word)
   if (mode == 1 || (mode == 0 && fits)) {
-    a.s_begin = 0; a.s_end = T;
+    a.s_begin = s_begin; a.s_end = s_end;
     dispatch_fwd(L.KS, bf, a, half, nblocks, st);
   } else {
-    for (int s = 0; s < T; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
       a.s_begin = s; a.s_end = s + 1;
       dispatch_fwd(L.KS, bf, a, half, nblocks, st);
     }

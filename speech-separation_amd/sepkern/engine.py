@@ -114,6 +114,8 @@ class Engine:
         # hand-off chain slows from 9.5 to 15.6 ms/step under the GEMMs' L2/fabric load.  =0: no overlap.
         self.overlap_mode = int(os.environ.get("SEPKERN_OVERLAP", "2"))
         self.overlap = self.overlap_mode in (1, 2)
+        # forward: recurrences in two launches with half of the next input projection beside the second (see forward())
+        self.fwd_split = os.environ.get("SEPKERN_FWD_SPLIT", "0") == "1"
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
 
@@ -206,9 +208,9 @@ class Engine:
         ws = None
         hn = torch.empty(2 * L, B, H, device=dev) if want_state else None
         cn = torch.empty(2 * L, B, H, device=dev) if want_state else None
-        for l in range(L):
+        def weights_of(l, I):
+            """(W_ih rows gate-interleaved and padded to Ip columns, summed bias gate-interleaved, Ip) of layer l."""
             wih = self.p("weight_ih_l%d" % l)
-            whh = self.p("weight_hh_l%d" % l)
             # b_ih + b_hh for both directions: the two bias blocks are adjacent rows of a (2, 8H) matrix
             off_ih, _ = self.layout.blocks["bias_ih_l%d" % l]
             bsum = torch.empty(8 * H, device=dev)
@@ -218,21 +220,61 @@ class Engine:
             # ... and in the same pass pads an input width that is no multiple of 4 (F = 257 -> 260) with zero columns,
             # so that the rows of both operands of the layer-0 products are 16-byte aligned (float4 fetches)
             Ip = ops.pad_to(I, 4)
-            inp2d = inp.view(R, I)
-            if Ip != I:
-                inp2d = torch.zeros(R, Ip, device=dev)
-                inp2d[:, :I] = inp.view(R, I)
             wih_gi = ops.gate_rows(wih.view(8 * H, I), H, out=torch.empty(8 * H, Ip, device=dev), cols=I)
-            bsum = ops.gate_rows(bsum, H)
-            gx = torch.empty(T, B, 2, 4 * H, device=dev)
-            self._proj(cache, inp2d, wih_gi, gx.view(R, 8 * H), bsum)
+            return wih_gi, ops.gate_rows(bsum, H), Ip
+
+        # Split recurrences (fp32): a layer that feeds another one runs as TWO launches of T/2 steps.  After the first,
+        # the forward half of y is final for t < T/2 and the reverse half for t >= T/2, so half of the next layer's input
+        # projection -- those rows times the matching half of W_ih -- is issued on the side stream and runs CO-RESIDENT
+        # with the second launch (a recurrence leaves its CU's matrix pipe idle half of the time); the other
+        # half of the product follows on the main stream.  Same sums in a different order: fp32 rounding-level changes.
+        split = (self.fwd_split and self.overlap and not self.bf16 and self.lstm_mode == 0 and T % 2 == 0 and T >= 16 and L > 1)
+        main = torch.cuda.current_stream(dev)
+        if split and self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        keep = []
+        gx_ready = None                                  # (gx, wih_gi) of the NEXT layer when its projection was split in
+        for l in range(L):
+            whh = self.p("weight_hh_l%d" % l)
+            if gx_ready is None:
+                wih_gi, bsum, Ip = weights_of(l, I)
+                inp2d = inp.view(R, I)
+                if Ip != I:
+                    inp2d = torch.zeros(R, Ip, device=dev)
+                    inp2d[:, :I] = inp.view(R, I)
+                gx = torch.empty(T, B, 2, 4 * H, device=dev)
+                self._proj(cache, inp2d, wih_gi, gx.view(R, 8 * H), bsum)
+            else:
+                gx, wih_gi = gx_ready
+                inp2d = inp.view(R, I)
+                gx_ready = None
             y = torch.empty(T, B, 2 * H, device=dev)
             cs = torch.empty(T, B, 2, H, device=dev) if save else None
-            ws = ops.lstm_fwd(gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
-                              hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
-                              T, B, H, self.lstm_mode | self.fwd_bits, bf16=self.bf16)
+            args = (gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
+                    hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
+                    T, B, H, self.lstm_mode | self.fwd_bits)
+            if split and l + 1 < L:
+                S1, half = T // 2, (T // 2) * B              # steps per launch, rows of y per half
+                nw, nb, _ = weights_of(l + 1, 2 * H)         # (8H, 2H) interleaved rows, bias
+                ngx = torch.empty(T, B, 2, 4 * H, device=dev)
+                ws = ops.lstm_fwd(*args, bf16=False, steps=(0, S1))
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    # rows t < T/2: forward half of y (columns :H) x W[:, :H]^T;  rows t >= T/2: reverse half x W[:, H:]^T
+                    ops.gemm(y.view(R, 2 * H), nw, ngx.view(R, 8 * H), half, 8 * H, H, 2 * H, 2 * H, 8 * H, transB=True, bias=nb,
+                             batch=2, sA=half * 2 * H + H, sB=H, sC=half * 8 * H, sbias=0)
+                ws = ops.lstm_fwd(*args, bf16=False, steps=(S1, T))
+                main.wait_stream(self.side)
+                # the other halves, accumulated: rows t < T/2 x W[:, H:]^T of the reverse half, rows t >= T/2 x W[:, :H]^T
+                ops.gemm(y.view(-1)[H:], nw.view(-1)[H:], ngx.view(R, 8 * H), half, 8 * H, H, 2 * H, 2 * H, 8 * H, transB=True,
+                         accumulate=True, batch=2, sA=half * 2 * H - H, sB=-H, sC=half * 8 * H)
+                gx_ready = (ngx, nw)
+                keep += [nw, nb, ngx, y]
+            else:
+                ws = ops.lstm_fwd(*args, bf16=self.bf16)
             saved.append((inp2d, gx, cs, y, wih_gi))
             inp, I = y, 2 * H
+        del keep
         if not save:
             ops.lstm_status(ws)          # inference: the caller copies the masks to the host next, a sync costs nothing
         y2d = inp.view(R, 2 * H)

@@ -439,15 +439,17 @@ def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, sprea
             (0x200000 if repflags else 0) | (0x400000 if spread else 0) | ((int(poll_delay) & 31) << 23))
 
 
-def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0):
+def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0, steps=None):
     """bf16=True: W_hh and h_{t-1} enter the matrix cores rounded to bf16 (fp32 accumulate, fp32 state).
     half=True: 8-unit / 256-thread workgroups, two per CU (include/sepkern.h, mode bit 17); blockmap 0..2: which
-    workgroups share an XCD / a CU (mode bits 18..19; speed only)."""
+    workgroups share an XCD / a CU (mode bits 18..19; speed only).  steps=(s0, s1): only that range of processing
+    steps (sk_lstm_fwd_range: consecutive calls on the same workspace advance one sequence)."""
     ws = lstm_ws(T, B, H)
     mode = int(mode) | (0x10000 if bf16 else 0) | (0x20000 if half else 0) | ((int(blockmap) & 3) << 18)
-    with _timed("lstm_fwd_kernel", 2.0 * T * B * 2 * 4 * H * H):
-        _lib.call("sk_lstm_fwd", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(y), _ptr(gates), _ptr(cs),
-                  _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, _stream())
+    s0, s1 = (0, T) if steps is None else steps
+    with _timed("lstm_fwd_kernel", 2.0 * (s1 - s0) * B * 2 * 4 * H * H):
+        _lib.call("sk_lstm_fwd_range", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(y), _ptr(gates), _ptr(cs),
+                  _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, s0, s1, _stream())
     return ws
 
 

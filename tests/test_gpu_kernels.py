@@ -509,3 +509,39 @@ def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H,
         out = bwd(ops.lstm_variant_bits(*variant), ref)
         for a, b in zip(out, bref):
             assert torch.equal(a, b), variant
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("T,B,H,lens,cuts", [(10, 32, 896, [10] * 20 + [7] * 8 + [2] * 4, (5,)), (9, 20, 300, [9] * 7 + [4] * 13, (2, 7)),
+                                             (8, 16, 64, [8] * 10 + [3] * 6, (1, 4))])
+def test_lstm_forward_in_step_ranges_equals_one_launch(ops, mode, bf16, T, B, H, lens, cuts):
+    """sk_lstm_fwd_range: a sequence advanced by consecutive launches over [0, s1), [s1, s2), ... [sk, T) on one workspace
+    gives, bit for bit, what one launch over [0, T) gives -- outputs, saved gates / cell states and the final state (the
+    engine splits a layer in two to run half of the next input projection beside the second launch)."""
+    g = torch.Generator().manual_seed(3 * H + T)
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+
+    def fwd(ranges):
+        gg = gx.clone()
+        y = torch.zeros(T, B, 2 * H).cuda()
+        cs = torch.zeros(T, B, 2, H).cuda()
+        hn, cn = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+        for r in ranges:
+            ws = ops.lstm_fwd(gg, whh, h0, c0, lens_d, y, gg, cs, hn, cn, T, B, H, mode, bf16=bf16, steps=r)
+        ops.lstm_status(ws)
+        return y, gg, cs, hn, cn
+
+    valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
+    ref = fwd([None])
+    edges = (0,) + tuple(cuts) + (T,)
+    out = fwd(list(zip(edges[:-1], edges[1:])))
+    for a, b in zip(out, ref):
+        if a.dim() == 4 and a.shape[-1] == 4 * H:
+            a, b = a[valid], b[valid]
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        ops.lstm_fwd(gx, whh, h0, c0, lens_d, out[0], None, None, None, None, T, B, H, mode, steps=(3, 3))

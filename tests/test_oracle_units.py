@@ -167,3 +167,21 @@ def test_bf16_oracle_without_rounding_is_the_fp32_oracle(monkeypatch):
     l2, _, a2 = OB.compute_loss(model, batch, hidden)
     assert 0 < abs(float(l2) - float(l0)) < 2e-2 * abs(float(l0))
     assert np.abs(a2["mask_out"].detach().numpy() - a0["mask_out"].detach().numpy()).max() < 3e-2
+
+
+def test_frame_counts_from_file_headers(tmp_path):
+    """sepkern/data.py: frames per utterance for length-balanced sharding, read from the npz member header / the wav header
+    without decoding the payload (steps/extract_feats.py:90 writes zlib-compressed npz, (257, T) per key)."""
+    import scipy.io.wavfile
+    from sepkern.data import npz_frames, wav_frames
+    rng = np.random.default_rng(0)
+    for T in (1, 37, 400):
+        p = str(tmp_path / ("u%d.npz" % T))
+        np.savez_compressed(p, mix=rng.standard_normal((257, T)).astype(np.float32), s1=np.zeros((257, T), np.float32))
+        assert npz_frames(p) == T
+        np.savez_compressed(p, mix=(rng.standard_normal((257, T)) + 1j).astype(np.complex64))
+        assert npz_frames(p) == T
+    for n in (128, 1000, 51072):
+        p = str(tmp_path / ("w%d.wav" % n))
+        scipy.io.wavfile.write(p, 8000, np.zeros(n, np.int16))
+        assert wav_frames(p) == 1 + n // 128
