@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 105
+#define SK_VERSION 106
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -79,12 +79,16 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
                 int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, sk_stream_t stream);
 /* Same product with K split into `splitk` slices (for weight gradients: few output tiles, K = T*B rows):
  * slices write dense partial slabs into ws (>= sk_gemm_workspace_bytes), a second kernel adds them in
- * fixed slice order and applies bias / accumulate / act -- deterministic, no atomics. */
+ * fixed slice order and applies bias / accumulate / act -- deterministic, no atomics.
+ * variant (speed only, results agree to fp32 summation order): 0 = choose -- operand tiles DMA'd straight into LDS when
+ * every operand row is 16-byte aligned and K is a multiple of 16, the register-staged kernel otherwise; 1 = always
+ * the register-staged kernel (the engine's choice for products it runs co-resident with a recurrence: it leaves
+ * the recurrence more of the matrix pipe). */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                        int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
                        int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws,
-                       sk_stream_t stream);
+                       int variant, sk_stream_t stream);
 /* Same contract, bf16 matrix-core inputs (BASELINE configs[3]: "bf16"): A and B stay fp32 in memory and are
  * rounded to bf16 (round-to-nearest-even) on the way into the matrix cores; products are exact and are
  * accumulated in fp32; C, bias, slabs are fp32.  Equals an fp32 GEMM of the bf16-rounded operands up to

@@ -102,6 +102,34 @@ __device__ __forceinline__ void stash(float (*S)[LD], int tid, const float4 (&r)
   }
 }
 
+// Epilogue of one wave's 64 x 64 sub-tile at (row0, col0).  C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16 (&acc)[2][2], float* C, int ldc, const float* bias,
+                                           bool partial, int row0, int col0, int lane) {
+  const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < g.M) {
+          float* cp = C + (int64_t)row * ldc + col;
+          float v = acc[i][j][r] + bv;
+          if (!partial) {
+            if (g.accumulate) v += *cp;
+            if (g.act == 1) v = sk_sigmoid(v);
+          }
+          *cp = v;
+        }
+      }
+    }
+}
+
 // VEC == false: the variant for operands with unaligned rows (both operands then use dword loads).
 template <bool TA, bool TB, bool VEC = true>
 __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
@@ -185,28 +213,151 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
     cur ^= 1;
   }
 
-  // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The same product with both operand tiles DMA'd from global memory STRAIGHT INTO LDS (global_load_lds_dwordx4: no
+// staging registers, no ds_write), for operands whose rows are 16-byte aligned and a K range that is a multiple of 16.
+// Same block / wave / MFMA tiling and the same epilogue as gemm_f32_kernel, so the two are interchangeable per launch.
+// A DMA writes lane-linearly (lane l -> LDS base + 16 l), so the LDS image is shaped on the SOURCE side:
+//   operand stored [dim][K] (A of NN / NT, B of NT): piece q = tile rows 16q .. 16q+15, lane l fetches k chunk l>>4
+//     (4 floats) of row l&15 -> image offset (row>>4) * 1024 + chunk * 256 + (row&15) * 16: a wave instruction still
+//     covers 16 rows x 64 contiguous bytes of memory, and a fragment is ONE ds_read_b128 per lane (16 consecutive
+//     rows x one chunk = 16 distinct 16-byte bank groups).  The four floats of a chunk feed four MFMA steps: the K
+//     index of step (c', i) is 8c' + 4 (lane>>5) + i -- any K order is a valid K order as long as both operands agree.
+//   operand stored [K][dim] (A of TN, B of NN / TN): piece q = k rows 2q, 2q+1, 128 dims each; in rows with bit 2 of
+//     k set the two 32-dim halves of every 64 are swapped (lane fetches dim ^ 32), so that the two half-waves of a
+//     fragment read (k and k+4, same dims) fall on opposite halves of the 64 banks: conflict-free ds_read_b32.
+// Rows / dims past the matrix edge are clamped to valid addresses: their products land in rows / columns never stored.
+template <bool KMAJOR>
+__device__ __forceinline__ const float* dma_src(const float* P, int ld, int dim0, int dimLimit, int k0, int piece, int lane) {
+  if (KMAJOR) {
+    const int krow = 2 * piece + (lane >> 5);
+    const int dim = (4 * (lane & 31)) ^ (((krow >> 2) & 1) << 5);
+    return P + (int64_t)(k0 + krow) * ld + min(dim0 + dim, dimLimit - 4);
+  } else {
+    const int row = 16 * piece + (lane & 15), c = lane >> 4;
+    return P + (int64_t)min(dim0 + row, dimLimit - 1) * ld + k0 + 4 * c;
+  }
+}
+
+// byte offset inside an 8 KB operand image of this lane's fragment data for the 32-row fragment starting at row d0
+// (a multiple of 32), before the per-step immediates (dim-major: + 512 c'; k-major: + 512 (8c' + i))
+template <bool KMAJOR>
+__device__ __forceinline__ int frag_base(int d0, int lane) {
+  const int l31 = lane & 31, kh = lane >> 5;
+  if (KMAJOR) return 4 * kh * 512 + ((d0 ^ (kh << 5)) + l31) * 4;
+  return ((d0 + l31) >> 4) * 1024 + kh * 256 + (l31 & 15) * 16;
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void frag_load(const char* img, int base, int cp, float (&v)[4]) {
+  if (KMAJOR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float*>(img + base + (8 * cp + i) * 512);
+  } else {
+    const float4 q = *reinterpret_cast<const float4*>(img + base + cp * 512);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  }
+}
+
+// One DMA instruction (64 lanes x 16 bytes -> 1 KB of LDS at lds_addr) as inline assembly: hipcc puts an
+// s_waitcnt vmcnt(0) in front of every LDS read that follows an LDS-DMA BUILTIN it cannot prove disjoint, which
+// serialises the next tile's fetch with this tile's products.  The kernel orders DMA and reads itself (vmcnt(0) +
+// barrier at the top of each K step).  M0 = LDS base of the instruction (wave-uniform).
+__device__ __forceinline__ void dma_1k(const float* src, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory");
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(GemmArgs g) {
+  constexpr int TILE = BM * BK * 4;  // 8 KB per operand image
+  __shared__ __attribute__((aligned(1024))) char lds[2][2 * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
+    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+  }
+  int m0, n0;
+  {
+    const int tilesM = gridDim.x / g.tilesN, per = GROUP_M * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GROUP_M;
+    const int gsz = min(GROUP_M, tilesM - first);
+    m0 = (first + rem2 % gsz) * BM;
+    n0 = (rem2 / gsz) * BN;
+  }
+  const int z = blockIdx.z, ks = blockIdx.y;
+  const float* A = g.A + z * g.sA;
+  const float* B = g.B + z * g.sB;
+  const bool partial = g.splitk > 1;
+  float* C = partial ? g.slabs + ((int64_t)z * g.splitk + ks) * g.M * g.N : g.C + z * g.sC;
+  const int ldc = partial ? g.N : g.ldc;
+  const float* bias = (g.bias && !partial) ? g.bias + z * g.sbias : nullptr;
+  const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / BK;  // the host sends only K ranges that are multiples of BK here
+
+  // A is k-major in memory when TA (stored K x M); B is k-major when !TB (stored K x N).  Wave w DMAs pieces 2w, 2w+1.
+  const float* srcA[2];
+  const float* srcB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    srcA[i] = dma_src<TA>(A, g.lda, m0, g.M, kbeg, 2 * wave + i, lane);
+    srcB[i] = dma_src<!TB>(B, g.ldb, n0, g.N, kbeg, 2 * wave + i, lane);
+  }
+  const int64_t stepA = TA ? (int64_t)BK * g.lda : BK, stepB = !TB ? (int64_t)BK * g.ldb : BK;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
+  const unsigned my_pieces = __builtin_amdgcn_readfirstlane(lds_base + 2 * wave * 1024);
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dma_1k(srcA[i], my_pieces + buf * 2 * TILE + i * 1024);
+      dma_1k(srcB[i], my_pieces + buf * 2 * TILE + TILE + i * 1024);
+      srcA[i] += stepA;
+      srcB[i] += stepB;
+    }
+  };
+
+  f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + l31;
-      if (col >= g.N) continue;
-      const float bv = bias ? bias[col] : 0.f;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row < g.M) {
-          float* cp = C + (int64_t)row * ldc + col;
-          float v = acc[i][j][r] + bv;
-          if (!partial) {
-            if (g.accumulate) v += *cp;
-            if (g.act == 1) v = sk_sigmoid(v);
-          }
-          *cp = v;
-        }
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fa0 = frag_base<TA>(wm * 64, lane), fa1 = frag_base<TA>(wm * 64 + 32, lane);
+  const int fb0 = frag_base<!TB>(wn * 64, lane), fb1 = frag_base<!TB>(wn * 64 + 32, lane);
+
+  if (nk > 0) stage(0);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step kt have landed ...
+    __syncthreads();                                   // ... and everybody's; all reads of the other buffer are done
+    if (kt + 1 < nk) stage(cur ^ 1);
+    const char* ai = lds[cur];
+    const char* bi = lds[cur] + TILE;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      float a0[4], a1[4], b0[4], b1[4];
+      frag_load<TA>(ai, fa0, cp, a0);
+      frag_load<TA>(ai, fa1, cp, a1);
+      frag_load<!TB>(bi, fb0, cp, b0);
+      frag_load<!TB>(bi, fb1, cp, b1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc[1][1], 0, 0, 0);
       }
     }
+    cur ^= 1;
+  }
+  store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -653,15 +804,31 @@ extern "C" int sk_gemm_f32(const float* A, const float* B, float* C, const float
                            int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA,
                            int64_t sB, int64_t sC, int64_t sbias, sk_stream_t stream) {
   return sk_gemm_f32_splitk(A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, accumulate, act, batch, sA, sB, sC,
-                            sbias, 1, nullptr, stream);
+                            sbias, 1, nullptr, 0, stream);
 }
 
 namespace {
 
+// The LDS-DMA kernel takes a launch when every operand row is 16-byte aligned, every K slice is a multiple of its
+// K step, a k-major operand's tile dimension is a multiple of 4 (whole float4 pieces) and it is not the T/T form.
+// SEPKERN_GEMM_DMA=0 (diagnostics) keeps everything on the register-staged kernel.
+bool dma_ok(const GemmArgs& g, int transA, int transB) {
+  static const bool enabled = [] {
+    const char* e = getenv("SEPKERN_GEMM_DMA");
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled || !g.vecA || !g.vecB || (transA && transB)) return false;
+  if (g.K % BK != 0 || g.kchunk % BK != 0) return false;
+  if (transA && (g.M % 4 != 0 || g.M < 4)) return false;
+  if (!transB && (g.N % 4 != 0 || g.N < 4)) return false;
+  return true;
+}
+
 int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
-                int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
+                int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
+  SK_CHECK_ARG(variant == 0 || variant == 1, "sk_gemm: unknown variant %d", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
@@ -692,6 +859,13 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, g);
     else
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, g);
+  } else if (variant == 0 && dma_ok(g, transA, transB)) {
+    if (!transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false>), grid, dim3(256), 0, st, g);
+    else if (!transA && transB)
+      hipLaunchKernelGGL((gemm_f32_dma_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false>), grid, dim3(256), 0, st, g);
   } else if (g.vecA && g.vecB) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
@@ -725,16 +899,16 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
 
 extern "C" int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                            int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA,
-                           int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
+                           int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   return gemm_launch(false, A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, accumulate, act, batch, sA, sB, sC,
-                     sbias, splitk, ws, stream);
+                     sbias, splitk, ws, variant, stream);
 }
 
 extern "C" int sk_gemm_bf16_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
                            int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA,
                            int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
   return gemm_launch(true, A, B, C, bias, M, N, K, lda, ldb, ldc, transA, transB, accumulate, act, batch, sA, sB, sC,
-                     sbias, splitk, ws, stream);
+                     sbias, splitk, ws, 0, stream);
 }
 
 // ---------------------------------------------------------------- bf16 operands in memory (NT form)

@@ -116,6 +116,7 @@ class Engine:
         self.overlap = self.overlap_mode in (1, 2)
         # forward: recurrences in two launches with half of the next input projection beside the second (see forward())
         self.fwd_split = os.environ.get("SEPKERN_FWD_SPLIT", "0") == "1"
+        self.side_staged = os.environ.get("SEPKERN_SIDE_STAGED", "1") == "1"   # see _wgrad
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
 
@@ -164,24 +165,27 @@ class Engine:
         a, bt = self._copy(cache, "row", dout2d), self._copy(cache, "t", w)      # w^T: (K, N padded)
         ops.gemm_bf16_nt(a, bt, out2d, R, K, a.shape[1], a.shape[1], bt.shape[1], K, splitk=0, ws_tag=ws_tag)
 
-    def _wgrad(self, cache, dout2d, inp2d, gw, acc, ws_tag):
-        """gw (N, K) [+]= dout (R, N)^T inp (R, K)."""
+    def _wgrad(self, cache, dout2d, inp2d, gw, acc, ws_tag, beside=False):
+        """gw (N, K) [+]= dout (R, N)^T inp (R, K).  beside=True: the product runs co-resident with a recurrence (side
+        stream): the register-staged GEMM kernel, which leaves the recurrence more of the matrix pipe than the LDS-DMA
+        one does (measured: same step time with either, 2 ms longer recurrences with the latter)."""
         R, N = dout2d.shape
         K = inp2d.shape[1]
         if not self.nt:
             ops.gemm(dout2d, inp2d, gw, N, K, R, N, inp2d.stride(0), K, transA=True, accumulate=acc, splitk=0,
-                     ws_tag=ws_tag, bf16=self.bf16)
+                     ws_tag=ws_tag, bf16=self.bf16, staged=beside and self.side_staged)
             return
         at, bt = self._copy(cache, "t", dout2d), self._copy(cache, "t", inp2d)    # (N, R padded), (K, R padded)
         ops.gemm_bf16_nt(at, bt, gw, N, K, ops.pad_to(R, 64), at.shape[1], bt.shape[1], K, accumulate=acc, splitk=0,
                          ws_tag=ws_tag)
 
-    def _whh_grad(self, cache, dgx2d, y2d, h0, dg_first, gw, T, B, acc, ws_tag):
+    def _whh_grad(self, cache, dgx2d, y2d, h0, dg_first, gw, T, B, acc, ws_tag, beside=False):
         """dW_hh (2,4H,H) [+]= sum_t dG_t^T h_prev(t) (ops.lstm_whh_grad); in bf16 from the transposed copies: the time
         shift is an offset of B columns into one of them, and the copies end in >= 64 zero columns."""
         H = self.H
         if not (self.nt and T > 1 and B % 8 == 0):
-            ops.lstm_whh_grad(dgx2d, y2d, h0, dg_first, gw, T, B, H, accumulate=acc, bf16=self.bf16, ws_tag=ws_tag)
+            ops.lstm_whh_grad(dgx2d, y2d, h0, dg_first, gw, T, B, H, accumulate=acc, bf16=self.bf16, ws_tag=ws_tag,
+                              staged=beside and self.side_staged)
             return
         at, bt = self._copy(cache, "t", dgx2d), self._copy(cache, "t", y2d)       # (8H, ld), (2H, ld)
         ld = at.shape[1]
@@ -336,7 +340,7 @@ class Engine:
         if stream is not main:
             stream.wait_stream(main)
         with torch.cuda.stream(stream):
-            self._wgrad(cache, dz2d, ctx["xbn"], self.g("lin.weight"), acc, "gemm_side" if overlap else "gemm")
+            self._wgrad(cache, dz2d, ctx["xbn"], self.g("lin.weight"), acc, "gemm_side" if overlap else "gemm", beside=overlap)
             ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc, ws_tag="bn_side" if overlap else "bn")
             keep.append(dz)
         del dz
@@ -389,11 +393,12 @@ class Engine:
                 # dW_hh[d] = sum_t dG_t^T h_prev(t): the layer output shifted by one step in time (+ the h0 steps)
                 # (rows come out gate-interleaved, like dgx: sk_gate_rows puts them back into the parameters' order)
                 gw_hh = torch.empty(2, 4 * H, H, device=dev)
-                self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, gw_hh, T, B, False, "gemm_" + tag)
+                beside = stream is not main
+                self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, gw_hh, T, B, False, "gemm_" + tag, beside)
                 ops.gate_rows(gw_hh, H, back=True, out=self.g("weight_hh_l%d" % l), accumulate=acc)
                 # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
                 gw_ih = torch.empty(8 * H, Ip, device=dev)
-                self._wgrad(cache, dgx.view(R, 8 * H), inp, gw_ih, False, "gemm_" + tag)
+                self._wgrad(cache, dgx.view(R, 8 * H), inp, gw_ih, False, "gemm_" + tag, beside)
                 ops.gate_rows(gw_ih, H, back=True, out=self.g("weight_ih_l%d" % l).view(8 * H, I), accumulate=acc, cols=I)
                 db = torch.empty(8 * H, device=dev)
                 ops.colsum(dbias, nbg, 8 * H, 8 * H, db, ws_tag="bn_" + tag)       # a few rows: the kernel did the sums

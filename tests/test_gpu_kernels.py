@@ -33,6 +33,9 @@ def dev(t):
     (300, 200, 257, False, True),      # layer-0 input projection shape class (K=257: unaligned rows)
     (256, 256, 64, False, False), (256, 256, 64, True, False), (256, 256, 64, False, True), (256, 256, 64, True, True),
     (130, 514, 96, False, True), (1000, 72, 1, False, False), (129, 131, 300, True, False), (64, 1792, 514, False, False),
+    # shapes the LDS-DMA kernel takes (aligned rows, K % 16 == 0), with ragged tile edges in M and N
+    (300, 260, 512, False, True), (300, 260, 528, False, False), (132, 516, 1024, True, False), (1000, 772, 1792, False, True),
+    (517, 1792, 3584, False, False), (1028, 132, 2048, True, False), (1, 4, 16, False, True), (4, 4, 16, True, False),
 ])
 def test_gemm_matches_fp64(ops, M, N, K, tA, tB):
     g = torch.Generator().manual_seed(M * 7 + N)
@@ -101,7 +104,8 @@ def test_gemm_accumulate_sigmoid_batch_and_ld(ops):
     np.testing.assert_allclose(out.cpu().numpy(), torch.sigmoid(X.double() @ W.double().t() + b.double()).numpy(), atol=2e-6)
 
 
-@pytest.mark.parametrize("M,N,K,S", [(300, 260, 5000, 5), (140, 257, 3000, 3), (129, 64, 4096, 0)])
+@pytest.mark.parametrize("M,N,K,S", [(300, 260, 5000, 5), (140, 257, 3000, 3), (129, 64, 4096, 0), (132, 64, 4096, 0),
+                                     (300, 260, 4096, 4), (140, 260, 3008, 1)])
 def test_gemm_splitk_is_deterministic_and_matches_fp64(ops, M, N, K, S):
     g = torch.Generator().manual_seed(K)
     A, B = torch.randn(K, 2 * M, generator=g), torch.randn(K, 2 * N, generator=g)     # weight-gradient shape (TN)
