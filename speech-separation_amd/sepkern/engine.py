@@ -116,7 +116,10 @@ class Engine:
         self.overlap = self.overlap_mode in (1, 2)
         # forward: recurrences in two launches with half of the next input projection beside the second (see forward())
         self.fwd_split = os.environ.get("SEPKERN_FWD_SPLIT", "0") == "1"
-        self.side_staged = os.environ.get("SEPKERN_SIDE_STAGED", "1") == "1"   # see _wgrad
+        # fp32 GEMM kernel per stream (sk_gemm_f32_splitk's variant): "main,side".  Default: choose (LDS-DMA where it
+        # applies) on the main stream, the register-staged kernel for products that run beside a recurrence (_wgrad).
+        # "2,2": every product by the exact three-way bf16 split on the bf16 matrix pipe (opt-in).
+        self.var_main, self.var_side = (int(v) for v in os.environ.get("SEPKERN_GEMM_VARIANTS", "0,1").split(","))
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
 
@@ -150,7 +153,8 @@ class Engine:
         R, K = inp2d.shape
         N = w.shape[0]
         if not self.nt:
-            ops.gemm(inp2d, w, out2d, R, N, K, inp2d.stride(0), K, N, transB=True, bias=bias, act=act, bf16=self.bf16)
+            ops.gemm(inp2d, w, out2d, R, N, K, inp2d.stride(0), K, N, transB=True, bias=bias, act=act, bf16=self.bf16,
+                     variant=self.var_main)
             return
         a, b = self._copy(cache, "row", inp2d), self._copy(cache, "row", w)
         ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act)
@@ -160,7 +164,7 @@ class Engine:
         R, N = dout2d.shape
         K = w.shape[1]
         if not self.nt:
-            ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=0, ws_tag=ws_tag, bf16=self.bf16)
+            ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=0, ws_tag=ws_tag, bf16=self.bf16, variant=self.var_main)
             return
         a, bt = self._copy(cache, "row", dout2d), self._copy(cache, "t", w)      # w^T: (K, N padded)
         ops.gemm_bf16_nt(a, bt, out2d, R, K, a.shape[1], a.shape[1], bt.shape[1], K, splitk=0, ws_tag=ws_tag)
@@ -173,7 +177,7 @@ class Engine:
         K = inp2d.shape[1]
         if not self.nt:
             ops.gemm(dout2d, inp2d, gw, N, K, R, N, inp2d.stride(0), K, transA=True, accumulate=acc, splitk=0,
-                     ws_tag=ws_tag, bf16=self.bf16, staged=beside and self.side_staged)
+                     ws_tag=ws_tag, bf16=self.bf16, variant=self.var_side if beside else self.var_main)
             return
         at, bt = self._copy(cache, "t", dout2d), self._copy(cache, "t", inp2d)    # (N, R padded), (K, R padded)
         ops.gemm_bf16_nt(at, bt, gw, N, K, ops.pad_to(R, 64), at.shape[1], bt.shape[1], K, accumulate=acc, splitk=0,
@@ -185,7 +189,7 @@ class Engine:
         H = self.H
         if not (self.nt and T > 1 and B % 8 == 0):
             ops.lstm_whh_grad(dgx2d, y2d, h0, dg_first, gw, T, B, H, accumulate=acc, bf16=self.bf16, ws_tag=ws_tag,
-                              staged=beside and self.side_staged)
+                              variant=self.var_side if beside else self.var_main)
             return
         at, bt = self._copy(cache, "t", dgx2d), self._copy(cache, "t", y2d)       # (8H, ld), (2H, ld)
         ld = at.shape[1]

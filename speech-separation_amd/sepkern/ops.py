@@ -109,12 +109,13 @@ def pick_splitk(M, N, K, batch=1):
 
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, accumulate=False, act=0,
-         batch=1, sA=0, sB=0, sC=0, sbias=0, splitk=1, ws_tag="gemm", bf16=False, staged=False):
+         batch=1, sA=0, sB=0, sC=0, sbias=0, splitk=1, ws_tag="gemm", bf16=False, variant=0):
     """Cout[M,N] = act(opA(A) opB(B) + bias (+ Cout)).  A/B/Cout are tensors whose data_ptr() is the
     first element of the operand (views are fine: leading dimensions are explicit).  splitk > 1 (or 0 =
     choose) splits K into deterministic partial slabs -- for weight gradients.  bf16=True rounds A and B to
-    bf16 on the way into the matrix cores (fp32 accumulate; everything in memory stays fp32).  staged=True (fp32):
-    the register-staged kernel even where the LDS-DMA one applies (sk_gemm_f32_splitk's `variant`: speed only)."""
+    bf16 on the way into the matrix cores (fp32 accumulate; everything in memory stays fp32).  variant (fp32 only,
+    sk_gemm_f32_splitk's `variant`): 0 choose, 1 the register-staged kernel even where the LDS-DMA one applies,
+    2 exact three-way bf16 split of both operands on the bf16 matrix pipe (fp32 products, another summation order)."""
     for t in (A, B, Cout, bias):
         _chk(t)
     if splitk == 0:
@@ -128,7 +129,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
         if bf16:
             _lib.call("sk_gemm_bf16_splitk", *args, _stream())
         else:
-            _lib.call("sk_gemm_f32_splitk", *args, int(staged), _stream())
+            _lib.call("sk_gemm_f32_splitk", *args, int(variant), _stream())
 
 
 def pad_to(n, m):
@@ -473,7 +474,7 @@ def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=N
     return ws
 
 
-def lstm_whh_grad(dgx, y, h0, dg_first, out, T, B, H, accumulate=False, bf16=False, ws_tag="gemm", staged=False):
+def lstm_whh_grad(dgx, y, h0, dg_first, out, T, B, H, accumulate=False, bf16=False, ws_tag="gemm", variant=0):
     """dW_hh (2,4H,H) [+]= sum_t dG_t^T h_{prev(t)} for both directions, WITHOUT materialising h_prev: the recurrent
     input of step t is the layer's own output one step earlier in processing order, so
       forward : dgx[1:, :, 0]^T  y[:-1, :, :H]   (rows past a sequence's end have dG = 0)
@@ -484,7 +485,7 @@ def lstm_whh_grad(dgx, y, h0, dg_first, out, T, B, H, accumulate=False, bf16=Fal
     if T > 1:
         A = dgx.view(-1)[B * 8 * H:]                     # direction 0 starts at t = 1; direction 1 at t = 0, +4H
         gemm(A, y, out, 4 * H, H, (T - 1) * B, 8 * H, 2 * H, H, transA=True, accumulate=acc, batch=2,
-             sA=4 * H - B * 8 * H, sB=B * 2 * H + H, sC=4 * H * H, splitk=0, ws_tag=ws_tag, bf16=bf16, staged=staged)
+             sA=4 * H - B * 8 * H, sB=B * 2 * H + H, sC=4 * H * H, splitk=0, ws_tag=ws_tag, bf16=bf16, variant=variant)
         acc = True
     gemm(dg_first, h0, out, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=acc, batch=2, sA=B * 4 * H, sB=B * H,
          sC=4 * H * H, ws_tag=ws_tag, bf16=bf16)

@@ -55,12 +55,20 @@ def main():
     if "--nt" in sys.argv:
         return bench_nt()
     bf16 = "--bf16" in sys.argv
-    for name, M, N, K, tA, tB, batch, sk in SHAPES:
+    variant = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 0   # sk_gemm_f32_splitk's variant
+    shapes = SHAPES
+    if "--shape" in sys.argv:                       # --shape M,N,K,tA,tB[,splitk]  (may repeat)
+        shapes = []
+        for i, a in enumerate(sys.argv):
+            if a == "--shape":
+                v = [int(x) for x in sys.argv[i + 1].split(",")]
+                shapes.append(("custom", v[0], v[1], v[2], bool(v[3]), bool(v[4]), 1, v[5] if len(v) > 5 else 1))
+    for name, M, N, K, tA, tB, batch, sk in shapes:
         A = torch.randn((K, M * batch) if tA else (M, K), device="cuda")
         B = torch.randn((N, K) if tB else (K, N * batch), device="cuda")
         C = torch.empty(batch, M, N, device="cuda")
         lda, ldb = A.shape[1], B.shape[1]
-        kw = dict(transA=tA, transB=tB, batch=batch, sA=M if batch > 1 else 0, sB=N if batch > 1 else 0, sC=M * N, splitk=sk, bf16=bf16)
+        kw = dict(transA=tA, transB=tB, batch=batch, sA=M if batch > 1 else 0, sB=N if batch > 1 else 0, sC=M * N, splitk=sk, bf16=bf16, variant=variant)
         used = ops.pick_splitk(M, N, K, batch) if sk == 0 else sk
         for _ in range(2):
             ops.gemm(A, B, C, M, N, K, lda, ldb, N, **kw)

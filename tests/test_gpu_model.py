@@ -311,7 +311,7 @@ def test_coscheduled_backward_is_bitwise_the_serial_backward(arch):
     arch.compute_loss(model, 0, batch)[0].backward()          # builds the engine
     assert model._engine.overlap, "co-scheduling is expected to be on by default"
     model._engine.fwd_split = False                            # (changes the order of sums: its own test below)
-    model._engine.side_staged = False                          # same GEMM kernel on either stream (the default picks the
+    model._engine.var_side = model._engine.var_main            # same GEMM kernel on either stream (the default picks the
                                                                # register-staged one beside a recurrence: other K order)
     g_ser, l_ser = grads(False)
     for _ in range(3):
