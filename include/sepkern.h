@@ -78,8 +78,10 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
                 int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
                 int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, sk_stream_t stream);
 /* Same product with K split into `splitk` slices (for weight gradients: few output tiles, K = T*B rows):
- * slices write dense partial slabs into ws (>= sk_gemm_workspace_bytes), a second kernel adds them in
- * fixed slice order and applies bias / accumulate / act -- deterministic, no atomics.
+ * slices write dense partial slabs into ws (>= sk_gemm_workspace_bytes); the block that finishes a tile's LAST slice
+ * (a ticket counter per tile at the head of ws) adds the slabs in fixed slice order and applies bias / accumulate /
+ * act -- deterministic, no floating-point atomics, no second launch (the bf16 kernels use a second kernel for the same
+ * sums).  ws must be ZERO-FILLED before its first use; every launch leaves its head (the counters) zeroed again.
  * variant (speed only, results agree to fp32 summation order): 0 = choose -- operand tiles DMA'd straight into LDS when
  * every operand row is 16-byte aligned and K is a multiple of 16, the register-staged kernel otherwise; 1 = always
  * the register-staged kernel (the engine's choice for products it runs co-resident with a recurrence: it leaves

@@ -35,8 +35,11 @@ struct GemmArgs {
   int tilesN;
   int splitk, kchunk;  // split-K: blockIdx.y = slice, K range [y*kchunk, min(K,(y+1)*kchunk)), partials to slabs
   float* slabs;        // (batch, splitk, M, N) dense fp32 partial products when splitk > 1
+  unsigned* counters;  // one ticket counter per (batch, tile), zero between launches: the fp32 kernels reduce the slabs
+                       // themselves (finish_splitk); nullptr = the separate splitk_reduce_kernel does
   int64_t sA, sB, sC, sbias;
 };
+constexpr size_t COUNTER_BYTES = 65536;  // head of a split-K workspace: 16384 counters
 
 // Fetch this thread's two float4 pieces of an operand tile.  Two branch-free forms, selected by a
 // block-uniform condition (per-element "load or zero" branches make hipcc wait vmcnt(0) per load):
@@ -123,8 +126,68 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16 (&acc
           if (!partial) {
             if (g.accumulate) v += *cp;
             if (g.act == 1) v = sk_sigmoid(v);
+            *cp = v;
+          } else {
+            __hip_atomic_store(cp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by another XCD
           }
-          *cp = v;
+        }
+      }
+    }
+}
+
+// Split-K epilogue inside the product kernel (no second launch): every slice has written its partial tile to its
+// slab with write-through stores; when those have landed the block draws a ticket from the tile's counter, and the
+// block that draws the LAST ticket adds the tile's slabs in slice order (deterministic: the same sums as
+// splitk_reduce_kernel) and applies bias / accumulate / act.  It also puts the counter back to zero, so a workspace
+// that starts zeroed stays usable launch after launch.  Cross-XCD visibility as in the recurrence kernels: sc1 stores,
+// vmcnt(0) before the ticket, sc1 loads after it.
+__device__ __forceinline__ void finish_splitk(const GemmArgs& g, int z, int row0, int col0, int tid) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    unsigned* cnt = g.counters + (size_t)z * gridDim.x + blockIdx.x;
+    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == (unsigned)g.splitk - 1u;
+    if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int lane = tid & 63, kh = lane >> 5, l31 = lane & 31;
+  const int64_t mn = (int64_t)g.M * g.N;
+  const float* sl = g.slabs + (int64_t)z * g.splitk * mn;
+  float* C = g.C + z * g.sC;
+  const float* bias = g.bias ? g.bias + z * g.sbias : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+      float a[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, g.M - 1);
+        a[r] = __hip_atomic_load(sl + (int64_t)row * g.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int k = 1; k < g.splitk; ++k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, g.M - 1);
+          a[r] += __hip_atomic_load(sl + k * mn + (int64_t)row * g.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < g.M) {
+          float* cp = C + (int64_t)row * g.ldc + col;
+          float x = a[r] + bv;
+          if (g.accumulate) x += *cp;
+          if (g.act == 1) x = sk_sigmoid(x);
+          *cp = x;
         }
       }
     }
@@ -214,6 +277,7 @@ __global__ __launch_bounds__(256, 4) void gemm_f32_kernel(GemmArgs g) {
   }
 
   store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
+  if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -362,6 +426,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(GemmArgs g) {
     cur ^= 1;
   }
   store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
+  if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -514,6 +579,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_split3_kernel(GemmArgs g) {
     cur ^= 1;
   }
   store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
+  if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -698,8 +764,68 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs g) {
           if (!partial) {
             if (g.accumulate) v += *cp;
             if (g.act == 1) v = sk_sigmoid(v);
+            *cp = v;
+          } else {
+            __hip_atomic_store(cp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by another XCD
           }
-          *cp = v;
+        }
+      }
+    }
+}
+
+// Split-K epilogue inside the product kernel (no second launch): every slice has written its partial tile to its
+// slab with write-through stores; when those have landed the block draws a ticket from the tile's counter, and the
+// block that draws the LAST ticket adds the tile's slabs in slice order (deterministic: the same sums as
+// splitk_reduce_kernel) and applies bias / accumulate / act.  It also puts the counter back to zero, so a workspace
+// that starts zeroed stays usable launch after launch.  Cross-XCD visibility as in the recurrence kernels: sc1 stores,
+// vmcnt(0) before the ticket, sc1 loads after it.
+__device__ __forceinline__ void finish_splitk(const GemmArgs& g, int z, int row0, int col0, int tid) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    unsigned* cnt = g.counters + (size_t)z * gridDim.x + blockIdx.x;
+    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == (unsigned)g.splitk - 1u;
+    if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int lane = tid & 63, kh = lane >> 5, l31 = lane & 31;
+  const int64_t mn = (int64_t)g.M * g.N;
+  const float* sl = g.slabs + (int64_t)z * g.splitk * mn;
+  float* C = g.C + z * g.sC;
+  const float* bias = g.bias ? g.bias + z * g.sbias : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = col0 + j * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+      float a[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, g.M - 1);
+        a[r] = __hip_atomic_load(sl + (int64_t)row * g.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int k = 1; k < g.splitk; ++k) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, g.M - 1);
+          a[r] += __hip_atomic_load(sl + k * mn + (int64_t)row * g.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (row < g.M) {
+          float* cp = C + (int64_t)row * g.ldc + col;
+          float x = a[r] + bv;
+          if (g.accumulate) x += *cp;
+          if (g.act == 1) x = sk_sigmoid(x);
+          *cp = x;
         }
       }
     }
@@ -953,7 +1079,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
 
 extern "C" size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk) {
   if (splitk <= 1) return 0;
-  return sk_align((size_t)M * N * batch * splitk * sizeof(float), 256);
+  return COUNTER_BYTES + sk_align((size_t)M * N * batch * splitk * sizeof(float), 256);
 }
 
 extern "C" int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int M, int N, int K, int lda,
@@ -1004,9 +1130,12 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), bk) * bk);
   splitk = (int)sk_cdiv(K, g.kchunk);  // slices that actually hold work
   g.splitk = splitk;
-  g.slabs = (float*)ws;
   const int64_t tiles = sk_cdiv(M, BM) * g.tilesN;
   SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm: too many tiles");
+  // workspace = [ticket counters | slabs]; the fp32 kernels reduce in-kernel when the counters cover every (batch, tile)
+  g.slabs = ws ? (float*)((char*)ws + COUNTER_BYTES) : nullptr;
+  const bool inkernel = !bf16 && splitk > 1 && tiles * batch * sizeof(unsigned) <= COUNTER_BYTES;
+  g.counters = inkernel ? (unsigned*)ws : nullptr;
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
   if (bf16) {
@@ -1052,7 +1181,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((gemm_f32_kernel<true, true, false>), grid, dim3(256), 0, st, g);
   }
   SK_CHECK_LAUNCH("sk_gemm");
-  if (splitk > 1) {
+  if (splitk > 1 && !inkernel) {
     const int64_t quads = sk_cdiv((int64_t)M * N, 4);
     const unsigned nb = (unsigned)(sk_cdiv(quads, 256) > 2048 ? 2048 : sk_cdiv(quads, 256));
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb, 1, (unsigned)batch), dim3(256), 0, st, g);
@@ -1097,7 +1226,7 @@ extern "C" int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const flo
   g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), bf2::BK) * bf2::BK);
   splitk = (int)sk_cdiv(K, g.kchunk);
   g.splitk = splitk;
-  g.slabs = (float*)ws;
+  g.slabs = ws ? (float*)((char*)ws + COUNTER_BYTES) : nullptr;  // (the head of a workspace belongs to the fp32 kernels' counters)
   // 256-wide column tiles unless N is small enough that they would leave most of the chip idle
   const int64_t tiles256 = sk_cdiv(M, bf2::BM) * sk_cdiv(N, 256) * splitk * batch;
   const bool wide = (N % 256 == 0 || N > 1024) && tiles256 >= 2 * 256;
@@ -1117,7 +1246,7 @@ extern "C" int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const flo
     r.A = nullptr; r.B = nullptr; r.C = C; r.bias = bias;
     r.M = M; r.N = N; r.K = K; r.lda = 0; r.ldb = 0; r.ldc = ldc;
     r.accumulate = accumulate; r.act = act; r.vecA = r.vecB = 0; r.tilesN = g.tilesN;
-    r.splitk = splitk; r.kchunk = g.kchunk; r.slabs = (float*)ws;
+    r.splitk = splitk; r.kchunk = g.kchunk; r.slabs = g.slabs; r.counters = nullptr;
     r.sA = 0; r.sB = 0; r.sC = sC; r.sbias = sbias;
     const int64_t quads = sk_cdiv((int64_t)M * N, 4);
     const unsigned nb = (unsigned)(sk_cdiv(quads, 256) > 2048 ? 2048 : sk_cdiv(quads, 256));
