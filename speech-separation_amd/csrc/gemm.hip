@@ -339,7 +339,7 @@ __device__ __forceinline__ void dma_1k(const float* src, unsigned lds_addr) {
 }
 
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel_dma(GemmArgs g) {
   constexpr int TILE = BM * BK * 4;  // 8 KB per operand image
   __shared__ __attribute__((aligned(1024))) char lds[2][2 * TILE];
 
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_dma_kernel(GemmArgs g) {
 // with another summation order, not a lower-precision one (tests: error against fp64 no larger than the fp32-MFMA
 // kernel's).  Nine v_mfma_f32_32x32x16_bf16 (8 passes each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (16 passes
 // each): 72 passes instead of 128 per 32 x 32 x 16 block, for ~5.5 VALU instructions per operand element to split it
-// (other waves' products run meanwhile).  Operand tiles are DMA'd into LDS as fp32 exactly as in gemm_f32_dma_kernel;
+// (other waves' products run meanwhile).  Operand tiles are DMA'd into LDS as fp32 exactly as in gemm_f32_kernel_dma;
 // the K order is the natural one (lane holds k = 8 (lane>>5) .. +7 of its row, the bf16 MFMA's fragment shape).
 // Non-finite inputs: x = +-inf splits into (inf, nan, nan): such a product is NaN where an fp32 FMA gives +-inf.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -499,7 +499,7 @@ __device__ __forceinline__ void mma9(f32x16& acc, const Split3& a, const Split3&
 }
 
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_split3_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel_split3(GemmArgs g) {
   constexpr int TILE = BM * BK * 4;  // 8 KB per operand image
   __shared__ __attribute__((aligned(1024))) char lds[2][2 * TILE];
 
@@ -1149,18 +1149,18 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, g);
   } else if (variant == 2 && dma_ok(g, transA, transB)) {
     if (!transA && !transB)
-      hipLaunchKernelGGL((gemm_f32_split3_kernel<false, false>), grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel_split3<false, false>), grid, dim3(256), 0, st, g);
     else if (!transA && transB)
-      hipLaunchKernelGGL((gemm_f32_split3_kernel<false, true>), grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel_split3<false, true>), grid, dim3(256), 0, st, g);
     else
-      hipLaunchKernelGGL((gemm_f32_split3_kernel<true, false>), grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel_split3<true, false>), grid, dim3(256), 0, st, g);
   } else if (variant != 1 && dma_ok(g, transA, transB, variant == 0)) {
     if (!transA && !transB)
-      hipLaunchKernelGGL((gemm_f32_dma_kernel<false, false>), grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel_dma<false, false>), grid, dim3(256), 0, st, g);
     else if (!transA && transB)
-      hipLaunchKernelGGL((gemm_f32_dma_kernel<false, true>), grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel_dma<false, true>), grid, dim3(256), 0, st, g);
     else
-      hipLaunchKernelGGL((gemm_f32_dma_kernel<true, false>), grid, dim3(256), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel_dma<true, false>), grid, dim3(256), 0, st, g);
   } else if (g.vecA && g.vecB) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
