@@ -329,6 +329,38 @@ __device__ __forceinline__ void istft_frame(float2* row, const float2* tw, const
   }
 }
 
+// Bin-major fast path of the tile load (the reference's (257, T) layout: stride_t == 1 for spectrum and mask): thread
+// (fr = tid & 15, k0 = tid >> 4) owns frame t0 + fr and bins k0, k0 + 16, ... -- 17 loads at a constant pointer
+// stride, no per-element index arithmetic.  fetch() only issues the global loads (into registers: they travel while
+// the current tile is transformed and overlap-added), stash() applies the mask and fills the ring slot.
+struct TileRegs {
+  float2 x[17];
+  float m[17];
+};
+
+__device__ __forceinline__ void istft_fetch(TileRegs& r, int t0, int T, const float2* __restrict__ mix, int64_t mo, int64_t msf,
+                                            const float* __restrict__ mask, int64_t ko, int64_t ksf) {
+  const int fr = threadIdx.x & 15, k0 = threadIdx.x >> 4;
+  const int t = t0 + fr;
+  const bool ok = t >= 0 && t < T;
+  const float2* pm = mix + mo + (ok ? t : 0) + (int64_t)k0 * msf;
+  const float* pk = mask ? mask + ko + (ok ? t : 0) + (int64_t)k0 * ksf : nullptr;
+#pragma unroll
+  for (int q = 0; q < 17; ++q) {
+    const bool live = ok && (q < 16 || k0 == 0);  // bin 256 = k0 0, q 16
+    r.x[q] = live ? pm[(int64_t)q * 16 * msf] : make_float2(0.f, 0.f);
+    r.m[q] = (live && pk) ? pk[(int64_t)q * 16 * ksf] : 1.f;
+  }
+}
+
+__device__ __forceinline__ void istft_stash(const TileRegs& r, float2 (*rows)[RLD], int t0) {
+  const int fr = threadIdx.x & 15, k0 = threadIdx.x >> 4;
+  float2* row = rows[(t0 + fr + 3) % RING] + k0;
+#pragma unroll
+  for (int q = 0; q < 17; ++q)
+    if (q < 16 || k0 == 0) row[16 * q] = make_float2(r.x[q].x * r.m[q], r.x[q].y * r.m[q]);
+}
+
 // One workgroup reconstructs `tpb` consecutive 16-hop tiles of one (utterance, source): every frame is read
 // and transformed once; the 3 frames that overlap into the next tile stay in the LDS ring.
 __global__ __launch_bounds__(256, 3) void istft_kernel(
@@ -355,7 +387,10 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(
   const int64_t mo = mix_offs[u], mst = mix_st[u], msf = mix_sf[u];
   const int64_t ko = mask ? mask_offs[us] : 0, kst = mask ? mask_st[u] : 0, ksf = mask ? mask_sf[u] : 0;
   const int64_t oo = out_offs[us];
+  const bool binmajor = mst == 1 && (!mask || kst == 1);  // block-uniform
 
+  TileRegs pre;
+  if (binmajor) istft_fetch(pre, tile0 * FPB, T, mix, mo, msf, mask, ko, ksf);
   for (int i = tid; i < NFFT; i += 256) {
     tw[i] = g_tw512[i];
     win[i] = g_hann512[i];
@@ -366,30 +401,62 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(
     __syncthreads();
     if (fr < 3) istft_frame(rows[(tf + fr + 3) % RING], tw, win, j);
   }
+  // overlap-add roles: thread (m0 = tid & 127, hsel = tid >> 7) produces sample m0 of hops t0 + hsel + 2q, q = 0..7.
+  // With all four taps inside [0, T) the window-sum-square is a constant of the thread.
+  const int m0 = tid & (HOP - 1), hsel = tid >> 7;
+  float wss_full = 0.f;
+  __syncthreads();  // win is complete
+#pragma unroll
+  for (int q = 3; q >= 0; --q) {
+    const float w = win[q * HOP + m0];
+    wss_full += w * w;
+  }
+  const float inv_full = 1.0f / wss_full;
+
   for (int tile = tile0; tile < tile1; ++tile) {
     const int t0 = tile * FPB;
     __syncthreads();  // the previous tile's overlap-add is done with the slots about to be refilled
-    istft_load<FPB>(rows, t0, T, mix, mo, mst, msf, mask, ko, kst, ksf);
+    if (binmajor)
+      istft_stash(pre, rows, t0);
+    else
+      istft_load<FPB>(rows, t0, T, mix, mo, mst, msf, mask, ko, kst, ksf);
     __syncthreads();
+    if (binmajor && tile + 1 < tile1) istft_fetch(pre, t0 + FPB, T, mix, mo, msf, mask, ko, ksf);  // travels under the FFTs
     istft_frame(rows[(t0 + fr + 3) % RING], tw, win, j);
     __syncthreads();
     // overlap-add in increasing frame order, window-sum-square normalisation, trim, convert
-    for (int i = tid; i < FPB * HOP; i += 256) {
-      const int hp = t0 + (i >> 7), m0 = i & (HOP - 1);
-      const int n = hp * HOP + m0 - NFFT / 2;
-      if (n < 0 || n >= nout) continue;
-      float acc = 0.f, wss = 0.f;
+    int slot = (t0 + hsel) % RING;  // ring slot of frame hp - 3 (frame t lives in slot (t + 3) % RING)
 #pragma unroll
-      for (int q = 3; q >= 0; --q) {
-        const int t = hp - q;
-        if (t >= 0 && t < T) {
-          const int m = q * HOP + m0;
-          acc += reinterpret_cast<const float*>(rows[(t + 3) % RING])[m];
-          const float w = win[m];
-          wss += w * w;
+    for (int q = 0; q < FPB * HOP / 256; ++q) {
+      const int hp = t0 + hsel + 2 * q;
+      const int n = hp * HOP + m0 - NFFT / 2;
+      const int s3 = slot, s2 = slot + 1 >= RING ? slot + 1 - RING : slot + 1, s1 = slot + 2 >= RING ? slot + 2 - RING : slot + 2,
+                s0 = slot + 3 >= RING ? slot + 3 - RING : slot + 3;
+      slot = slot + 2 >= RING ? slot + 2 - RING : slot + 2;
+      if (n < 0 || n >= nout) continue;
+      float acc;
+      if (hp >= 3 && hp < T) {  // all four frames exist
+        acc = reinterpret_cast<const float*>(rows[s3])[3 * HOP + m0];
+        acc += reinterpret_cast<const float*>(rows[s2])[2 * HOP + m0];
+        acc += reinterpret_cast<const float*>(rows[s1])[HOP + m0];
+        acc += reinterpret_cast<const float*>(rows[s0])[m0];
+        acc *= inv_full;
+      } else {
+        acc = 0.f;
+        float wss = 0.f;
+        const int sl[4] = {s0, s1, s2, s3};
+#pragma unroll
+        for (int qq = 3; qq >= 0; --qq) {
+          const int t = hp - qq;
+          if (t >= 0 && t < T) {
+            const int m = qq * HOP + m0;
+            acc += reinterpret_cast<const float*>(rows[sl[qq]])[m];
+            const float w = win[m];
+            wss += w * w;
+          }
         }
+        if (wss > 1.17549435e-38f) acc /= wss;
       }
-      if (wss > 1.17549435e-38f) acc /= wss;
       if (wav_out) wav_out[oo + n] = acc;
       if (pcm_out) {
         const float sv = acc * 32767.0f;
