@@ -235,6 +235,60 @@ def test_mask_istft_matches_oracle_and_round_trips(ops):
         np.testing.assert_allclose(got, y[:len(got)], atol=3e-6)
 
 
+def test_mask_istft_many_tiles_per_workgroup_and_frame_major_strides(ops):
+    """(1) Enough (utterance, source) pairs that a workgroup walks MANY consecutive tiles (tpb > 2: the register-prefetch
+    pipeline across tiles, ring wrap-around, ragged ends), checked against the oracle on a sample of the pairs.
+    (2) The general-stride path of the C ABI: spectrum and mask given frame-major ((T, 257) rows, the model's own output
+    order) must give the same samples as the (257, T) layout, bit for bit."""
+    import ctypes as C
+    from sepkern import _lib
+    rng = np.random.default_rng(21)
+    U, S = 64, 2                                                     # 65 tiles x 128 pairs -> 4 tiles per workgroup
+    ns = [int(v) for v in rng.integers(90000, 140000, U)]            # 700 .. 1090 frames: 45 .. 69 tiles per pair
+    ns[0], ns[1] = 128 * 1023 + 5, 128 * 1024 + 127                  # tile counts on both sides of a multiple of 16 frames
+    ys = [_sig(n, 500 + i) for i, n in enumerate(ns)]
+    specs = [OS.stft(y) for y in ys]
+    masks = [[rng.uniform(0, 1, s.shape).astype(np.float32) for _ in range(S)] for s in specs]
+    d_specs = [torch.from_numpy(s).cuda() for s in specs]
+    d_masks = [[torch.from_numpy(m).cuda() for m in ms] for ms in masks]
+    wav, pcm = ops.mask_istft(d_specs, d_masks)
+    for u in (0, 1, 2, 17, U - 1):
+        for k in range(S):
+            ref_f, ref_i = OS.reconstruct(specs[u], masks[u][k])
+            got_f, got_i = wav[u][k].cpu().numpy(), pcm[u][k].cpu().numpy()
+            assert got_f.shape == ref_f.shape
+            np.testing.assert_allclose(got_f, ref_f, atol=3e-6)
+            d = np.abs(got_i.astype(np.int32) - ref_i.astype(np.int32))
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    # (2) frame-major operands through the C ABI, three utterances
+    sel = [0, 2, 5]
+    Ts = [specs[u].shape[1] for u in sel]
+    F = 257
+    spec_tf = torch.cat([d_specs[u].t().contiguous().view(-1) for u in sel])                       # (T, F) rows
+    mask_tf = torch.cat([torch.cat([d_masks[u][k] for k in range(S)], 0).t().contiguous().view(-1) for u in sel])   # (T, S*F)
+    i64 = lambda v: torch.tensor(v, dtype=torch.int64, device="cuda")
+    moffs, koffs, ooffs, acc_m, acc_k, acc_o = [], [], [], 0, 0, 0
+    for T in Ts:
+        moffs.append(acc_m)
+        acc_m += T * F
+        for k in range(S):
+            koffs.append(acc_k + k * F)                                                            # source k: columns k*F ..
+            ooffs.append(acc_o)
+            acc_o += 128 * (T - 1)
+        acc_k += T * S * F
+    out = torch.empty(acc_o, dtype=torch.float32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    args = [i64(moffs), i64([F] * 3), i64([1] * 3), i64(koffs), i64([S * F] * 3), i64([1] * 3),
+            torch.tensor(Ts, dtype=torch.int32, device="cuda"), i64(ooffs)]
+    _lib.call("sk_mask_istft", p(spec_tf), p(args[0]), p(args[1]), p(args[2]), p(mask_tf), p(args[3]), p(args[4]), p(args[5]),
+              p(args[6]), 3, S, 512, 128, p(out), None, p(args[7]), max(Ts), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for i, u in enumerate(sel):
+        for k in range(S):
+            o = ooffs[i * S + k]
+            assert torch.equal(out[o:o + 128 * (Ts[i] - 1)], wav[u][k])
+
+
 def test_istft_int16_wraps_like_reference(ops):
     y = _sig(4096, 9) * 12.0                                   # |y| well above 1.0
     s = OS.stft(y)
