@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 106
+#define SK_VERSION 107
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -190,6 +190,15 @@ int sk_bn_update_running(const float* mean, const float* var, float* running_mea
 /* out = (x - mean) / sqrt(var + eps) * gamma + beta */
 int sk_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                 float* out, int R, int C, float eps, sk_stream_t stream);
+/* BatchNorm folded into the Linear layer that follows it (lin(bn(x)), reference archs/uPIT.py:138-141; SURVEY 2.3 K4:
+ * "normalize fused into the Linear prologue"): with s = gamma / sqrt(var + eps), t = beta - mean * s,
+ *   Wf[o][c] = W[o][c] * s[c]  (leading dimension ldf >= C, extra columns zero),  bf[o] = b[o] + sum_c W[o][c] * t[c],
+ * so that lin(bn(x)) = x Wf^T + bf and the normalised activations are never written.  s and t (C each) are returned for
+ * sk_bn_unfold_grad: the weight gradient dW (+)= (dz^T x) diag(s) + colsum(dz) t^T from G = dz^T x (O x C, ld ldg). */
+int sk_bn_fold(const float* W, const float* b, const float* mean, const float* var, const float* gamma, const float* beta,
+               float eps, int O, int C, float* Wf, int ldf, float* bf, float* s, float* t, sk_stream_t stream);
+int sk_bn_unfold_grad(const float* G, int ldg, const float* dzsum, const float* s, const float* t, float* dW, int O, int C,
+                      int accumulate, sk_stream_t stream);
 /* training-mode backward: dgamma, dbeta, dx from dout, x and the batch statistics */
 int sk_bn_bwd(const float* dout, const float* x, const float* mean, const float* var, const float* gamma,
               float* dx, float* dgamma, float* dbeta, void* ws, int R, int C, float eps, sk_stream_t stream);

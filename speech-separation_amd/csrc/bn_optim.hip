@@ -84,6 +84,54 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
+// BatchNorm folded into the Linear layer that follows it (reference archs/uPIT.py:138-141: lin(bn(x))):
+//   bn(x)[c] = x[c] * s[c] + t[c],  s = gamma / sqrt(var + eps),  t = beta - mean * s
+//   lin(bn(x))[o] = sum_c x[c] * (W[o][c] * s[c]) + (b[o] + sum_c W[o][c] * t[c])
+// One workgroup per output row o: writes the folded row Wf[o][:] and the folded bias bf[o]; workgroup 0 also writes
+// s and t (the backward pass needs them).  The normalised activations are never materialised.
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float eps, int C, float* __restrict__ Wf, int ldf,
+                                                      float* __restrict__ bf, float* __restrict__ s_out,
+                                                      float* __restrict__ t_out) {
+  __shared__ float red[256];
+  const int o = blockIdx.x;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float sc = gamma[c] / sqrtf(var[c] + eps);
+    const float tc = beta[c] - mean[c] * sc;
+    const float w = W[(size_t)o * C + c];
+    Wf[(size_t)o * ldf + c] = w * sc;
+    acc += w * tc;
+    if (o == 0) {
+      s_out[c] = sc;
+      t_out[c] = tc;
+    }
+  }
+  for (int c = C + threadIdx.x; c < ldf; c += 256) Wf[(size_t)o * ldf + c] = 0.f;  // padding columns of the folded copy
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {  // fixed-order tree: reproducible
+    if (threadIdx.x < h) red[threadIdx.x] += red[threadIdx.x + h];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bf[o] = (b ? b[o] : 0.f) + red[0];
+}
+
+// Gradient of the UNFOLDED weight from G = dz^T x (the product against the raw activations):
+//   dW[o][c] (+)= G[o][c] * s[c] + dzsum[o] * t[c]        (since dz^T bn(x) = (dz^T x) diag(s) + colsum(dz) t^T)
+__global__ __launch_bounds__(256) void bn_unfold_grad_kernel(const float* __restrict__ G, int ldg, const float* __restrict__ dzsum,
+                                                             const float* __restrict__ s, const float* __restrict__ t,
+                                                             float* __restrict__ dW, int O, int C, int accumulate) {
+  const int64_t total = (int64_t)O * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int o = (int)(i / C), c = (int)(i - (int64_t)o * C);
+    const float v = G[(size_t)o * ldg + c] * s[c] + dzsum[o] * t[c];
+    dW[i] = accumulate ? dW[i] + v : v;
+  }
+}
+
 // dx = gamma * rstd / N * (N*dy - dbeta - xhat * dgamma), N = rows the sums dbeta / dgamma (and mean / var) cover
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ var,
@@ -215,6 +263,26 @@ extern "C" int sk_bn_apply(const float* x, const float* mean, const float* var, 
   hipLaunchKernelGGL(bn_apply_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, mean, var,
                      gamma, beta, out, total, C, eps);
   SK_CHECK_LAUNCH("sk_bn_apply");
+  return SK_OK;
+}
+
+extern "C" int sk_bn_fold(const float* W, const float* b, const float* mean, const float* var, const float* gamma,
+                          const float* beta, float eps, int O, int C, float* Wf, int ldf, float* bf, float* s, float* t,
+                          sk_stream_t stream) {
+  SK_CHECK_ARG(W && mean && var && gamma && beta && Wf && bf && s && t && O > 0 && C > 0 && ldf >= C, "sk_bn_fold: bad arguments");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, W, b, mean, var, gamma, beta, eps,
+                     C, Wf, ldf, bf, s, t);
+  SK_CHECK_LAUNCH("sk_bn_fold");
+  return SK_OK;
+}
+
+extern "C" int sk_bn_unfold_grad(const float* G, int ldg, const float* dzsum, const float* s, const float* t, float* dW,
+                                 int O, int C, int accumulate, sk_stream_t stream) {
+  SK_CHECK_ARG(G && dzsum && s && t && dW && O > 0 && C > 0 && ldg >= C, "sk_bn_unfold_grad: bad arguments");
+  const int64_t total = (int64_t)O * C;
+  hipLaunchKernelGGL(bn_unfold_grad_kernel, dim3(stream_blocks(total)), dim3(256), 0, (hipStream_t)stream, G, ldg, dzsum, s,
+                     t, dW, O, C, accumulate);
+  SK_CHECK_LAUNCH("sk_bn_unfold_grad");
   return SK_OK;
 }
 

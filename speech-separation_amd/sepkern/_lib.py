@@ -13,7 +13,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEPKERN_LIB") or os.path.join(_HERE, "libsepkern.so")   # SEPKERN_LIB: diagnostic builds
 
-SK_VERSION = 106
+SK_VERSION = 107
 
 _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -43,6 +43,8 @@ PROTOTYPES = {
     "sk_bn_update_running": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "sk_bn_apply": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "sk_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "sk_bn_fold": (_i, [_p, _p, _p, _p, _p, _p, _f, _i, _i, _p, _i, _p, _p, _p, _p]),
+    "sk_bn_unfold_grad": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _i, _p]),
     "sk_bn_bwd_sums": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "sk_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, C.c_double, _f, _p]),
     "sk_colsum": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),

@@ -119,6 +119,9 @@ class Engine:
         # fp32 GEMM kernel per stream (sk_gemm_f32_splitk's variant): "main,side".  Default: choose (LDS-DMA where it
         # applies) on the main stream, the register-staged kernel for products that run beside a recurrence (_wgrad).
         # "2,2": every product by the exact three-way bf16 split on the bf16 matrix pipe (opt-in).
+        # BatchNorm folded into the Linear layer (fp32 path; the bf16 arithmetic is DEFINED with bn(y) and W rounded
+        # separately, oracle/upit_bf16.py, so that path keeps the explicit normalisation)
+        self.bn_fold = os.environ.get("SEPKERN_BN_FOLD", "1") == "1" and not self.bf16
         self.var_main, self.var_side = (int(v) for v in os.environ.get("SEPKERN_GEMM_VARIANTS", "0,1").split(","))
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
@@ -296,14 +299,23 @@ class Engine:
             ops.bn_update_running(mean, var, self.running_mean, self.running_var, int(bn_count), self.momentum)
         else:
             mean, var, bn_count = self.running_mean, self.running_var, float(R)
-        xbn = torch.empty(R, 2 * H, device=dev)
-        ops.bn_apply(y2d, mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
         mask = torch.empty(T, B, O, device=dev)
-        self._proj(cache, xbn, self.p("lin.weight"), mask.view(R, O), self.p("lin.bias"), act=1)
+        xbn = fold = None
+        if self.bn_fold:
+            # BatchNorm folded into the Linear weights (sk_bn_fold): mask = sigmoid(y Wf^T + bf), the
+            # normalised activations are never written (one 92 MB pass less, forward and backward)
+            Wf, bf_, s_, t_ = ops.bn_fold(self.p("lin.weight"), self.p("lin.bias"), mean, var, self.p("bn.weight"),
+                                          self.p("bn.bias"), self.eps)
+            self._proj(cache, y2d, Wf, mask.view(R, O), bf_, act=1)
+            fold = (s_, t_)
+        else:
+            xbn = torch.empty(R, 2 * H, device=dev)
+            ops.bn_apply(y2d, mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
+            self._proj(cache, xbn, self.p("lin.weight"), mask.view(R, O), self.p("lin.bias"), act=1)
         ctx = None
         if save:
-            ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, mask=mask, lens=lens, h0=h0, c0=c0,
-                       T=T, B=B, training=training)
+            ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, fold=fold, mask=mask, lens=lens, h0=h0,
+                       c0=c0, T=T, B=B, training=training)
         return mask, hn, cn, ctx
 
     # ------------------------------------------------------------------ backward
@@ -340,15 +352,29 @@ class Engine:
         self._dgrad(cache, dz2d, self.p("lin.weight"), dxbn, "gemm")
         # the Linear layer's own gradients are needed by nobody before clip+Adam: side stream, next to the top
         # layer's recurrence
+        y_top = ctx["saved"][-1][3].view(R, 2 * H)
         stream = self.side if overlap else main
         if stream is not main:
             stream.wait_stream(main)
         with torch.cuda.stream(stream):
-            self._wgrad(cache, dz2d, ctx["xbn"], self.g("lin.weight"), acc, "gemm_side" if overlap else "gemm", beside=overlap)
-            ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc, ws_tag="bn_side" if overlap else "bn")
+            tag = "_side" if overlap else ""
+            if ctx["fold"] is not None:
+                # dW = dz^T bn(y) = (dz^T y) diag(s) + colsum(dz) t^T  (sk_bn_unfold_grad): the product runs against y itself
+                G = torch.empty(O, 2 * H, device=dev)
+                dzsum = torch.empty(O, device=dev)
+                self._wgrad(cache, dz2d, y_top, G, False, "gemm" + tag, beside=overlap)
+                ops.colsum(dz, R, O, O, dzsum, ws_tag="bn" + tag)
+                ops.bn_unfold_grad(G, dzsum, ctx["fold"][0], ctx["fold"][1], self.g("lin.weight"), accumulate=acc)
+                if acc:
+                    self.g("lin.bias").add_(dzsum)
+                else:
+                    self.g("lin.bias").copy_(dzsum)
+                keep += [G, dzsum]
+            else:
+                self._wgrad(cache, dz2d, ctx["xbn"], self.g("lin.weight"), acc, "gemm" + tag, beside=overlap)
+                ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc, ws_tag="bn" + tag)
             keep.append(dz)
         del dz
-        y_top = ctx["saved"][-1][3].view(R, 2 * H)
         dy = torch.empty(R, 2 * H, device=dev)
         dgamma = torch.empty(2 * H, device=dev)
         dbeta = torch.empty(2 * H, device=dev)

@@ -404,6 +404,29 @@ def bn_apply(x2d, mean, var, gamma, beta, out, eps):
               _stream())
 
 
+def bn_fold(W, b, mean, var, gamma, beta, eps, ld=None):
+    """BatchNorm folded into the Linear layer behind it (sk_bn_fold): returns (Wf (O, ld), bf (O), s (C), t (C)) with
+    lin(bn(x)) = x Wf[:, :C]^T + bf."""
+    for t_ in (W, b, mean, var, gamma, beta):
+        _chk(t_)
+    O, Cc = W.shape
+    ld = Cc if ld is None else ld
+    Wf = torch.empty(O, ld, device=W.device)
+    bf, s, t = torch.empty(O, device=W.device), torch.empty(Cc, device=W.device), torch.empty(Cc, device=W.device)
+    _lib.call("sk_bn_fold", _ptr(W), _ptr(b), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps), O, Cc, _ptr(Wf), ld,
+              _ptr(bf), _ptr(s), _ptr(t), _stream())
+    return Wf, bf, s, t
+
+
+def bn_unfold_grad(G, dzsum, s, t, dW, accumulate=False):
+    """dW (O, C) (+)= G[:, :C] diag(s) + dzsum t^T (sk_bn_unfold_grad): the gradient of the unfolded Linear weight from
+    G = dz^T x, the product against the raw (un-normalised) activations."""
+    for t_ in (G, dzsum, s, t, dW):
+        _chk(t_)
+    O, Cc = dW.shape
+    _lib.call("sk_bn_unfold_grad", _ptr(G), G.stride(0), _ptr(dzsum), _ptr(s), _ptr(t), _ptr(dW), O, Cc, int(accumulate), _stream())
+
+
 def bn_bwd(dout, x2d, mean, var, gamma, dx, dgamma, dbeta, eps):
     R, Cc = x2d.shape
     _lib.call("sk_bn_bwd", _ptr(dout), _ptr(x2d), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(dx), _ptr(dgamma),

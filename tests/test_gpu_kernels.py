@@ -356,6 +356,33 @@ def test_bn_stats_apply_backward(ops):
     np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=2e-6)
 
 
+def test_bn_folded_into_linear_forward_and_weight_gradient(ops):
+    """sk_bn_fold / sk_bn_unfold_grad (BatchNorm normalisation fused into the Linear that follows it):
+    lin(bn(x)) = x Wf^T + bf, and dW = dz^T bn(x) recovered from G = dz^T x -- against the explicit computation in fp64."""
+    g = torch.Generator().manual_seed(8)
+    R, Cc, O = 300, 70, 23
+    x = torch.randn(R, Cc, generator=g) * 3 + 1
+    W, b = torch.randn(O, Cc, generator=g), torch.randn(O, generator=g)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    mean, var = x.mean(0), x.var(0, unbiased=False)
+    eps = 1e-5
+    Wf, bf, s, t = ops.bn_fold(dev(W), dev(b), dev(mean), dev(var), dev(gamma), dev(beta), eps, ld=72)
+    xd = x.double()
+    xbn = (xd - mean.double()) / torch.sqrt(var.double() + eps) * gamma.double() + beta.double()
+    ref = xbn @ W.double().t() + b.double()
+    got = xd @ Wf.cpu().double()[:, :Cc].t() + bf.cpu().double()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-4)
+    assert torch.all(Wf[:, Cc:] == 0)
+    dz = torch.randn(R, O, generator=g)
+    G = (dz.double().t() @ xd).float()
+    dW0 = torch.randn(O, Cc, generator=g)
+    for acc in (False, True):
+        dW = dev(dW0.clone())
+        ops.bn_unfold_grad(dev(G), dev(dz.sum(0)), s, t, dW, accumulate=acc)
+        want = dz.double().t() @ xbn + (dW0.double() if acc else 0)
+        np.testing.assert_allclose(dW.cpu().double().numpy(), want.numpy(), atol=2e-3, rtol=1e-5)
+
+
 def test_colsum_and_sigmoid_bwd(ops):
     torch.manual_seed(1)
     x = torch.randn(777, 130)
