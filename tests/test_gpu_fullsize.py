@@ -129,3 +129,51 @@ def test_bf16_3spk_step_32x400_matches_bf16_oracle():
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] < 1e-2, worst
+
+
+def test_rsh_4spk_step_32x400_matches_oracle():
+    """BASELINE configs[4] at its stated shape: the RSH arch (2x600 BLSTM over [mixture | attention], 4 recurrent
+    passes with the LSTM state carried from pass to pass and the attention reduced by every estimated mask,
+    reference archs/RSH.py:160-283) on 32 four-speaker utterances x 400 frames against oracle/rsh.py (pinned to the
+    reference's own goldens): loss 2e-5 relative, same norm, every parameter gradient <= 5e-4 relative L2 (the gradient
+    chains through 4 passes x 400 steps x 2 layers and through the attention)."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    import RSH
+    from oracle import rsh as OR
+    torch.set_num_threads(_threads())
+    torch.manual_seed(23)
+    rng = np.random.default_rng(23)
+    Hr, Lr, S = 600, 2, 4
+    model = RSH.SepDNN(0, hidden_dim=str(Hr), num_layers=str(Lr))
+    model.cuda()
+    model.train()
+    orc = OR.OracleRSH(F, Hr, Lr)
+    orc.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    orc.train()
+    lens = sorted([int(v) for v in rng.integers(T // 2, T + 1, B)])
+    lens[-1], lens[0] = T, T // 2
+    samples = []
+    for n in lens:
+        mix = np.abs(rng.standard_normal((n, F))).astype(np.float32)
+        d = {"combo": np.concatenate((mix, np.ones(mix.shape)), axis=1).astype(np.float32)}
+        for s in range(S):
+            d["source%d" % (s + 1)] = (np.abs(rng.standard_normal((n, F))) * 0.4).astype(np.float32)
+        samples.append(d)
+    hid = [(torch.randn(2 * Lr, B, Hr), torch.randn(2 * Lr, B, Hr))]          # one sub-batch: every utterance has 4 speakers
+    model.next_hidden = [(h.cuda(), c.cuda()) for h, c in hid]
+    loss, norm = RSH.compute_loss(model, 0, RSH.Collator("combo")(samples))
+    loss.backward()
+    torch.cuda.synchronize()
+    model.check_status()
+    grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+    lo, no, _ = OR.compute_loss(orc, OR.collate(samples), hid)
+    lo.backward()
+    assert float(norm) == float(no)
+    np.testing.assert_allclose(float(loss.detach()), float(lo.detach()), rtol=2e-5)
+    worst = ("", 0.0)
+    for k, p in orc.named_parameters():
+        e = float((grads[k] - p.grad.double()).norm() / (p.grad.double().norm() + 1e-30))
+        if e > worst[1]:
+            worst = (k, e)
+    assert worst[1] < 5e-4, worst
