@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 107
+#define SK_VERSION 108
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -87,6 +87,9 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * the register-staged kernel (the engine's choice for products it runs co-resident with a recurrence: it leaves
  * the recurrence more of the matrix pipe). */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
+/* Zero the ticket counters at the head of a split-K workspace (once, before its first use; a buffer that was allocated
+ * zero-filled needs no call). */
+int sk_gemm_workspace_init(void* ws, sk_stream_t stream);
 int sk_gemm_f32_splitk(const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                        int lda, int ldb, int ldc, int transA, int transB, int accumulate, int act,
                        int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws,

@@ -1077,6 +1077,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
 
 }  // namespace
 
+extern "C" int sk_gemm_workspace_init(void* ws, sk_stream_t stream) {
+  SK_CHECK_ARG(ws, "sk_gemm_workspace_init: null pointer");
+  SK_CHECK_HIP(hipMemsetAsync(ws, 0, COUNTER_BYTES, (hipStream_t)stream));
+  return SK_OK;
+}
+
 extern "C" size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk) {
   if (splitk <= 1) return 0;
   return COUNTER_BYTES + sk_align((size_t)M * N * batch * splitk * sizeof(float), 256);

@@ -175,6 +175,28 @@ def test_gemm_splitk_is_deterministic_and_matches_fp64(ops, M, N, K, S):
     assert torch.equal(outs[0], outs[1])                     # fixed-order slab reduction: bitwise reproducible
 
 
+def test_gemm_splitk_workspace_from_a_c_caller(ops):
+    """A split-K workspace that did NOT come zero-filled (a C caller's own allocation): sk_gemm_workspace_init zeroes the
+    ticket counters at its head once; launches then leave them zeroed (two launches in a row give the same, right result)."""
+    import ctypes as C
+    from sepkern import _lib
+    g = torch.Generator().manual_seed(31)
+    M, N, K, S = 260, 132, 2048, 4
+    A, B = dev(torch.randn(K, M, generator=g)), dev(torch.randn(K, N, generator=g))
+    ref = A.cpu().double().t() @ B.cpu().double()
+    nbytes = _lib.load().sk_gemm_workspace_bytes(M, N, 1, S)
+    ws = torch.full((nbytes,), 0xA5, dtype=torch.uint8, device="cuda")                     # garbage, counters included
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.call("sk_gemm_workspace_init", p(ws), st)
+    for _ in range(2):
+        out = torch.full((M, N), float("nan")).cuda()
+        _lib.call("sk_gemm_f32_splitk", p(A), p(B), p(out), None, M, N, K, M, N, N, 1, 0, 0, 0, 1, 0, 0, 0, 0, S, p(ws), 0, st)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
+    assert int(ws[:65536].max()) == 0                                                          # counters back at zero
+
+
 # ------------------------------------------------------------------------------------ STFT / iSTFT
 def _sig(n, seed):
     rng = np.random.default_rng(seed)
