@@ -85,7 +85,9 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * variant (speed only, results agree to fp32 summation order): 0 = choose -- operand tiles DMA'd straight into LDS when
  * every operand row is 16-byte aligned and K is a multiple of 16, the register-staged kernel otherwise; 1 = always
  * the register-staged kernel (the engine's choice for products it runs co-resident with a recurrence: it leaves
- * the recurrence more of the matrix pipe). */
+ * the recurrence more of the matrix pipe); 2 = exact three-way bf16 split of both operands on the bf16 matrix pipe
+ * (nine exact piece products per element pair, fp32 accumulators: an fp32 product in another summation order; power-
+ * bound on MI355X, opt-in); 3 = the LDS-DMA kernel wherever it applies (diagnostics). */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 /* Zero the ticket counters at the head of a split-K workspace (once, before its first use; a buffer that was allocated
  * zero-filled needs no call). */

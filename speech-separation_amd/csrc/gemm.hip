@@ -341,7 +341,10 @@ __device__ __forceinline__ void dma_1k(const float* src, unsigned lds_addr) {
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 3) void gemm_f32_kernel_dma(GemmArgs g) {
   constexpr int TILE = BM * BK * 4;  // 8 KB per operand image
-  __shared__ __attribute__((aligned(1024))) char lds[2][2 * TILE];
+  // LDS stages: the DMA runs NST - 1 K steps ahead of the products.  A third stage (48 KB of LDS) measured +4 % on the
+  // N/N and +1..4 % on the T/N products stand-alone, -4 % on N/T, and nothing on the training step: two are shipped.
+  constexpr int NST = 2;
+  __shared__ __attribute__((aligned(1024))) char lds[NST][2 * TILE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -383,7 +386,9 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel_dma(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       dma_1k(srcA[i], my_pieces + buf * 2 * TILE + i * 1024);
+#ifndef SK_ABL_HALFDMA  // (SK_ABL_*: ablation builds for tools/gemm_bench.py, `make gemm_variant`: results wrong by construction)
       dma_1k(srcB[i], my_pieces + buf * 2 * TILE + TILE + i * 1024);
+#endif
       srcA[i] += stepA;
       srcB[i] += stepB;
     }
@@ -401,11 +406,19 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel_dma(GemmArgs g) {
   const int fb0 = frag_base<!TB>(wn * 64, lane), fb1 = frag_base<!TB>(wn * 64 + 32, lane);
 
   if (nk > 0) stage(0);
+  if (NST == 3 && nk > 1) stage(1);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step kt have landed ...
-    __syncthreads();                                   // ... and everybody's; all reads of the other buffer are done
-    if (kt + 1 < nk) stage(cur ^ 1);
+#ifndef SK_ABL_NOBAR
+    if (NST == 3 && kt + 1 < nk)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // step kt has landed; the 4 instructions of step kt + 1 may still fly
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step kt have landed ...
+    __syncthreads();                                   // ... and everybody's; all reads of the buffer refilled next are done
+#endif
+#ifndef SK_ABL_NODMA
+    if (kt + NST - 1 < nk) stage(NST == 3 ? (cur + 2) % 3 : cur ^ 1);
+#endif
     const char* ai = lds[cur];
     const char* bi = lds[cur] + TILE;
 #pragma unroll
@@ -423,7 +436,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel_dma(GemmArgs g) {
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc[1][1], 0, 0, 0);
       }
     }
-    cur ^= 1;
+    cur = NST == 3 ? (cur + 1) % 3 : cur ^ 1;
   }
   store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
   if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
@@ -773,64 +786,6 @@ __global__ __launch_bounds__(256, 3) void gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
-// Split-K epilogue inside the product kernel (no second launch): every slice has written its partial tile to its
-// slab with write-through stores; when those have landed the block draws a ticket from the tile's counter, and the
-// block that draws the LAST ticket adds the tile's slabs in slice order (deterministic: the same sums as
-// splitk_reduce_kernel) and applies bias / accumulate / act.  It also puts the counter back to zero, so a workspace
-// that starts zeroed stays usable launch after launch.  Cross-XCD visibility as in the recurrence kernels: sc1 stores,
-// vmcnt(0) before the ticket, sc1 loads after it.
-__device__ __forceinline__ void finish_splitk(const GemmArgs& g, int z, int row0, int col0, int tid) {
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    unsigned* cnt = g.counters + (size_t)z * gridDim.x + blockIdx.x;
-    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = old == (unsigned)g.splitk - 1u;
-    if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  const int lane = tid & 63, kh = lane >> 5, l31 = lane & 31;
-  const int64_t mn = (int64_t)g.M * g.N;
-  const float* sl = g.slabs + (int64_t)z * g.splitk * mn;
-  float* C = g.C + z * g.sC;
-  const float* bias = g.bias ? g.bias + z * g.sbias : nullptr;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = col0 + j * 32 + l31;
-      if (col >= g.N) continue;
-      const float bv = bias ? bias[col] : 0.f;
-      float a[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = min(row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, g.M - 1);
-        a[r] = __hip_atomic_load(sl + (int64_t)row * g.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      for (int k = 1; k < g.splitk; ++k) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, g.M - 1);
-          a[r] += __hip_atomic_load(sl + k * mn + (int64_t)row * g.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (row < g.M) {
-          float* cp = C + (int64_t)row * g.ldc + col;
-          float x = a[r] + bv;
-          if (g.accumulate) x += *cp;
-          if (g.act == 1) x = sk_sigmoid(x);
-          *cp = x;
-        }
-      }
-    }
-}
-
 }  // namespace bf
 
 // ------------------------------------------------------------------------------------------------------
@@ -1119,7 +1074,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                 int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
-  SK_CHECK_ARG(variant >= 0 && variant <= 2, "sk_gemm: unknown variant %d", variant);
+  SK_CHECK_ARG(variant >= 0 && variant <= 3, "sk_gemm: unknown variant %d", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");

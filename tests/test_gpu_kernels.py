@@ -175,6 +175,29 @@ def test_gemm_splitk_is_deterministic_and_matches_fp64(ops, M, N, K, S):
     assert torch.equal(outs[0], outs[1])                     # fixed-order slab reduction: bitwise reproducible
 
 
+@pytest.mark.parametrize("variant", [3])
+@pytest.mark.parametrize("M,N,K,tA,tB,S", [(300, 260, 512, False, True, 1), (700, 260, 528, False, False, 1), (516, 132, 1024, True, False, 1),
+                                            (1000, 772, 1792, False, True, 1), (517, 1792, 3584, False, False, 2),
+                                            (1028, 132, 4096, True, False, 4), (256, 128, 16, False, True, 1)])
+def test_gemm_dma_kernels_forced(ops, variant, M, N, K, tA, tB, S):
+    """sk_gemm_f32_splitk variant 3 (the LDS-DMA kernel wherever it applies; two LDS stages for N/T, three for N/N and T/N):
+    ragged edges in M and N, bias, accumulate, in-kernel split-K; against fp64 and run-to-run identical."""
+    g = torch.Generator().manual_seed(M + 3 * N + variant)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    bias, C0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = (A.double().t() if tA else A.double()) @ (B.double().t() if tB else B.double()) + bias.double() + C0.double()
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        ops.gemm(dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N, transA=tA, transB=tB, bias=dev(bias), accumulate=True,
+                 splitk=S, variant=variant)
+        torch.cuda.synchronize()
+        outs.append(C.cpu())
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_gemm_splitk_workspace_from_a_c_caller(ops):
     """A split-K workspace that did NOT come zero-filled (a C caller's own allocation): sk_gemm_workspace_init zeroes the
     ticket counters at its head once; launches then leave them zeroed (two launches in a row give the same, right result)."""
