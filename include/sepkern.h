@@ -87,7 +87,8 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * the register-staged kernel (the engine's choice for products it runs co-resident with a recurrence: it leaves
  * the recurrence more of the matrix pipe); 2 = exact three-way bf16 split of both operands on the bf16 matrix pipe
  * (nine exact piece products per element pair, fp32 accumulators: an fp32 product in another summation order; power-
- * bound on MI355X, opt-in); 3 = the LDS-DMA kernel wherever it applies (diagnostics). */
+ * bound on MI355X, opt-in); 3 = the 128 x 128-tile LDS-DMA kernel wherever it applies, 4 = its 256 x 128-tile, 8-wave form
+ * wherever that applies (diagnostics; 0 picks among 1, 3 and 4 by shape). */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 /* Zero the ticket counters at the head of a split-K workspace (once, before its first use; a buffer that was allocated
  * zero-filled needs no call). */

@@ -443,6 +443,130 @@ __global__ __launch_bounds__(256, 3) void gemm_f32_kernel_dma(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The LDS-DMA kernel with a 256 x 128 block tile and EIGHT waves (4 x 2, each still 64 x 64): the B tile is fetched
+// once per 256 rows instead of once per 128, i.e. 0.75 x the bytes moved global -> LDS per flop (the quantity the
+// ablation in DESIGN.md 4b shows the kernel's loss to be proportional to), at the same waves per SIMD and the same
+// registers per wave as the 128 x 128 kernel.  Same images, K order and epilogue; the A image is 16 pieces (256 rows),
+// a k-major A row is one whole DMA instruction.
+template <bool KMAJOR>
+__device__ __forceinline__ const float* dma_src_w256(const float* P, int ld, int dim0, int dimLimit, int k0, int piece, int lane) {
+  if (KMAJOR) {  // piece = k row; lane fetches 4 dims; the 32-dim halves of every 64 swapped where bit 2 of k is set
+    const int dim = (4 * lane) ^ (((piece >> 2) & 1) << 5);
+    return P + (int64_t)(k0 + piece) * ld + min(dim0 + dim, dimLimit - 4);
+  }
+  return dma_src<false>(P, ld, dim0, dimLimit, k0, piece, lane);  // 16 pieces of 16 rows
+}
+
+template <bool KMAJOR, int DIM>  // DIM = tile dimension of the image (row bytes of a k-major image = 4 DIM)
+__device__ __forceinline__ int frag_base_w(int d0, int lane) {
+  const int l31 = lane & 31, kh = lane >> 5;
+  if (KMAJOR) return 4 * kh * (4 * DIM) + ((d0 ^ (kh << 5)) + l31) * 4;
+  return ((d0 + l31) >> 4) * 1024 + kh * 256 + (((l31 & 15) + 8 * kh) & 15) * 16;
+}
+
+template <bool KMAJOR, int DIM>
+__device__ __forceinline__ void frag_load_w(const char* img, int base, int cp, float (&v)[4]) {
+  if (KMAJOR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float*>(img + base + (8 * cp + i) * (4 * DIM));
+  } else {
+    const float4 q = *reinterpret_cast<const float4*>(img + base + cp * 512);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_f32_kernel_dma256(GemmArgs g) {
+  constexpr int BMW = 256;
+  constexpr int TILE_A = BMW * BK * 4, TILE_B = BN * BK * 4, STAGE = TILE_A + TILE_B;  // 16 + 8 KB
+  __shared__ __attribute__((aligned(1024))) char lds[2][STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
+    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+  }
+  int m0, n0;
+  {
+    constexpr int GM = GROUP_M / 2;  // the same 1024 rows per group
+    const int tilesM = gridDim.x / g.tilesN, per = GM * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GM;
+    const int gsz = min(GM, tilesM - first);
+    m0 = (first + rem2 % gsz) * BMW;
+    n0 = (rem2 / gsz) * BN;
+  }
+  const int z = blockIdx.z, ks = blockIdx.y;
+  const float* A = g.A + z * g.sA;
+  const float* B = g.B + z * g.sB;
+  const bool partial = g.splitk > 1;
+  float* C = partial ? g.slabs + ((int64_t)z * g.splitk + ks) * g.M * g.N : g.C + z * g.sC;
+  const int ldc = partial ? g.N : g.ldc;
+  const float* bias = (g.bias && !partial) ? g.bias + z * g.sbias : nullptr;
+  const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / BK;
+
+  // wave w DMAs A pieces 2w, 2w+1 (of 16) and B piece w (of 8)
+  const float* srcA[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) srcA[i] = dma_src_w256<TA>(A, g.lda, m0, g.M, kbeg, 2 * wave + i, lane);
+  const float* srcB = dma_src<!TB>(B, g.ldb, n0, g.N, kbeg, wave, lane);
+  const int64_t stepA = TA ? (int64_t)BK * g.lda : BK, stepB = !TB ? (int64_t)BK * g.ldb : BK;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
+  const unsigned pa = __builtin_amdgcn_readfirstlane(lds_base + 2 * wave * 1024);
+  const unsigned pb = __builtin_amdgcn_readfirstlane(lds_base + TILE_A + wave * 1024);
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dma_1k(srcA[i], pa + buf * STAGE + i * 1024);
+      srcA[i] += stepA;
+    }
+    dma_1k(srcB, pb + buf * STAGE);
+    srcB += stepB;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fa0 = frag_base_w<TA, BMW>(wm * 64, lane), fa1 = frag_base_w<TA, BMW>(wm * 64 + 32, lane);
+  const int fb0 = frag_base_w<!TB, BN>(wn * 64, lane), fb1 = frag_base_w<!TB, BN>(wn * 64 + 32, lane);
+
+  if (nk > 0) stage(0);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage(cur ^ 1);
+    const char* ai = lds[cur];
+    const char* bi = lds[cur] + TILE_A;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      float a0[4], a1[4], b0[4], b1[4];
+      frag_load_w<TA, BMW>(ai, fa0, cp, a0);
+      frag_load_w<TA, BMW>(ai, fa1, cp, a1);
+      frag_load_w<!TB, BN>(bi, fb0, cp, b0);
+      frag_load_w<!TB, BN>(bi, fb1, cp, b1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[i], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b1[i], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b0[i], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[i], acc[1][1], 0, 0, 0);
+      }
+    }
+    cur ^= 1;
+  }
+  store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
+  if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
+}
+
+// ------------------------------------------------------------------------------------------------------
 // fp32 product on the bf16 matrix pipe by an EXACT three-way split (variant 2 of sk_gemm_f32_splitk, opt-in).
 // Every fp32 operand element x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits = 3 x 8:
 // hi = the top 8, taken by truncation; x - hi is exact in fp32 and has at most 16 significant bits; again for mid; what
@@ -1074,7 +1198,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                 int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
-  SK_CHECK_ARG(variant >= 0 && variant <= 3, "sk_gemm: unknown variant %d", variant);
+  SK_CHECK_ARG(variant >= 0 && variant <= 4, "sk_gemm: unknown variant %d", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
@@ -1091,7 +1215,13 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), bk) * bk);
   splitk = (int)sk_cdiv(K, g.kchunk);  // slices that actually hold work
   g.splitk = splitk;
-  const int64_t tiles = sk_cdiv(M, BM) * g.tilesN;
+  // 256 x 128 block tiles, 8 waves: variant 4, or chosen (variant 0) for the large unsplit N/T and N/N products -- measured
+  // +2 % / +5 % on them stand-alone and 37.50 / 37.61 / 37.65 vs 37.73 / 37.98 / 37.85 ms on the training step (one call);
+  // with split-K launches included the step does not move.  SEPKERN_GEMM_WIDE=0 (diagnostics): never chosen.
+  static const bool wide_ok = [] { const char* e = getenv("SEPKERN_GEMM_WIDE"); return !(e && e[0] == '0'); }();
+  const bool wide = !bf16 && M >= 256 && dma_ok(g, transA, transB) &&
+                    (variant == 4 || (variant == 0 && wide_ok && !transA && M >= 4096 && N >= 1024 && splitk == 1));
+  const int64_t tiles = sk_cdiv(M, wide ? 256 : BM) * g.tilesN;
   SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm: too many tiles");
   // workspace = [ticket counters | slabs]; the fp32 kernels reduce in-kernel when the counters cover every (batch, tile)
   g.slabs = ws ? (float*)((char*)ws + COUNTER_BYTES) : nullptr;
@@ -1108,6 +1238,13 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, g);
     else
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, g);
+  } else if (wide) {
+    if (!transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_kernel_dma256<false, false>), grid, dim3(512), 0, st, g);
+    else if (!transA && transB)
+      hipLaunchKernelGGL((gemm_f32_kernel_dma256<false, true>), grid, dim3(512), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel_dma256<true, false>), grid, dim3(512), 0, st, g);
   } else if (variant == 2 && dma_ok(g, transA, transB)) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_split3<false, false>), grid, dim3(256), 0, st, g);

@@ -175,7 +175,7 @@ def test_gemm_splitk_is_deterministic_and_matches_fp64(ops, M, N, K, S):
     assert torch.equal(outs[0], outs[1])                     # fixed-order slab reduction: bitwise reproducible
 
 
-@pytest.mark.parametrize("variant", [3])
+@pytest.mark.parametrize("variant", [3, 4])
 @pytest.mark.parametrize("M,N,K,tA,tB,S", [(300, 260, 512, False, True, 1), (700, 260, 528, False, False, 1), (516, 132, 1024, True, False, 1),
                                             (1000, 772, 1792, False, True, 1), (517, 1792, 3584, False, False, 2),
                                             (1028, 132, 4096, True, False, 4), (256, 128, 16, False, True, 1)])
