@@ -42,7 +42,7 @@ def main():
                 out.append((i, loss.detach().clone()))          # no host sync inside the timed loop
         torch.cuda.synchronize()
         secs = time.perf_counter() - t0
-        v = float(loss)
+        v = float(loss.detach())
         assert v == v and v > 0
         opt.check()
         frames = int(lens.sum().item()) * steps
