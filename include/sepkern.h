@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 108
+#define SK_VERSION 109
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -170,6 +170,15 @@ int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const flo
 int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
                       const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
                       float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, sk_stream_t stream);
+/* The same over the processing steps [s_begin, s_end) only (step s is time T-1-s for the forward direction, s for the
+ * reverse one): consecutive calls on one workspace advance one sequence (the carried gradients travel through ws), dbias
+ * accumulates over the calls, dh0 / dc0 / dg_first are produced by the call whose range ends at T.  After s steps the
+ * rows t >= T-s of the forward direction's dgx and the rows t < s of the reverse direction's are final -- the engine
+ * starts their weight-gradient products beside the remaining steps. */
+int sk_lstm_bwd_range(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
+                      const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
+                      float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, int s_begin, int s_end,
+                      sk_stream_t stream);
 /* Reorder the rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g H + u inside each block of 4H
  * rows) and the gate-interleaved order of gx / gates / dgx (row 4u + g).  back = 0: dst[4u+g] = src[gH+u] (weights,
  * biases -> interleaved); back = 1: dst[gH+u] (+)= src[4u+g] (weight gradients back to the parameter order,

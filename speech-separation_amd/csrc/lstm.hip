@@ -1079,7 +1079,16 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
                                  const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
                                  float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
                                  int mode, sk_stream_t stream) {
+  return sk_lstm_bwd_range(dy, dhn, dcn, whh, gates, cs, c0, lens, dgx, dh0, dc0, dbias, dg_first, ws, T, B, H, mode, 0, T,
+                           stream);
+}
+
+extern "C" int sk_lstm_bwd_range(const float* dy, const float* dhn, const float* dcn, const float* whh,
+                                 const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
+                                 float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
+                                 int mode, int s_begin, int s_end, sk_stream_t stream) {
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
+  SK_CHECK_ARG(s_begin >= 0 && s_begin < s_end && s_end <= T, "sk_lstm_bwd: bad step range [%d, %d) of %d", s_begin, s_end, T);
   SK_CHECK_ARG(((uintptr_t)gates % 16) == 0 && ((uintptr_t)dgx % 16) == 0, "sk_lstm_bwd: gates / dgx must be 16-byte aligned");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
   if (rc) return rc;
@@ -1110,22 +1119,25 @@ extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float*
   dim3 grid((unsigned)L.KS, (unsigned)nby, 2);
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_bwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));
-  if (dbias) SK_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)L.NBG * 8 * H * sizeof(float), st));  // rows >= grid y stay 0
+  if (dbias && s_begin == 0)  // (the kernels ADD their sums: a sequence advanced in several launches accumulates)
+    SK_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)L.NBG * 8 * H * sizeof(float), st));  // rows >= grid y stay 0
+  const bool last = s_end == T;
   if (mode == 1 || (mode == 0 && fits)) {
-    a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;
+    a.s_begin = s_begin; a.s_end = s_end; a.final_mm = last ? want_d0 : 0;  // not the last range: the state goes to the workspace
     dispatch_bwd(L.KS, bf, a, grid, st);
   } else {
     a.final_mm = 0;  // a step launch never waits on other workgroups
-    for (int s = 0; s < T; ++s) {
+    for (int s = s_begin; s < s_end; ++s) {
       a.s_begin = s; a.s_end = s + 1;
       dispatch_bwd(L.KS, bf, a, grid, st);
     }
-    if (want_d0) {
+    if (want_d0 && last) {
       a.s_begin = T; a.s_end = T; a.final_mm = 1;
       dispatch_bwd(L.KS, bf, a, grid, st);
     }
   }
-  if (dg_first) hipLaunchKernelGGL(first_dg_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, st, dgx, lens, dg_first, T, B, H);
+  if (dg_first && last)
+    hipLaunchKernelGGL(first_dg_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, st, dgx, lens, dg_first, T, B, H);
   SK_CHECK_LAUNCH("sk_lstm_bwd");
   return SK_OK;
 }

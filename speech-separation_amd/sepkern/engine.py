@@ -119,6 +119,9 @@ class Engine:
         # fp32 GEMM kernel per stream (sk_gemm_f32_splitk's variant): "main,side".  Default: choose (LDS-DMA where it
         # applies) on the main stream, the register-staged kernel for products that run beside a recurrence (_wgrad).
         # "2,2": every product by the exact three-way bf16 split on the bf16 matrix pipe (opt-in).
+        # backward recurrences in two launches, half of a layer's own weight-gradient products beside the second
+        # (backward(); built, parity-tested, measured 38.7 vs 37.7 ms per step: off)
+        self.bwd_split = os.environ.get("SEPKERN_BWD_SPLIT", "0") == "1"
         # BatchNorm folded into the Linear layer (fp32 path; the bf16 arithmetic is DEFINED with bn(y) and W rounded
         # separately, oracle/upit_bf16.py, so that path keeps the explicit normalisation)
         self.bn_fold = os.environ.get("SEPKERN_BN_FOLD", "1") == "1" and not self.bf16
@@ -200,6 +203,26 @@ class Engine:
                          sA=4 * H * ld - B, sB=H * ld + B, sC=4 * H * H, splitk=0, ws_tag=ws_tag)
         ops.gemm(dg_first, h0, gw, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=True, batch=2, sA=B * 4 * H, sB=B * H,
                  sC=4 * H * H, ws_tag=ws_tag, bf16=True)
+
+    def _wgrad_half(self, c, dgx, y, inp, gw_hh, gw_ih, T, B, Ip, ws_tag, beside):
+        """Half c (1 or 2) of a layer's weight-gradient products in the split backward schedule (fp32).  With S = T/2:
+        half 1 = the rows that are final after S steps of the backward recurrence (forward direction t >= S, reverse
+        direction t < S), half 2 = the rest, accumulated onto half 1.  Per direction, as one batched launch each:
+          dW_hh[d] (+)= sum_t dG_t[d]^T h_prev(t)[d]   (ops.lstm_whh_grad's time-shifted pairs, cut at S)
+          dW_ih[d] (+)= sum_t dG_t[d]^T x_t            (rows of gw_ih: direction 0's 4H, then direction 1's)"""
+        H, S = self.H, T // 2
+        dg, yv, xv = dgx.view(-1), y.view(-1), inp.reshape(-1)
+        var = self.var_side if beside else self.var_main
+        kw = dict(transA=True, accumulate=(c == 2), batch=2, splitk=0, ws_tag=ws_tag, variant=var)
+        if c == 1:     # forward direction: pairs (dG_t, y_{t-1}), t = S..T-1; reverse: (dG_t, y_{t+1}), t = 0..S-1
+            ops.gemm(dg[S * B * 8 * H:], yv[(S - 1) * B * 2 * H:], gw_hh, 4 * H, H, S * B, 8 * H, 2 * H, H,
+                     sA=4 * H - S * B * 8 * H, sB=H - (S - 2) * B * 2 * H, sC=4 * H * H, **kw)
+            ops.gemm(dg[S * B * 8 * H:], xv[S * B * Ip:], gw_ih, 4 * H, Ip, S * B, 8 * H, Ip, Ip,
+                     sA=4 * H - S * B * 8 * H, sB=-S * B * Ip, sC=4 * H * Ip, **kw)
+        else:          # forward direction: t = 1..S-1 (t = 0 pairs with h0: the caller's rank-B term); reverse: t = S..T-2
+            ops.gemm(dg[B * 8 * H:], yv, gw_hh, 4 * H, H, (S - 1) * B, 8 * H, 2 * H, H,
+                     sA=S * B * 8 * H + 4 * H - B * 8 * H, sB=(S + 1) * B * 2 * H + H, sC=4 * H * H, **kw)
+            ops.gemm(dg, xv, gw_ih, 4 * H, Ip, S * B, 8 * H, Ip, Ip, sA=S * B * 8 * H + 4 * H, sB=S * B * Ip, sC=4 * H * Ip, **kw)
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, lens, h0, c0, training, save, want_state=False):
@@ -350,9 +373,21 @@ class Engine:
         dz2d = dz.view(R, O)
         dxbn = torch.empty(R, 2 * H, device=dev)
         self._dgrad(cache, dz2d, self.p("lin.weight"), dxbn, "gemm")
-        # the Linear layer's own gradients are needed by nobody before clip+Adam: side stream, next to the top
-        # layer's recurrence
         y_top = ctx["saved"][-1][3].view(R, 2 * H)
+        dy = torch.empty(R, 2 * H, device=dev)
+        dgamma = torch.empty(2 * H, device=dev)
+        dbeta = torch.empty(2 * H, device=dev)
+        ops.bn_bwd_sums(dxbn, y_top, ctx["mean"], ctx["var"], dgamma, dbeta, self.eps)
+        put("bn.weight", dgamma)                         # local sums: the flat all-reduce adds the ranks up later
+        put("bn.bias", dbeta)
+        if self.sync_bn:                                 # dx needs the sums over the global batch (one all-reduce)
+            dgamma, dbeta = skdist.allreduce_bn_sums(dgamma, dbeta)
+        ops.bn_bwd_apply(dxbn, y_top, ctx["mean"], ctx["var"], self.p("bn.weight"), dgamma, dbeta, dy, ctx["bn_count"],
+                         self.eps)
+        del dxbn
+        # the Linear layer's own gradients are needed by nobody before clip+Adam: side stream, next to the top
+        # layer's recurrence (enqueued HERE, after the BatchNorm backward on the main stream: issued earlier they ran
+        # beside those short critical-path kernels and slowed them by 0.1 ms)
         stream = self.side if overlap else main
         if stream is not main:
             stream.wait_stream(main)
@@ -375,17 +410,6 @@ class Engine:
                 ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc, ws_tag="bn" + tag)
             keep.append(dz)
         del dz
-        dy = torch.empty(R, 2 * H, device=dev)
-        dgamma = torch.empty(2 * H, device=dev)
-        dbeta = torch.empty(2 * H, device=dev)
-        ops.bn_bwd_sums(dxbn, y_top, ctx["mean"], ctx["var"], dgamma, dbeta, self.eps)
-        put("bn.weight", dgamma)                         # local sums: the flat all-reduce adds the ranks up later
-        put("bn.bias", dbeta)
-        if self.sync_bn:                                 # dx needs the sums over the global batch (one all-reduce)
-            dgamma, dbeta = skdist.allreduce_bn_sums(dgamma, dbeta)
-        ops.bn_bwd_apply(dxbn, y_top, ctx["mean"], ctx["var"], self.p("bn.weight"), dgamma, dbeta, dy, ctx["bn_count"],
-                         self.eps)
-        del dxbn
         ws = None
         dh0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
         dc0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
@@ -404,10 +428,25 @@ class Engine:
             nbg = (B + 15) // 16
             dbias = torch.empty(nbg, 8 * H, device=dev)      # by-products of the recurrence: bias-gradient partials ...
             dg_first = torch.empty(2, B, 4 * H, device=dev)  # ... and the dG of the steps whose recurrent input is h0
-            ws = ops.lstm_bwd(dy, whh, gates, cs, c0[sl], lens, dgx, dh0[sl] if want_dstate else None,
-                              dc0[sl] if want_dstate else None, T, B, H, mode,
-                              dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None,
-                              bf16=self.bf16, dbias=dbias, dg_first=dg_first)
+            bargs = (dy, whh, gates, cs, c0[sl], lens, dgx, dh0[sl] if want_dstate else None,
+                     dc0[sl] if want_dstate else None, T, B, H, mode)
+            bkw = dict(dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None, bf16=self.bf16,
+                       dbias=dbias, dg_first=dg_first)
+            gw_hh = torch.empty(2, 4 * H, H, device=dev)     # rows gate-interleaved, like dgx (sk_gate_rows puts them back)
+            gw_ih = torch.empty(8 * H, Ip, device=dev)
+            split = self.bwd_split and overlap and not self.bf16 and T % 2 == 0 and T >= 16
+            if split:
+                # Split schedule: the recurrence in two launches of T/2 steps.  After the first, the forward direction's dgx
+                # is final for t >= T/2 and the reverse direction's for t < T/2, so HALF of this layer's own weight-gradient
+                # products (those rows, per direction: _wgrad_half) starts on the side stream beside the second launch --
+                # the top layer's recurrence then hosts work too, and only half of layer 0's products is left for the end.
+                ws = ops.lstm_bwd(*bargs, steps=(0, T // 2), **bkw)
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self._wgrad_half(1, dgx, y, inp, gw_hh, gw_ih, T, B, Ip, "gemm_side", True)
+                ws = ops.lstm_bwd(*bargs, steps=(T // 2, T), **bkw)
+            else:
+                ws = ops.lstm_bwd(*bargs, **bkw)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, Ip, device=dev)
                 self._dgrad(cache, dgx.view(R, 8 * H), wih_gi, dy_next, "gemm_dgrad")
@@ -417,18 +456,20 @@ class Engine:
             if stream is not main:
                 stream.wait_stream(main)
             elif overlap:
-                main.wait_stream(self.side)      # layer 0 reuses operand copies the side stream made for layer 1
+                main.wait_stream(self.side)      # layer 0 reuses operand copies (and, split, the half sums) of the side stream
             with torch.cuda.stream(stream):
                 tag = "side" if stream is not main else "main"
-                # dW_hh[d] = sum_t dG_t^T h_prev(t): the layer output shifted by one step in time (+ the h0 steps)
-                # (rows come out gate-interleaved, like dgx: sk_gate_rows puts them back into the parameters' order)
-                gw_hh = torch.empty(2, 4 * H, H, device=dev)
                 beside = stream is not main
-                self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, gw_hh, T, B, False, "gemm_" + tag, beside)
+                if split:
+                    self._wgrad_half(2, dgx, y, inp, gw_hh, gw_ih, T, B, Ip, "gemm_" + tag, beside)
+                    ops.gemm(dg_first, h0[sl], gw_hh, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=True, batch=2,
+                             sA=B * 4 * H, sB=B * H, sC=4 * H * H, ws_tag="gemm_" + tag)      # the steps that start from h0
+                else:
+                    # dW_hh[d] = sum_t dG_t^T h_prev(t): the layer output shifted by one step in time (+ the h0 steps)
+                    self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, gw_hh, T, B, False, "gemm_" + tag, beside)
+                    # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
+                    self._wgrad(cache, dgx.view(R, 8 * H), inp, gw_ih, False, "gemm_" + tag, beside)
                 ops.gate_rows(gw_hh, H, back=True, out=self.g("weight_hh_l%d" % l), accumulate=acc)
-                # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
-                gw_ih = torch.empty(8 * H, Ip, device=dev)
-                self._wgrad(cache, dgx.view(R, 8 * H), inp, gw_ih, False, "gemm_" + tag, beside)
                 ops.gate_rows(gw_ih, H, back=True, out=self.g("weight_ih_l%d" % l).view(8 * H, I), accumulate=acc, cols=I)
                 db = torch.empty(8 * H, device=dev)
                 ops.colsum(dbias, nbg, 8 * H, 8 * H, db, ws_tag="bn_" + tag)       # a few rows: the kernel did the sums

@@ -728,3 +728,52 @@ def test_lstm_forward_in_step_ranges_equals_one_launch(ops, mode, bf16, T, B, H,
         assert torch.equal(a, b)
     with pytest.raises(Exception):
         ops.lstm_fwd(gx, whh, h0, c0, lens_d, out[0], None, None, None, None, T, B, H, mode, steps=(3, 3))
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("T,B,H,lens,cuts", [(10, 32, 896, [10] * 20 + [7] * 8 + [2] * 4, (5,)), (9, 20, 300, [9] * 7 + [4] * 13, (2, 7)),
+                                             (8, 16, 64, [8] * 10 + [3] * 6, (1, 4))])
+def test_lstm_backward_in_step_ranges_equals_one_launch(ops, mode, bf16, T, B, H, lens, cuts):
+    """sk_lstm_bwd_range: the backward recurrence advanced by consecutive launches over [0, s1), [s1, s2), ... [sk, T) gives,
+    bit for bit, what one launch gives for dgx, dh0 / dc0 and dg_first, and the same bias-gradient partials up to the
+    rounding of adding per-launch sums; and after s steps the rows t >= T - s of the forward direction's dgx and t < s of the reverse one's already
+    hold their final values (what the engine's split backward schedule relies on)."""
+    g = torch.Generator().manual_seed(5 * H + T)
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
+    dhn, dcn = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+    gates = gx.clone()
+    y, cs = torch.zeros(T, B, 2 * H).cuda(), torch.zeros(T, B, 2, H).cuda()
+    ws = ops.lstm_fwd(gates, whh, h0, c0, lens_d, y, gates, cs, None, None, T, B, H, mode, bf16=bf16)
+    ops.lstm_status(ws)
+
+    def bwd(ranges, probe=None):
+        gg = gates.clone()
+        dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+        dbias = torch.zeros((B + 15) // 16, 2, 4 * H).cuda()
+        dgf = torch.zeros(2, B, 4 * H).cuda()
+        snap = None
+        for i, r in enumerate(ranges):
+            w = ops.lstm_bwd(dy, whh, gg, cs, c0, lens_d, gg, dh0, dc0, T, B, H, mode, dhn=dhn, dcn=dcn, bf16=bf16, dbias=dbias,
+                             dg_first=dgf, steps=r)
+            if probe is not None and i == 0:
+                torch.cuda.synchronize()
+                snap = gg.clone()
+        ops.lstm_status(w)
+        return (gg, dh0, dc0, dbias, dgf), snap
+
+    ref, _ = bwd([None])
+    edges = (0,) + tuple(cuts) + (T,)
+    out, snap = bwd(list(zip(edges[:-1], edges[1:])), probe=True)
+    for i, (a, b) in enumerate(zip(out, ref)):
+        if i == 3:          # dbias: per-launch sums are ADDED to it, (s_0..s_4) + (s_5..s_9) is another rounding than one sum
+            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+        else:
+            assert torch.equal(a, b)
+    s1 = cuts[0]
+    assert torch.equal(snap[T - s1:, :, 0], ref[0][T - s1:, :, 0])      # forward direction: the last s1 time steps are done
+    assert torch.equal(snap[:s1, :, 1], ref[0][:s1, :, 1])              # reverse direction: the first s1
