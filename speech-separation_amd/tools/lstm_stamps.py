@@ -22,6 +22,12 @@ def stamps(ws):
 
 def main():
     bf = "--bf16" in sys.argv
+    # the geometry / protocol the engine ships (sepkern/engine.py: fwd_bits, bwd_bits); --legacy: the r01 one (all zero)
+    if "--legacy" in sys.argv:
+        fbits = bbits = 0
+    else:
+        fbits = ops.lstm_variant_bits(False, 1, True, False, bf, 0)
+        bbits = ops.lstm_variant_bits(False, 1, False, False, False, 31)
     torch.manual_seed(0)
     gx = torch.randn(T, B, 2, 4 * H, device="cuda") * 0.5
     whh = torch.randn(2, 4 * H, H, device="cuda") / 30
@@ -30,11 +36,11 @@ def main():
     y, cs = torch.empty(T, B, 2 * H, device="cuda"), torch.empty(T, B, 2, H, device="cuda")
     for rep in range(2):
         g = gx.clone()
-        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, None, None, T, B, H, 1, bf16=bf)
+        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, None, None, T, B, H, 1 | fbits, bf16=bf)
         ops.lstm_status(ws)
         sf = stamps(ws)
         dy = torch.randn(T, B, 2 * H, device="cuda")
-        ws = ops.lstm_bwd(dy, whh, g, cs, c0, lens, g, None, None, T, B, H, 1, bf16=bf)
+        ws = ops.lstm_bwd(dy, whh, g, cs, c0, lens, g, None, None, T, B, H, 1 | bbits, bf16=bf)
         ops.lstm_status(ws)
         sb = stamps(ws)
     print("forward  (us per step, workgroup 0):")
