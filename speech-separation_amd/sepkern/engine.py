@@ -149,10 +149,20 @@ class Engine:
     # pass) holds the copies already made, keyed by (kind, id of the fp32 tensor), and keeps them alive.
     @staticmethod
     def _copy(cache, kind, t2d):
+        """bf16 operand copy of t2d ("row": as stored, "t": transposed), made once per pass.  A copy made on one stream and
+        used on the other is ordered by ITS OWN event: the user waits for that cast, not for everything the maker's
+        stream has queued behind it."""
         key = (kind, t2d.data_ptr(), tuple(t2d.shape))
-        if key not in cache:
-            cache[key] = ops.cast_bf16(t2d) if kind == "row" else ops.cast_bf16_t(t2d)
-        return cache[key]
+        cur = torch.cuda.current_stream()
+        ent = cache.get(key)
+        if ent is None:
+            c = ops.cast_bf16(t2d) if kind == "row" else ops.cast_bf16_t(t2d)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            cache[key] = ent = (c, ev, cur)
+        elif ent[2] != cur:
+            cur.wait_event(ent[1])
+        return ent[0]
 
     def _proj(self, cache, inp2d, w, out2d, bias, act=0):
         """out (R, N) = act(inp (R, K) w (N, K)^T + bias)."""
@@ -455,8 +465,10 @@ class Engine:
             stream = self.side if (overlap and l > 0) else main
             if stream is not main:
                 stream.wait_stream(main)
-            elif overlap:
-                main.wait_stream(self.side)      # layer 0 reuses operand copies (and, split, the half sums) of the side stream
+            elif overlap and split:
+                main.wait_stream(self.side)      # layer 0 adds its second half onto the half sums the side stream made
+            # (unsplit: layer 0's products share nothing with the side stream's but bf16 operand copies, which carry their
+            # own events -- _copy -- so they start as soon as layer 0's recurrence ends)
             with torch.cuda.stream(stream):
                 tag = "side" if stream is not main else "main"
                 beside = stream is not main
