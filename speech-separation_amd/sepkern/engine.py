@@ -119,6 +119,7 @@ class Engine:
         # fp32 GEMM kernel per stream (sk_gemm_f32_splitk's variant): "main,side".  Default: choose (LDS-DMA where it
         # applies) on the main stream, the register-staged kernel for products that run beside a recurrence (_wgrad).
         # "2,2": every product by the exact three-way bf16 split on the bf16 matrix pipe (opt-in).
+        self.dgrad_unsplit = os.environ.get("SEPKERN_DGRAD_UNSPLIT", "1") == "1"
         # backward recurrences in two launches, half of a layer's own weight-gradient products beside the second
         # (backward(); built, parity-tested, measured 38.7 vs 37.7 ms per step: off)
         self.bwd_split = os.environ.get("SEPKERN_BWD_SPLIT", "0") == "1"
@@ -180,7 +181,10 @@ class Engine:
         R, N = dout2d.shape
         K = w.shape[1]
         if not self.nt:
-            ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=0, ws_tag=ws_tag, bf16=self.bf16, variant=self.var_main)
+            # large data gradients unsplit: the 256 x 128-tile kernel (sk_gemm_f32_splitk picks it for unsplit N/N products)
+            # measured 125.5 TFLOP/s against 119-120 for two K slices of 128 x 128 tiles
+            sk = 1 if (self.dgrad_unsplit and not self.bf16 and R >= 4096 and K >= 1024 and N % 16 == 0) else 0
+            ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=sk, ws_tag=ws_tag, bf16=self.bf16, variant=self.var_main)
             return
         a, bt = self._copy(cache, "row", dout2d), self._copy(cache, "t", w)      # w^T: (K, N padded)
         ops.gemm_bf16_nt(a, bt, out2d, R, K, a.shape[1], a.shape[1], bt.shape[1], K, splitk=0, ws_tag=ws_tag)
