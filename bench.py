@@ -121,15 +121,70 @@ def cpu_baseline(H, L, S, B, T, budget_s=60.0):
                       "workload's own batch of %d x %d frames, %d steps after a small-batch warm-up" % (L, H, B, T, n)}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` called WITHOUT a launcher (no WORLD_SIZE in the environment): this process becomes the
+    launcher.  It has not imported torch and never touches the GPU; it starts one fresh child process per rank (the same
+    command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1), relays rank 0's stdout -- the
+    one JSON line -- and exits with the worst return code.  Nothing is exec'ed.  When one rank fails the others are
+    terminated by pid (they would otherwise wait in a collective until its timeout)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SEPKERN_BENCH_LAUNCHER="self")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    log("launcher: started %d ranks (pids %s), rendezvous 127.0.0.1:%d" % (n, [p.pid for p in procs], port))
+    out0 = []
+    import threading
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode("utf-8", "replace").splitlines()))
+    reader.start()
+    worst, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                log("launcher: rank %d exited with code %d" % (r, rc))
+                worst = worst or rc
+        if worst and live:
+            time.sleep(5.0)                               # let the others report their own error first
+            for r in sorted(live):
+                if procs[r].poll() is None:
+                    procs[r].terminate()
+            for r in sorted(live):
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            live.clear()
+        time.sleep(0.2)
+    reader.join()
+    for line in out0:
+        print(line, flush=True)
+    sys.exit(worst if 0 <= worst < 256 else 1)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                           # never returns
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if args.gpus != world:
+        sys.exit("bench.py --gpus %d under a launcher that started %d ranks" % (args.gpus, world))
     # rehearsal on a 1-GPU box: SEPKERN_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 (use with
     # SEPKERN_DIST_BACKEND=gloo and SEPKERN_LSTM_MODE=2, since two processes cannot both keep a
     # persistent grid resident on one GPU)
@@ -251,7 +306,19 @@ def main():
         ar = skdist.TIMING or []
         skdist.TIMING = None
         ar_ms = sum(a.elapsed_time(b) for a, b in ar) / max(1, len(ar))
+        # which physical device every rank computed on: "did the collective see N GPUs" is answerable from the line
+        import hashlib
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        ident = "%s|%s|%s|%d" % (getattr(props, "uuid", ""), getattr(props, "pci_bus_id", ""), getattr(props, "pci_device_id", ""),
+                                 torch.cuda.current_device())
+        h = int.from_bytes(hashlib.sha256(ident.encode()).digest()[:7], "little")
+        mine_dev = torch.tensor([h], device="cuda", dtype=torch.int64)
+        every_dev = [torch.zeros_like(mine_dev) for _ in range(world)]
+        dist.all_gather(every_dev, mine_dev)
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "distinct_devices": len({int(t.item()) for t in every_dev}),
+                     "launcher": os.environ.get("SEPKERN_BENCH_LAUNCHER", "external (torch.distributed.run)"),
+                     "grad_allreduce": skdist.overlap_mode_name(),
                      "ms_per_step_by_rank": [round(1000.0 * t / args.steps, 3) for t in per_rank],
                      "allreduce_ms_per_step": round(ar_ms, 3), "allreduce_calls": len(ar),
                      "allreduce_bytes": int(model._engine.grad_full.numel() * 4),

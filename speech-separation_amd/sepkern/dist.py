@@ -69,6 +69,13 @@ def global_norm(lens, feat_dim):
 TIMING = None
 
 
+def overlap_mode_name():
+    """How the gradient exchange of a step is issued (bench.py prints it): one collective after the backward pass
+    (default) or layer-ordered chunks on a communication stream while the backward pass is still running
+    (SEPKERN_DP_OVERLAP=1, GradReducer)."""
+    return "chunked-overlapped" if os.environ.get("SEPKERN_DP_OVERLAP", "0") == "1" else "single"
+
+
 def allreduce_grads(flat_grad):
     """Sum the flat gradient buffer over ranks in place (one collective over xGMI)."""
     if is_parallel():
