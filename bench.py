@@ -379,6 +379,27 @@ def main():
                         "on its CUs, which shortens the step and lengthens the launches it overlaps"}
         res["kernels"] = {k: {"launches_per_step": v[0] // args.steps, "ms_per_step": round(v[1] / args.steps, 3),
                               "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2)} for k, v in prof.items()}
+        # Every MFMA-bound kernel class against the same roofline, largest share of the step first, so that this line and
+        # the first rows of profiles/*_summary.txt (rocprofv3 --stats of the same command) name the same kernels.  The
+        # recurrences carry a second bound: a time step cannot be shorter than its products at the pipe's rate
+        # (mfma_floor_us: 2 waves per SIMD x 4H*H/(16*16*4*... ) MFMAs of 32 cycles) plus one cross-CU hand-off of h_t / dG_t
+        # (handoff_us = what the step takes beyond that floor: store -> drain -> flag -> poll -> LDS-DMA).
+        by = {}
+        for k, v in sorted(merged.items(), key=lambda kv: -kv[1][1]):
+            if v[2] <= 0:
+                continue
+            a_ = v[2] / (v[1] * 1e-3) / 1e12
+            row = {"launches_per_step": v[0] // args.steps, "avg_launch_ms": round(v[1] / v[0], 4),
+                   "ms_per_step": round(v[1] / args.steps, 3), "achieved": round(a_, 2), "frac": round(a_ / peak, 4)}
+            if k.startswith("lstm_"):
+                us = 1e3 * v[1] / v[0] / T
+                # per workgroup and time step: 16 batch rows x 64 gate columns x H, on 4 SIMDs
+                floor = (2.0 * 16 * 64 * H / 4) / (64.0 if args.dtype != "bf16" else 1024.0) / 2.4e3
+                row.update({"us_per_time_step": round(us, 3), "mfma_floor_us": round(floor, 3),
+                            "handoff_us": round(us - floor, 3)})
+            by[k] = row
+        res["roofline"]["by_kernel"] = by
+        res["roofline"]["top_kernel"] = next(iter(by)) if by else None
         # whole-step figure against the same roofline: 6 x MACs per frame
         if args.arch == "rsh":      # per pass: I = 2F inputs, F outputs; num_spk passes per frame
             P = S * (sum(2 * 4 * H * ((514 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257)

@@ -136,8 +136,17 @@ int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld
  *                     for the backward pass (both NULL for inference)
  *   ws    workspace of sk_lstm_workspace_bytes(); zeroed by the call itself
  * mode (low byte): 0 auto, 1 persistent (one launch, flag-synchronised time loop), 2 one launch per step.
- * mode >> 8: minimum number of 16-row batch groups a workgroup carries (0/1 = as few as fit): a larger
- * value shrinks the persistent grid, leaving CUs free for kernels running concurrently on other streams. */
+ * mode bits 8..15: minimum number of 16-row batch groups a workgroup carries (0/1 = as few as fit): a larger
+ * value shrinks the persistent grid, leaving CUs free for kernels running concurrently on other streams.
+ * Speed-only variants of the persistent kernels (never the arithmetic, except where noted): bit 16 bf16 matrix-core
+ * inputs (this one IS arithmetic: BASELINE configs[3]); bit 17 8-unit / 256-thread workgroups, two per CU; bits 18..19
+ * block id -> stream map; bit 20 one polling wave per workgroup; bit 21 flags replicated per XCD; bit 22 one flag per
+ * 128-byte line; bits 23..27 hold-back of a step's first poll in units of 0.1 us (0 = the library's choice, 31 = none);
+ * bit 28 (forward, fp32): two streams per workgroup -- a workgroup owns 8 hidden units x 16 batch rows of BOTH
+ * directions and works on one direction's step while the other direction's h_t travels (lstm_fwd2_kernel) -- taken
+ * where the shape allows it (H padded to 320 / 896 / 1024, 2 * ceil(H/8)-ish workgroups per 16 rows co-resident),
+ * otherwise the call silently uses the one-stream kernel; results differ from it by the rounding of summing four K
+ * quarters instead of two K halves. */
 size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
@@ -154,7 +163,8 @@ int sk_lstm_fwd_range(const float* gx, const float* whh, const float* h0, const 
 /* Backward of the recurrence.  dy (T,B,2H) is the gradient of the layer output; produces
  * dgx (T,B,2,4H) = gradient of the gate pre-activations (gate-interleaved like gx; zero at padded positions), from which
  * the caller forms dW_ih, dW_hh, db and dx with sk_gemm_f32 / sk_colsum, and dh0/dc0 (2,B,H; may
- * be NULL).  y is the forward output (h_t), used for nothing but is kept for symmetry. */
+ * be NULL).  gates / cs are what sk_lstm_fwd saved; dgx may alias gates (each cell is read, then overwritten, by
+ * the same lane). */
 int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs,
                 const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0, void* ws,
                 int T, int B, int H, int mode, sk_stream_t stream);
@@ -276,7 +286,8 @@ int sk_att_update_bwd(const float* dx_out, const float* x_out, float* dx_in, flo
  * guard (may be NULL): device float; non-zero means "the gradients of this step are not to be trusted" (a
  * persistent recurrence launch timed out, on this rank or -- summed by the data-parallel all-reduce -- on any
  * rank): sk_clip_adam then leaves parameters and moments untouched.
- * step is the 1-based Adam step count. ws >= sk_optim_workspace_bytes(n). */
+ * step is the 1-based count of sk_clip_adam calls; the bias corrections use step - scal[3], the number of updates
+ * actually applied. ws >= sk_optim_workspace_bytes(n). */
 size_t sk_optim_workspace_bytes(int64_t n);
 int sk_grad_norm(const float* g, int64_t n, float max_norm, const float* guard, float* scal, void* ws,
                  sk_stream_t stream);

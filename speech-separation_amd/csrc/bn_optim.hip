@@ -193,9 +193,14 @@ __global__ __launch_bounds__(256) void norm_fin_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                         const float* __restrict__ scal, float lr, float beta1,
-                                                        float beta2, float eps, float bc1, float bc2_sqrt) {
+                                                        float beta2, float eps, int step) {
   if (scal[2] != 0.f) return;  // untrusted gradients never reach the weights or the moments (grid-uniform)
   const float coef = scal[1];
+  // bias corrections in double, as torch.optim.Adam's scalar path does, for the number of updates actually APPLIED:
+  // the caller counts calls, scal[3] counts the calls that were skipped (this one is not)
+  const double applied = (double)(step - (int)scal[3]);
+  const float bc1 = (float)(1.0 - pow((double)beta1, applied));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, applied));
   const float step_size = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const float gi = g[i] * coef;
@@ -361,11 +366,8 @@ extern "C" int sk_grad_norm(const float* g, int64_t n, float max_norm, const flo
 extern "C" int sk_clip_adam(float* p, const float* g, float* m, float* v, int64_t n, const float* scal, float lr,
                             float beta1, float beta2, float eps, int step, sk_stream_t stream) {
   SK_CHECK_ARG(p && g && m && v && scal && n > 0 && step >= 1, "sk_clip_adam: bad arguments");
-  // bias corrections in double on the host, as torch.optim.Adam's scalar path does
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, scal,
-                     lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2));
+                     lr, beta1, beta2, eps, step);
   SK_CHECK_LAUNCH("sk_clip_adam");
   return SK_OK;
 }

@@ -16,6 +16,7 @@
 //  * Per step the workgroups of a (direction, batch group) exchange h_t (forward) or dG_t
 //    (backward) through a small buffer laid out exactly as the MFMA B-operand image
 //    ([k/4][16 rows][4], 1 KB per 16-k chunk): producers write it with write-through (sc1) stores
+//    (fp32 forward: one dword per cell, 256 B per owner wave; bf16 and backward: 8 / 16 B per cell)
 //    and raise one sc1 flag per workgroup; consumers poll the flags with sc1 loads and pull the
 //    image into LDS with LDS-DMA (global_load_lds ... sc1: no VGPRs, L1 bypassed), so the hand-off
 //    is correct for any workgroup->XCD placement (gfx950's per-XCD L2s are not coherent).
@@ -27,6 +28,7 @@
 //  * mode 2 runs the same kernel one step per launch (state through the workspace); it is the
 //    fallback when the grid cannot be co-resident (more workgroups than CUs).
 #include "sk_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -559,6 +561,358 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ forward, two streams per workgroup
+// The kernel above leaves the matrix pipe idle for half of every step: all workgroups of a stream compute, then all
+// publish, then all wait for each other (3.05 us of MFMA in a 6.0 us step at H = 896).  Here a workgroup owns 8 hidden
+// units x 16 batch rows of BOTH directions.  The two directions are independent recurrences, so while one direction's
+// h_s travels to the other workgroups (store -> drain -> flag -> poll) the matrix pipe works on the other direction's
+// step.  Same W_hh bytes in registers (2 directions x 32 gate rows x H), same number of MFMAs per workgroup and step,
+// same bytes exchanged; a stream has 2x the participants (H/8 workgroups) at half the payload each.
+//
+// Roles (768 threads, no workgroup barrier inside the time loop):
+//   waves 0..7   MFMA waves: wave (mt = w&1, kq = w>>1) multiplies gate-row tile mt (4 units x 4 gates) of BOTH
+//                directions by K quarter kq of that direction's h image.  Per direction-step: wait for "flags up" (an
+//                LDS word), pull its half of the K quarter's pieces by LDS-DMA (7 x 1 KB at H = 896), meet the other
+//                tile's wave of the same K quarter at a counter in LDS, NQ x 4 MFMAs, partial tile -> LDS, count up.
+//   waves 8..11  cell waves: wave (d = c>>1, mt = c&1) owns the 64 cells (4 units x 16 rows) of tile mt, direction d,
+//                for the whole sequence (c, h in registers).  Per step: wait for the 4 partial tiles, cell update,
+//                publish h (write-through, 16 B per row: 4 units gathered through LDS) + drain; the LAST of the pair
+//                raises the stream's flag; bulk stores; the pair's first wave then polls the stream's flags and tells
+//                the MFMA waves.
+// Hand-off protocol, flags, exchange image and workspace are those of lstm_fwd_kernel (placement-independent).
+// Wait for a word in LDS to reach `target`.  Ends on the workgroup's abort word, and -- every wait in these kernels is
+// bounded -- after 1.5 x the flag-poll limit on its own (it then raises the abort word and the launch's status words).
+__device__ __forceinline__ bool lds_wait_ge(int* word, int target, int* abort_word, unsigned* ctrl) {
+  long long t0 = 0;
+  for (unsigned it = 0;; ++it) {
+    if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
+    if ((it & 15u) == 15u) {
+      if (__hip_atomic_load(abort_word, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
+      if ((it & 1023u) == 1023u) {
+        const long long now = wall_clock64();
+        if (t0 == 0) t0 = now;
+        if (now - t0 > SPIN_TICKS + SPIN_TICKS / 2) {
+          __hip_atomic_store(abort_word, 1, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
+          __hip_atomic_store(ctrl - 64, 1u, SK_RLX, SK_AGENT);  // the sticky word (workspace word 0), see ws_layout
+          return false;
+        }
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// One wave's arrival at a counter in LDS (everything this wave stored or had landed in LDS before is visible to whoever
+// reads the count afterwards): returns, in every lane, the count BEFORE this arrival.
+__device__ __forceinline__ int pair_arrive(int* counter, int lane) {
+  int before = 0;
+  if (lane == 0) before = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __builtin_amdgcn_readfirstlane(before);
+}
+
+// Diagnostic build only (-DSK_LSTM_STAMPS): workgroup 0's MFMA wave 0 (slots 0..7) and cell wave 8 (slots 8..14) add up
+// the 100 MHz ticks they spend in each phase; tools/lstm_stamps.py --dual prints them.
+#ifdef SK_LSTM_STAMPS
+#define SK2_DECL long long st2_t = wall_clock64(), st2_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SK2_STAMP(i)                      \
+  do {                                    \
+    const long long n__ = wall_clock64(); \
+    st2_acc[i] += n__ - st2_t;            \
+    st2_t = n__;                          \
+  } while (0)
+#define SK2_FLUSH(ctrl, base, n)                                                      \
+  do {                                                                                \
+    if (blockIdx.x == 0 && lane == 0)                                                 \
+      for (int i__ = 0; i__ < (n); ++i__) ((long long*)(ctrl))[4 + (base) + i__] = st2_acc[i__]; \
+  } while (0)
+#else
+#define SK2_DECL
+#define SK2_STAMP(i)
+#define SK2_FLUSH(ctrl, base, n)
+#endif
+
+template <int KS>
+__global__ __launch_bounds__(768) void lstm_fwd2_kernel(FwdArgs a) {
+  constexpr int HP = 16 * KS;
+  constexpr int NCH = KS;        // 1 KB chunks (16 k) of one direction's h image
+  constexpr int NQ = NCH / 4;    // chunks per MFMA wave (one K quarter)
+  constexpr int NUG = HP / 8;    // workgroups (8 units each) per batch group = producers per stream
+  constexpr int NP0 = (NQ + 1) / 2;  // pieces of a K quarter pulled by the tile-0 wave (the tile-1 wave: the rest)
+  static_assert(NCH % 4 == 0, "four K quarters");
+  __shared__ __attribute__((aligned(16))) float hs[2][16 * HP];    // per direction: B-operand image of h_{s-1}
+  __shared__ __attribute__((aligned(16))) float red[2][8][64][4];  // per direction: the 8 MFMA waves' partial tiles
+  __shared__ __attribute__((aligned(16))) float pubs[4][16][4];    // per cell wave: h of its 4 units, row-major (publish)
+  __shared__ int up[2];             // [direction]: images whose pieces may be pulled (poller -> MFMA waves)
+  __shared__ int kq_full[2][4];     // [direction][K quarter]: arrivals of the two tile waves with their pieces landed
+  __shared__ int part_done[2][2];   // [direction][tile]: partial tiles written so far (MFMA waves -> cell waves)
+  __shared__ int pub_done[2];       // [direction]: arrivals of the two cell waves with their h published
+  __shared__ int choice[4][8];      // [K quarter][decision % 8]: which direction the pair of tile waves takes next
+  __shared__ int s_abort;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;
+  int ug, bg;
+  {  // streams (batch groups) dealt to XCD groups where the counts allow (speed only; any bijection is correct)
+    const int L = (int)blockIdx.x, x = L & 7, j = L >> 3;
+    if ((a.map & 3) == 1 && NBG <= 8 && (8 % NBG) == 0 && (NUG % (8 / NBG)) == 0) {
+      const int g = 8 / NBG;
+      bg = x / g;
+      ug = j * g + (x % g);
+    } else {
+      bg = L / NUG;
+      ug = L - bg * NUG;
+    }
+  }
+  if (tid == 0) {
+    s_abort = 0;
+    up[0] = up[1] = 0;
+    for (int i = 0; i < 4; ++i) kq_full[0][i] = kq_full[1][i] = 0;
+    part_done[0][0] = part_done[0][1] = part_done[1][0] = part_done[1][1] = 0;
+    pub_done[0] = pub_done[1] = 0;
+    for (int i = 0; i < 32; ++i) (&choice[0][0])[i] = 0;
+  }
+  const int nsteps = a.s_end - a.s_begin;
+  const bool from_h0 = a.s_begin == 0;  // the first image is built from h0 by the cell waves, not pulled
+  const size_t xblk = (size_t)16 * HP;  // floats per (parity, direction, batch group) exchange block
+
+  if (w < 8) {
+    // ================================================================== MFMA waves
+    const int mt = w & 1, kq = w >> 1;
+    float wreg[2][4 * NQ];
+    {
+      const int i = lane & 15, k4 = lane >> 4;
+      const int unit_i = ug * 8 + 4 * mt + (i >> 2), g_i = i & 3;
+      const bool rowok = unit_i < H;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const float* wrow = a.whh + ((size_t)d * 4 * H + (size_t)g_i * H + unit_i) * H;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int k = 16 * (kq * NQ + q) + 4 * k4;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (rowok && k < H) v = *reinterpret_cast<const float4*>(wrow + k);
+          wreg[d][4 * q + 0] = v.x;
+          wreg[d][4 * q + 1] = v.y;
+          wreg[d][4 * q + 2] = v.z;
+          wreg[d][4 * q + 3] = v.w;
+        }
+      }
+    }
+    const int p_lo = kq * NQ + (mt ? NP0 : 0), p_n = mt ? NQ - NP0 : NP0;  // the pieces this wave pulls
+    __syncthreads();  // the only workgroup barrier: the LDS words above are initialised
+    SK2_DECL
+    // One direction-step (d compile-time: the W slice is indexed statically).  Returns false on abort.
+    auto dstep = [&](auto dtag, int r) -> bool {
+      constexpr int d = decltype(dtag)::value;
+      const int s = a.s_begin + r;
+      if (r > 0 || !from_h0) {
+        // "flags up" also says that every wave of this workgroup is done with the previous image and partial tiles
+        // of direction d (this workgroup's own flag is among those the poller saw)
+        if (!lds_wait_ge(&up[d], r + 1, &s_abort, a.ctrl)) return false;
+        SK2_STAMP(4 * d + 0);
+        const float* src = a.xbuf + ((size_t)(((s - 1) & 1) * 2 + d) * NBG + bg) * xblk;
+        for (int p = p_lo; p < p_lo + p_n; ++p) dma_piece(src + p * 256, &hs[d][p * 256], lane);
+        wait_vmcnt<0>();
+        pair_arrive(&kq_full[d][kq], lane);
+        SK2_STAMP(4 * d + 1);
+      }
+      if (!lds_wait_ge(&kq_full[d][kq], 2 * (r + 1), &s_abort, a.ctrl)) return false;
+      SK2_STAMP(4 * d + 2);
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const float* hp = &hs[d][(kq * NQ) * 256 + lane * 4];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 hb = *reinterpret_cast<const float4*>(hp + q * 256);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[d][4 * q + 0], hb.x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[d][4 * q + 1], hb.y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[d][4 * q + 2], hb.z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[d][4 * q + 3], hb.w, acc1, 0, 0, 0);
+      }
+      *reinterpret_cast<f32x4*>(&red[d][w][lane][0]) = acc0 + acc1;
+      // release: the tile is in LDS (and this wave's reads of the image have returned) before the count goes up
+      if (lane == 0) __hip_atomic_fetch_add(&part_done[d][mt], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      SK2_STAMP(4 * d + 3);
+      return true;
+    };
+    // Whichever direction's flags are up goes next (the one further behind first; never more than one step apart, so
+    // that the two streams keep interleaving).  Every wave decides for itself; a direction's steps stay in order.
+    int r0 = 0, r1 = 0;
+    while (r0 < nsteps || r1 < nsteps) {
+#ifdef SK2_STRICT
+      const bool go0 = r0 <= r1;
+#else
+      const bool can0 = r0 < nsteps && r0 <= r1 + 1, can1 = r1 < nsteps && r1 <= r0 + 1;
+      const bool rdy0 = can0 && ((r0 == 0 && from_h0) || __hip_atomic_load(&up[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= r0 + 1);
+      const bool rdy1 = can1 && ((r1 == 0 && from_h0) || __hip_atomic_load(&up[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= r1 + 1);
+      bool go0;
+      if (rdy0 && rdy1) go0 = r0 <= r1;
+      else if (rdy0 || rdy1) go0 = rdy0;
+      else go0 = can0 && (!can1 || r0 <= r1);  // nothing is up: wait (inside dstep) for the one further behind
+      // The two tile waves of a K quarter meet at a counter inside every direction-step: they MUST take the steps in the
+      // same order (one waiting in direction 0 for a partner that waits in direction 1 would never end).  They read the
+      // readiness words at different moments, so the first of the pair to reach decision n publishes it and the other
+      // adopts it (n = steps done so far, equal for both at matching decisions; a slot is reused every 8 decisions).
+      {
+        const int n = r0 + r1;
+        int dec = 0;
+        if (lane == 0) {
+          int* slot = &choice[kq][n & 7];
+          const int want = ((n + 1) << 1) | (go0 ? 0 : 1);
+          int cur = __hip_atomic_load(slot, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (;;) {
+            if ((cur >> 1) == n + 1) { dec = cur & 1; break; }
+            if (__hip_atomic_compare_exchange_strong(slot, &cur, want, __ATOMIC_ACQ_REL, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+              dec = want & 1;
+              break;
+            }
+          }
+        }
+        go0 = __builtin_amdgcn_readfirstlane(dec) == 0;
+      }
+#endif
+      if (go0) {
+        if (!dstep(std::integral_constant<int, 0>{}, r0)) return;
+        ++r0;
+      } else {
+        if (!dstep(std::integral_constant<int, 1>{}, r1)) return;
+        ++r1;
+      }
+    }
+    if (w == 0) SK2_FLUSH(a.ctrl, 0, 8);
+    return;
+  }
+
+  // ==================================================================== cell waves
+  const int c = w - 8, d = c >> 1, mt = c & 1;
+  const int u_l = lane >> 4, bl = lane & 15;
+  const int unit = ug * 8 + 4 * mt + u_l, b = bg * 16 + bl;
+  const bool cellok = unit < H && b < B;
+  const int len_b = (b < B) ? a.lens[b] : 0;
+  const int xoff = ((unit >> 2) * 16 + bl) * 4 + (unit & 3);  // image position of (k = unit, row = bl)
+  float* const xb0 = a.xbuf + ((size_t)(0 * 2 + d) * NBG + bg) * xblk;
+  float* const xb1 = a.xbuf + ((size_t)(1 * 2 + d) * NBG + bg) * xblk;
+  const int fs = (a.opt & 4) ? FSPREAD : 1;
+  unsigned* const flags0 = a.flags + (size_t)(d * NBG + bg) * NUG * fs;
+  const int pt = mt * 64 + lane;  // thread index inside the direction's pair of cell waves
+#ifndef SK2_NOPRIO
+  __builtin_amdgcn_s_setprio(2);  // the cell waves carry the hand-off chain: first pick of the issue slots
+#endif
+  float c_reg = 0.f, h_reg = 0.f;
+  if (cellok) {
+    if (from_h0) {
+      c_reg = a.c0[((size_t)d * B + b) * H + unit];
+      h_reg = a.h0[((size_t)d * B + b) * H + unit];
+    } else {
+      c_reg = a.state[((size_t)d * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
+      h_reg = __hip_atomic_load(((a.s_begin - 1) & 1 ? xb1 : xb0) + xoff, SK_RLX, SK_AGENT);
+    }
+  }
+  __syncthreads();  // the only workgroup barrier (pairs with the MFMA waves')
+  // ---- image of the first step: from h0, or (a later range of a sequence) the block the previous launch published,
+  //      which the MFMA waves pull like any other
+  if (from_h0) {
+    for (int i = pt; i < 16 * (HP / 4); i += 128) {
+      const int bb = i & 15, cq = i >> 4;  // row, k/4
+      const int brow = bg * 16 + bb;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (brow < B && 4 * cq < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)d * B + brow) * H + 4 * cq);
+      *reinterpret_cast<float4*>(&hs[d][(cq * 16 + bb) * 4]) = v;
+    }
+    // both cell waves stand in for the two tile waves of every K quarter
+    if (lane < 4) __hip_atomic_fetch_add(&kq_full[d][lane], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else if (mt == 0 && lane == 0) {
+    __hip_atomic_store(&up[d], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+
+  float4 gxv = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int t0 = d ? T - 1 - a.s_begin : a.s_begin;
+    if (cellok) gxv = *reinterpret_cast<const float4*>(a.gx + (((size_t)t0 * B + b) * 2 + d) * 4 * H + 4 * (size_t)unit);
+  }
+  SK2_DECL
+  for (int r = 0; r < nsteps; ++r) {
+    const int s = a.s_begin + r;
+    const int t = d ? T - 1 - s : s;
+    // 1. the four K-quarter partial tiles of this (direction, tile)
+    if (!lds_wait_ge(&part_done[d][mt], 4 * (r + 1), &s_abort, a.ctrl)) return;
+    SK2_STAMP(0);
+    f32x4 acc = *reinterpret_cast<const f32x4*>(&red[d][mt][lane][0]);
+    acc += *reinterpret_cast<const f32x4*>(&red[d][mt + 2][lane][0]);
+    acc += *reinterpret_cast<const f32x4*>(&red[d][mt + 4][lane][0]);
+    acc += *reinterpret_cast<const f32x4*>(&red[d][mt + 6][lane][0]);
+    // 2. cell update (lane-local: D row = 4 (lane>>4) + reg -> i,f,g,o of (unit, b))
+    const float gi_ = fast_sigmoid(acc[0] + gxv.x);
+    const float gf = fast_sigmoid(acc[1] + gxv.y);
+    const float gg = fast_tanh(acc[2] + gxv.z);
+    const float go = fast_sigmoid(acc[3] + gxv.w);
+    const float c_new = gf * c_reg + gi_ * gg;
+    const float h_new = go * fast_tanh(c_new);
+    const bool valid = cellok && t < len_b;
+    if (valid) {
+      c_reg = c_new;
+      h_reg = h_new;
+    }
+    // 3. publish h_s: the 4 units of a row are adjacent in the image -> gathered through LDS, one 16-byte write-through
+    //    store per row (16 lanes, 256 contiguous bytes per wave); drain; the last wave of the pair raises the flag
+    pubs[c][bl][u_l] = cellok ? h_reg : 0.f;
+    if (lane < 16) {
+      const u32x4 hv = *reinterpret_cast<const u32x4*>(&pubs[c][lane][0]);  // same wave: LDS operations are in order
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((s & 1) ? xb1 : xb0, 0, (int)(xblk * 4), 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128(hv, rs, (unsigned)((((ug * 2 + mt) * 16 + lane) * 4) * 4), 0, 16 /* sc1 */);
+    }
+    SK2_STAMP(1);
+    wait_vmcnt<0>();
+    SK2_STAMP(2);
+    if (pair_arrive(&pub_done[d], lane) == 2 * r + 1 && lane == 0)
+      __hip_atomic_store(flags0 + (size_t)ug * fs, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+    const long long t_pub = a.poll_delay ? wall_clock64() : 0LL;
+    SK2_STAMP(3);
+    // 4. bulk stores of the step, off the chain
+    if (cellok) {
+      a.y[((size_t)t * B + b) * 2 * H + (size_t)d * H + unit] = valid ? h_new : 0.f;
+      if (a.gates && valid) {
+        f32x4 gv = {gi_, gf, gg, go};
+        *reinterpret_cast<f32x4*>(a.gates + (((size_t)t * B + b) * 2 + d) * 4 * H + 4 * (size_t)unit) = gv;
+        a.cs[(((size_t)t * B + b) * 2 + d) * H + unit] = c_new;
+      }
+    }
+    if (r + 1 == nsteps) break;
+    // 5. next step: input-projection terms; the pair's first wave waits for the stream's flags and tells the MFMA waves
+    {
+      const int tn = d ? t - 1 : t + 1;
+      if (cellok) gxv = *reinterpret_cast<const float4*>(a.gx + (((size_t)tn * B + b) * 2 + d) * 4 * H + 4 * (size_t)unit);
+    }
+    SK2_STAMP(4);
+    if (mt == 0) {
+      if (!wait_flags(flags0, NUG, (unsigned)(s + 1), a.ctrl, lane, a.poll_delay ? t_pub + 10LL * a.poll_delay : 0LL, fs)) {
+        if (lane == 0) __hip_atomic_store(&s_abort, 1, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
+      if (lane == 0) __hip_atomic_store(&up[d], r + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    SK2_STAMP(5);
+  }
+  if (w == 8) SK2_FLUSH(a.ctrl, 8, 6);
+#ifdef SK_LSTM_STAMPS
+  if (mt == 0 && lane == 0) {  // every workgroup, both directions: the unused tail of the exchange buffer (diagnostic build only)
+    long long* dbg = reinterpret_cast<long long*>(a.xbuf + (size_t)4 * NBG * xblk) + ((size_t)blockIdx.x * 2 + d) * 16;
+    for (int i = 0; i < 6; ++i) dbg[i] = st2_acc[i];
+    dbg[9] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
+    dbg[10] = ug;
+    dbg[11] = bg;
+  }
+#endif
+  if (cellok) {
+    if (a.s_end == T) {
+      if (a.hn) a.hn[((size_t)d * B + b) * H + unit] = h_reg;
+      if (a.cn) a.cn[((size_t)d * B + b) * H + unit] = c_reg;
+    } else {
+      a.state[((size_t)d * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = c_reg;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ backward
 // dh_{prev}[b][u] = sum_{k'} dG[b][k'] W_hh[row(k')][u],  k' = 4*unit_k + gate (gate-interleaved).
 // Transposed MFMA: D[m = out unit][n = batch] = sum_k' A[m][k'] B[k'][n]; wave w takes the k' chunks
@@ -942,6 +1296,17 @@ int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
   return 0;
 }
 
+// two-stream kernel: KS whose 16-k chunks split into four K quarters
+bool fwd2_supported(int KS) { return KS == 20 || KS == 56 || KS == 64; }
+int dispatch_fwd2(int KS, const FwdArgs& a, int nblocks, hipStream_t st) {
+  switch (KS) {
+    case 20: hipLaunchKernelGGL((lstm_fwd2_kernel<20>), dim3((unsigned)nblocks), dim3(768), 0, st, a); break;
+    case 56: hipLaunchKernelGGL((lstm_fwd2_kernel<56>), dim3((unsigned)nblocks), dim3(768), 0, st, a); break;
+    default: hipLaunchKernelGGL((lstm_fwd2_kernel<64>), dim3((unsigned)nblocks), dim3(768), 0, st, a); break;
+  }
+  return 0;
+}
+
 int dispatch_fwd(int KS, bool bf, const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
   if (bf) switch (KS) {
       case 20: return launch_fwd<20, true>(a, half, nblocks, st);
@@ -994,7 +1359,7 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 28) == 0,
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 29) == 0,
                "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
@@ -1024,6 +1389,7 @@ extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float*
   SK_CHECK_ARG(((uintptr_t)gx % 16) == 0 && ((uintptr_t)gates % 16) == 0, "sk_lstm_fwd: gx / gates must be 16-byte aligned");
   int rc = check_common("sk_lstm_fwd", T, B, H, whh, mode);
   if (rc) return rc;
+  const int mode_in = mode;
   const int gmin = (mode >> 8) & 0xff;  // bits 8..15: minimum batch groups per workgroup (frees CUs for concurrent kernels)
   const bool bf = (mode >> 16) & 1;     // bit 16: bf16 matrix-core inputs
   const bool half = (mode >> 17) & 1;   // bit 17: 8-unit, 256-thread workgroups, two per CU
@@ -1032,6 +1398,7 @@ extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float*
                                         // bit 22: one flag per 128-byte line
   if (opt & 4) opt &= ~2;              // one flag per line: no replicas on top (the flag block is sized for either)
   int poll_delay = (mode >> 23) & 31;  // bits 23..27: FwdArgs::poll_delay, units of 0.1 us; 0 = choose, 31 = none
+  const bool dual = (mode >> 28) & 1;  // bit 28: two-stream workgroups (8 units x both directions), where the shape allows
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -1055,6 +1422,14 @@ extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float*
   a.map = map; a.nby = nby; a.opt = opt; a.poll_delay = poll_delay;
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));  // per-launch status word + flags (not the sticky word)
+  if (dual && !bf && !half && mode != 2 && gmin <= 1 && fwd2_supported(L.KS) && 2 * L.KS * L.NBG <= num_cus()) {
+    // one 768-thread workgroup per CU (131-147 KB of LDS): 2 KS unit groups x NBG batch groups, both directions each
+    a.G = 1; a.nby = L.NBG; a.s_begin = s_begin; a.s_end = s_end;
+    a.poll_delay = ((mode_in >> 23) & 31) == 31 ? 0 : (((mode_in >> 23) & 31) ? ((mode_in >> 23) & 31) : 8);
+    dispatch_fwd2(L.KS, a, 2 * L.KS * L.NBG, st);
+    SK_CHECK_LAUNCH("sk_lstm_fwd");
+    return SK_OK;
+  }
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = s_begin; a.s_end = s_end;
     dispatch_fwd(L.KS, bf, a, half, nblocks, st);

@@ -145,6 +145,10 @@ class Engine:
         last check.  Training does not need it per step -- see `guard` -- drivers call it at epoch / checkpoint time."""
         ops.lstm_status(ops.workspace(0, "lstm"))
 
+    def sticky(self):
+        """The workspace's sticky status word as a device tensor (1 element, int32): non-zero after a timed-out launch."""
+        return ops.lstm_sticky(ops.workspace(0, "lstm"))
+
     # ------------------------------------------------------------------ the three kinds of product
     # fp32: the fp32 MFMA kernel on the fp32 tensors.  bf16: sk_gemm_bf16_nt on bf16 copies; `cache` (one dict per
     # pass) holds the copies already made, keyed by (kind, id of the fp32 tensor), and keeps them alive.
@@ -160,9 +164,12 @@ class Engine:
             c = ops.cast_bf16(t2d) if kind == "row" else ops.cast_bf16_t(t2d)
             ev = torch.cuda.Event()
             ev.record(cur)
-            cache[key] = ent = (c, ev, cur)
+            # the entry holds the fp32 SOURCE too: its address cannot be recycled for another tensor of the same shape
+            # while the copy is cached (sources are not written between their uses within a pass)
+            cache[key] = ent = (c, ev, cur, t2d)
         elif ent[2] != cur:
             cur.wait_event(ent[1])
+            ent[0].record_stream(cur)
         return ent[0]
 
     def _proj(self, cache, inp2d, w, out2d, bias, act=0):
@@ -323,8 +330,11 @@ class Engine:
             saved.append((inp2d, gx, cs, y, wih_gi))
             inp, I = y, 2 * H
         del keep
-        if not save:
-            ops.lstm_status(ws)          # inference: the caller copies the masks to the host next, a sync costs nothing
+        if not save and not skdist.is_parallel():
+            # inference: the caller copies the masks to the host next, a sync costs nothing.  Under data parallelism a
+            # raise on ONE rank would leave the others waiting in their next collective: there the sticky word stays set
+            # and the driver reports it on every rank together (steps/train_qsub.py::validation_pass)
+            ops.lstm_status(ws)
         y2d = inp.view(R, 2 * H)
         if training:
             mean = torch.empty(2 * H, device=dev)

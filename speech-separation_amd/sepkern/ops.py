@@ -66,8 +66,10 @@ def workspace(nbytes, tag="default"):
     key = (torch.cuda.current_device(), tag)
     ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        # zeroed: the LSTM workspace starts with a sticky status word that no launch clears (include/sepkern.h)
-        ws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+        # zeroed: the LSTM workspace starts with a sticky status word that no launch clears (include/sepkern.h) ...
+        old, ws = ws, torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device="cuda")
+        if old is not None and tag == "lstm":
+            ws[:4].copy_(old[:4])      # ... and a larger request must not lose it (RSH passes of different (T, B))
         _WS[key] = ws
     return ws
 
@@ -461,11 +463,14 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
-def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0):
-    """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..23);
-    poll_delay: the forward kernel's polling wave holds its first poll of a step back adaptively."""
+def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0, dual=False):
+    """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..28);
+    poll_delay: the forward kernel's polling wave holds its first poll of a step back (units of 0.1 us, 0 = the library's
+    choice, 31 = none); dual: the forward kernel with two streams per workgroup (8 units x both directions) where the
+    shape allows it -- same results up to the rounding of a different summation order over K."""
     return ((0x20000 if half else 0) | ((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) |
-            (0x200000 if repflags else 0) | (0x400000 if spread else 0) | ((int(poll_delay) & 31) << 23))
+            (0x200000 if repflags else 0) | (0x400000 if spread else 0) | ((int(poll_delay) & 31) << 23) |
+            (0x10000000 if dual else 0))
 
 
 def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0, steps=None):

@@ -51,11 +51,14 @@ class ClipAdam:
                                "(grid not co-resident?); try SEPKERN_LSTM_MODE=2" % n)
 
     def state_dict(self):
+        """'step' is the number of updates actually APPLIED (calls minus skipped calls; the kernel's bias corrections use
+        the same number), so a resumed run continues with the corrections an uninterrupted one would use."""
         self._state()
-        return {"step": self.step_count, "m": self.m.clone(), "v": self.v.clone()}
+        return {"step": self.step_count - self.skipped(), "m": self.m.clone(), "v": self.v.clone()}
 
     def load_state_dict(self, sd):
         self._state()
         self.step_count = int(sd["step"])
+        self.scal.zero_()
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])

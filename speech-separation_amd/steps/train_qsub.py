@@ -194,19 +194,71 @@ def resume(model, optimizer, run, args):
 
 
 # ----------------------------------------------------------------------------------------------- passes
+POLL_EVERY = 50      # steps between two reads of the optimizer's skipped-step counter (one small host sync each)
+
+
+def recover_from_timeout(model, optimizer, newly_skipped, epoch):
+  """A persistent recurrence launch timed out (its bounded wait gave up: the grid was not co-resident).  The device
+  already kept that step away from the weights on EVERY rank (the guard word is all-reduced with the gradients, so the
+  skipped count is the same everywhere and all ranks take this branch together).  Clear the sticky word, continue IN
+  THIS PROCESS with one launch per step (never re-exec a process that holds the GPU), and say so."""
+  try:
+    model.check_status()                 # reads and clears the workspace's sticky word
+  except Exception as e:                 # SepkernError(SK_ETIMEOUT): expected here
+    print("train: %s" % e, file=sys.stderr)
+  eng = getattr(model, "_engine", None)
+  if eng is None or eng.lstm_mode == 2:
+    raise RuntimeError("the recurrence failed in per-step launch mode too (%d steps skipped in epoch %d)"
+                       % (newly_skipped, epoch + 1))
+  eng.lstm_mode = 2
+  print("train: epoch %d: %d step(s) skipped after a timed-out persistent recurrence launch; their loss terms are dropped, "
+        "continuing with one launch per step (SEPKERN_LSTM_MODE=2)" % (epoch + 1, newly_skipped), file=sys.stderr)
+  sys.stderr.flush()
+
+
 def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
   """One pass over this rank's batches.  Returns the device tensor [sum(loss * norm), sum(norm)] of the GLOBAL
-  epoch (all-reduced), still un-synchronised."""
-  acc = torch.zeros(2, device=next(model.parameters()).device, dtype=torch.float64)
-  for batch in batches:
+  epoch (all-reduced), still un-synchronised.  Every POLL_EVERY steps (and at the end) the fused optimizer's
+  skipped-step counter is read: the loss terms of a window that contains a skipped step (garbage or NaN forwards) are
+  dropped instead of poisoning the epoch's sums, and the run continues in per-step launch mode."""
+  dev = next(model.parameters()).device
+  acc = torch.zeros(2, device=dev, dtype=torch.float64)
+  win = torch.zeros(2, device=dev, dtype=torch.float64)
+  fused = hasattr(optimizer, "skipped")
+  seen = optimizer.skipped() if fused else 0
+  eng_guard = None
+
+  def close_window():
+    nonlocal seen, win
+    if fused:
+      now = optimizer.skipped()
+      if now > seen:
+        recover_from_timeout(model, optimizer, now - seen, epoch)
+        seen = now
+        win = torch.zeros_like(win)
+        return
+    acc.add_(win)
+    win = torch.zeros_like(win)
+
+  for i, batch in enumerate(batches):
     loss, norm = m.compute_loss(model, epoch, batch)
-    acc[0] += loss.detach().double() * norm.double()
+    win[0] += loss.detach().double() * norm.double()
     # under data parallelism `norm` is already the global frame count: every rank adds its 1/world share
-    acc[1] += norm.double() / world
+    win[1] += norm.double() / world
     loss.backward()
     if torch_clip:
+      # torch's optimizer knows nothing of the guard word: look at it here (one host sync per step on this
+      # compatibility path; it is all-reduced with the gradients, so every rank decides alike)
+      eng = getattr(model, "_engine", None)
+      if eng is not None and float(eng.guard.item()) != 0.0:
+        recover_from_timeout(model, optimizer, 1, epoch)
+        win = torch.zeros_like(win)
+        continue
       torch.nn.utils.clip_grad_norm_(model.parameters(), CLIP_NORM)
     optimizer.step()
+    if (i + 1) % POLL_EVERY == 0:
+      close_window()
+  close_window()
   if world > 1:
     torch.distributed.all_reduce(acc)
   return acc
@@ -214,8 +266,10 @@ def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
 
 def validation_pass(m, model, batches, epoch, world, plot_dir):
   """Eval-mode pass over this rank's shard of the CV set; no collective inside (the arch keeps its local norm
-  when not training).  Returns the global [sum(loss * norm), sum(norm)]."""
-  acc = torch.zeros(2, device=next(model.parameters()).device, dtype=torch.float64)
+  when not training).  Returns the global [sum(loss * norm), sum(norm)].  The recurrence's sticky status word rides
+  with the sums, so that a timed-out launch on one rank is raised by ALL ranks together (a raise on one rank alone
+  would leave the others waiting in this all-reduce)."""
+  acc = torch.zeros(3, device=next(model.parameters()).device, dtype=torch.float64)
   model.eval()
   with torch.no_grad():
     for i, batch in enumerate(batches):
@@ -224,17 +278,37 @@ def validation_pass(m, model, batches, epoch, world, plot_dir):
       acc[0] += loss.detach().double() * norm.double()
       acc[1] += norm.double()
   model.train()
+  eng = getattr(model, "_engine", None)
+  if eng is not None:
+    acc[2] = (eng.sticky() != 0).double().sum()
   if world > 1:
     torch.distributed.all_reduce(acc)
-  return acc
+  if float(acc[2]) != 0.0:
+    try:
+      model.check_status()               # clears this rank's word
+    except Exception:
+      pass
+    raise RuntimeError("validation pass of epoch %d: a persistent recurrence launch timed out on %d rank(s)"
+                       % (epoch + 1, int(acc[2])))
+  return acc[:2]
 
 
-def report_failures(model, optimizer):
-  """Epoch boundary: surface a timed-out recurrence launch (host sync)."""
-  if hasattr(optimizer, "check"):
-    optimizer.check()
-  if hasattr(model, "check_status"):
-    model.check_status()
+def report_failures(model, optimizer, world):
+  """Epoch boundary: surface a timed-out recurrence launch that train_epoch's recovery did not absorb (host sync).  The
+  verdict is all-reduced first: every rank raises, or none does."""
+  bad = 0
+  if hasattr(optimizer, "skipped") and getattr(model, "_engine", None) is not None:
+    bad = int(model._engine.sticky().item() != 0)
+  if world > 1:
+    t = torch.tensor([float(bad)], device=next(model.parameters()).device)
+    torch.distributed.all_reduce(t)
+    bad = int(t.item() != 0)
+  if bad:
+    try:
+      model.check_status()
+    except Exception:
+      pass
+    raise RuntimeError("a persistent recurrence launch timed out after the fallback to per-step launches")
 
 
 def write_checkpoint(model, optimizer, run, epoch_number):
@@ -294,7 +368,7 @@ def main(argv=None):
         print("For epoch: " + run.epoch_tag(number) + " cv set loss is: " + str(cv_value))
       run.logs["cv"].record(number, cv_value, chief)
     value = float(acc[0] / acc[1])                  # the epoch's one host sync
-    report_failures(model, optimizer)
+    report_failures(model, optimizer, world)
     if chief:
       print("For epoch: " + run.epoch_tag(number) + " loss is: " + str(value))
     run.logs["train"].record(number, value, chief)

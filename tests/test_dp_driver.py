@@ -132,3 +132,21 @@ def test_dp_training_equals_single_process_on_the_same_global_batches(world, n, 
             np.testing.assert_allclose(flat, one[3], rtol=2e-3, atol=2e-5)
         else:
             np.testing.assert_allclose(losses, one[1], rtol=5e-2)     # same data but for the duplicated utterance
+
+
+def test_bench_py_launches_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the round driver calls bench.py): the parent
+    starts the ranks itself -- before importing torch or touching a GPU -- and relays the worst return code.  There is no
+    GPU here, so the ranks fail at their first device call: what is checked is the launcher (two ranks started with the
+    rendezvous variables set, a non-zero exit relayed, no JSON line printed, nothing left running)."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert "launcher: started 2 ranks" in r.stderr
+    if r.returncode == 0:                       # a GPU box: both ranks ran (one device each, or the rehearsal variables)
+        assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
+    else:
+        assert "exited with code" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

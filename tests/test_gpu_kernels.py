@@ -447,7 +447,7 @@ def test_clip_adam_matches_torch(ops):
     pt = torch.nn.Parameter(p0.clone())
     opt = torch.optim.Adam([pt], lr=1e-3)
     p = dev(p0.clone())
-    m, v, scal = torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(2).cuda()
+    m, v, scal = torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(4).cuda()     # scal: 4 floats (sepkern.h)
     for step in range(1, 4):
         g = torch.randn(n) * (0.01 if step == 2 else 1e-4)           # step 2 clips, the others do not
         pt.grad = g.clone()
@@ -692,6 +692,47 @@ def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H,
         out = bwd(ops.lstm_variant_bits(*variant), ref)
         for a, b in zip(out, bref):
             assert torch.equal(a, b), variant
+
+
+@pytest.mark.parametrize("T,B,H,lens,delay", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1], 0), (9, 32, 1024, [9] * 31 + [3], 31),
+                                              (40, 16, 896, [40] * 9 + [17] * 7, 4), (7, 20, 300, [7] * 7 + [4] * 13, 0), (6, 20, 600, [6] * 7 + [4] * 13, 0),
+                                              (11, 3, 320, [11, 5, 1], 0)])
+def test_lstm_two_stream_forward_kernel(ops, T, B, H, lens, delay):
+    """lstm_fwd2_kernel (mode bit 28: workgroups of 8 units x both directions, MFMA waves and cell waves, no workgroup
+    barrier in the time loop) against the one-stream kernel: same values up to the rounding of summing four K quarters
+    instead of two K halves (1e-6 absolute on O(1) activations over the whole sequence), bit-for-bit reproducible from run
+    to run, and a sequence advanced in two launches equals one launch bit for bit.  H = 600 (38 unit groups: no four-way K
+    split) silently takes the one-stream kernel: then the results are identical."""
+    g = torch.Generator().manual_seed(7 * H + T)
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+
+    def fwd(bits, ranges=(None,)):
+        gg = gx.clone()
+        y = torch.full((T, B, 2 * H), float("nan")).cuda()
+        cs = torch.zeros(T, B, 2, H).cuda()
+        hn, cn = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+        for r in ranges:
+            ws = ops.lstm_fwd(gg, whh, h0, c0, lens_d, y, gg, cs, hn, cn, T, B, H, 1 | bits, steps=r)
+        ops.lstm_status(ws)
+        return y, gg, cs, hn, cn
+
+    valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
+    ref = fwd(ops.lstm_variant_bits(False, 1, True, False, False, 0))
+    dual = ops.lstm_variant_bits(False, 1, True, False, False, delay, dual=True)
+    out = fwd(dual)
+    again = fwd(dual)
+    cut = fwd(dual, [(0, T // 3), (T // 3, T)])
+    for a, b, c_, e in zip(out, ref, again, cut):
+        if a.dim() == 4 and a.shape[-1] == 4 * H:
+            a, b, c_, e = a[valid], b[valid], c_[valid], e[valid]
+        if a.dim() == 4:                                                          # cs: defined at valid steps only
+            a, b, c_, e = a[valid], b[valid], c_[valid], e[valid]
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) < (1e-30 if H == 600 else 3e-6)
+        assert torch.equal(a, c_) and torch.equal(a, e)
 
 
 @pytest.mark.parametrize("bf16", [False, True])

@@ -489,3 +489,45 @@ def test_timed_out_recurrence_never_reaches_the_weights(arch):
     model.check_status()
     one_step()
     assert opt.skipped() == 1 and not torch.equal(model.flat_parameters()[0], before)
+    assert opt.state_dict()["step"] == opt.step_count - 1     # updates actually applied (the bias corrections' count)
+
+
+def test_training_driver_recovers_in_process_from_a_timed_out_launch(arch, capsys):
+    """steps/train_qsub.py::train_epoch polls the fused optimizer's skipped-step counter every POLL_EVERY steps: after a
+    timed-out persistent launch (simulated: the sticky word set) it clears the word, drops the loss terms of that window,
+    switches the engine to one launch per step IN THIS PROCESS and goes on training -- instead of skipping every later
+    step of the epoch and dying at its end."""
+    import importlib
+    from sepkern import ops
+    from sepkern.optim import ClipAdam
+    sys.path.insert(0, os.path.join(PKG, "steps"))
+    tq = importlib.import_module("train_qsub")
+    torch.manual_seed(6)
+    H, L, B, T = 64, 2, 4, 9
+    model = arch.SepDNN(0, hidden_dim=str(H), num_layers=str(L))
+    model.cuda()
+    model.train()
+    opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
+    rng = np.random.default_rng(1)
+    samples = [{"mix": np.abs(rng.standard_normal((T, 257))).astype(np.float32),
+                "source1": np.abs(rng.standard_normal((T, 257))).astype(np.float32),
+                "source2": np.abs(rng.standard_normal((T, 257))).astype(np.float32)} for _ in range(B)]
+    batch = arch.Collator("mix")(samples)
+    acc = tq.train_epoch(arch, model, opt, [batch] * 2, 0, 1, False)        # binds the engine, allocates the workspace
+    assert opt.skipped() == 0 and model._engine.lstm_mode == 0
+    clean = float(acc[0] / acc[1])
+    ops.lstm_sticky(ops.lstm_ws(T, B, H)).fill_(1)
+    before = model.flat_parameters()[0].clone()
+    old = tq.POLL_EVERY
+    tq.POLL_EVERY = 2
+    try:
+        acc = tq.train_epoch(arch, model, opt, [batch] * 6, 1, 1, False)
+    finally:
+        tq.POLL_EVERY = old
+    assert opt.skipped() == 2                                   # the first window of two steps; none after the recovery
+    assert model._engine.lstm_mode == 2
+    assert "continuing with one launch per step" in capsys.readouterr().err
+    assert not torch.equal(model.flat_parameters()[0], before)  # the four later steps were applied
+    value = float(acc[0] / acc[1])
+    assert np.isfinite(value) and 0 < value < 2 * clean
+    tq.report_failures(model, opt, 1)                           # nothing left to report

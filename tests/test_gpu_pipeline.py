@@ -204,3 +204,30 @@ def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step"] == 2 * 4 * 40
     assert d["value"] > 0 and d["unit"] == "frames/s" and "cpu_baseline" not in d
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with no torchrun around it (the way the round driver calls bench.py): the parent starts
+    the two ranks itself as fresh child processes BEFORE anything touches the GPU, relays rank 0's single JSON line and the
+    worst return code.  Rehearsed here with both ranks on cuda:0 over gloo (one-device box); on a node it is nccl = RCCL,
+    one rank per GPU."""
+    import json
+    env = dict(os.environ, SEPKERN_BENCH_ONE_DEVICE="1", SEPKERN_DIST_BACKEND="gloo", SEPKERN_LSTM_MODE="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    root = os.path.dirname(PKG)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--hidden", "64",
+                        "--layers", "2", "--batch", "4", "--frames", "40"], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 * 4 * 40 and d["value"] > 0
+    dd = d["distributed"]
+    assert dd["backend"] == "gloo" and dd["world_size"] == 2 and dd["distinct_devices"] == 1      # both ranks on cuda:0 here
+    assert dd["launcher"] == "self" and dd["grad_allreduce"] in ("single", "chunked-overlapped")
+    # a rank that fails takes the job down with a non-zero code instead of leaving the others in a collective
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--hidden", "63"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=400)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
