@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 109
+#define SK_VERSION 110
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -203,6 +203,9 @@ int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int ld_sr
  * sk_lstm_status: 0, or SK_ETIMEOUT if a launch since the last call timed out (reads the word back to the host,
  * synchronises the stream, clears the word). */
 int sk_lstm_status(void* ws, sk_stream_t stream);
+/* dst (R, ld_dst) = src (R, C; rows ld_src floats apart) with columns C..ld_dst-1 zero: the copy of the F = 257 input
+ * features with rows padded to 260 floats (16-byte aligned rows for both operands of the layer-0 products). */
+int sk_pad_rows(const float* src, int64_t R, int C, int ld_src, float* dst, int ld_dst, sk_stream_t stream);
 /* ---------------------------------------------------------------- BatchNorm1d over (rows, C)
  * Replaces nn.BatchNorm1d(2H) on (B, 2H, T) (reference archs/uPIT.py:119,138): statistics over
  * ALL rows = B*T_max positions, zero-padded frames included.

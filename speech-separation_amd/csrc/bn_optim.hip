@@ -156,6 +156,18 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
   }
 }
 
+// dst (R, ld_dst) <- src (R, C) with row stride ld_src; columns C..ld_dst-1 zero.  One pass (the engine pads the
+// F = 257 input features to 260 columns so that rows of both GEMM operands are 16-byte aligned).
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t R,
+                                                       int C, int ld_src, int ld_dst) {
+  const int64_t total = R * ld_dst;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / ld_dst;
+    const int c = (int)(i - r * ld_dst);
+    dst[i] = c < C ? src[r * ld_src + c] : 0.f;
+  }
+}
+
 constexpr int NORM_BLOCKS = 1024;
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
@@ -344,6 +356,14 @@ extern "C" int sk_sigmoid_bwd(const float* dmask, const float* m, float* dz, int
   SK_CHECK_ARG(dmask && m && dz && n > 0, "sk_sigmoid_bwd: bad arguments");
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, dmask, m, dz, n);
   SK_CHECK_LAUNCH("sk_sigmoid_bwd");
+  return SK_OK;
+}
+
+extern "C" int sk_pad_rows(const float* src, int64_t R, int C, int ld_src, float* dst, int ld_dst, sk_stream_t stream) {
+  SK_CHECK_ARG(src && dst && src != dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C, "sk_pad_rows: bad arguments");
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(stream_blocks(R * ld_dst)), dim3(256), 0, (hipStream_t)stream, src, dst, R, C,
+                     ld_src, ld_dst);
+  SK_CHECK_LAUNCH("sk_pad_rows");
   return SK_OK;
 }
 

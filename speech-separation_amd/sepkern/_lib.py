@@ -13,7 +13,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEPKERN_LIB") or os.path.join(_HERE, "libsepkern.so")   # SEPKERN_LIB: diagnostic builds
 
-SK_VERSION = 109
+SK_VERSION = 110
 
 _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -51,6 +51,7 @@ PROTOTYPES = {
     "sk_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, C.c_double, _f, _p]),
     "sk_colsum": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
     "sk_sigmoid_bwd": (_i, [_p, _p, _p, _i64, _p]),
+    "sk_pad_rows": (_i, [_p, _i64, _i, _i, _p, _i, _p]),
     "sk_pit_workspace_bytes": (_sz, [_i, _i, _i]),
     "sk_pit_mse_fwd": (_i, [_p, _p, C.POINTER(_p), _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
     "sk_pit_mse_bwd": (_i, [_p, _p, C.POINTER(_p), _p, _p, _p, _i, _i, _i, _i, _p, _p]),

@@ -41,6 +41,10 @@ def init_from_env(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = backend or os.environ.get("SEPKERN_DIST_BACKEND", "nccl")
+        if overlap_enabled():
+            # chunked exchange beside the backward pass: keep the collective's kernels within the CUs a persistent
+            # recurrence grid leaves free (32 of 256 at the benchmark shape)
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         if backend == "nccl":
             torch.cuda.set_device(lr)
             dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
@@ -73,7 +77,7 @@ def overlap_mode_name():
     """How the gradient exchange of a step is issued (bench.py prints it): one collective after the backward pass
     (default) or layer-ordered chunks on a communication stream while the backward pass is still running
     (SEPKERN_DP_OVERLAP=1, GradReducer)."""
-    return "chunked-overlapped" if os.environ.get("SEPKERN_DP_OVERLAP", "0") == "1" else "single"
+    return "chunked-overlapped" if overlap_enabled() else "single"
 
 
 def allreduce_grads(flat_grad):
@@ -88,6 +92,62 @@ def allreduce_grads(flat_grad):
         else:
             dist.all_reduce(flat_grad)
     return flat_grad
+
+
+class GradReducer:
+    """SEPKERN_DP_OVERLAP=1 (default off): the gradient exchange of a step as layer-ordered chunks instead of one
+    collective after the backward pass.  The engine hands over each chunk of its flat gradient buffer (Linear +
+    BatchNorm, then the LSTM layers from the top down, the bottom layer with the guard words last:
+    engine.ParamLayout.grad_chunks) as soon as the kernels that complete it are enqueued; the chunk is all-reduced on a
+    communication stream behind an event of the producing stream, while the backward pass goes on with the next layer's
+    recurrence.  finish() makes the current stream wait for all of them.  Same sums as the single collective (every
+    element is reduced exactly once), every rank issues the same sequence.
+
+    Why it is opt-in: the persistent recurrence needs its workgroups co-resident (224 of 256 CUs at 3x896 / batch 32);
+    an RCCL kernel that holds more CUs than the grid leaves free would park some of them behind it (bounded spins: a
+    skipped step, never a wrong one).  init_from_env caps NCCL_MAX_NCHANNELS for this mode; the fp32 step hides ~2 ms
+    of a 37 ms step with it, the bf16 step ~2 of 14.6."""
+
+    def __init__(self):
+        self.comm = None
+        self.pending = []
+        self.first = None
+
+    def chunk(self, buf, lo, hi, producer_stream=None):
+        if not is_parallel():
+            return
+        part = buf[lo:hi]
+        if not part.is_cuda:                                  # CPU tensors (gloo tests): in line
+            dist.all_reduce(part)
+            return
+        if self.comm is None:
+            self.comm = torch.cuda.Stream(device=part.device)
+        ev = torch.cuda.Event()
+        ev.record(producer_stream if producer_stream is not None else torch.cuda.current_stream())
+        self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            if TIMING is not None and self.first is None:
+                self.first = torch.cuda.Event(enable_timing=True)
+                self.first.record()
+            self.pending.append(dist.all_reduce(part, async_op=True))
+
+    def finish(self):
+        """The current stream waits for every chunk issued since the last finish()."""
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.comm is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self.comm)
+            if TIMING is not None and self.first is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record(cur)
+                TIMING.append((self.first, e1))            # span from the first chunk's issue to the last one's end
+            self.first = None
+
+
+def overlap_enabled():
+    return os.environ.get("SEPKERN_DP_OVERLAP", "0") == "1"
 
 
 def combine_bn_stats(mean, var, count):

@@ -54,6 +54,21 @@ class ParamLayout:
             off = _align(off + n)
         self.total = off
 
+    GUARD = 4      # floats in front of the gradients in Engine.grad_full (word 0: the recurrence's status, see Engine)
+
+    def grad_chunks(self):
+        """[(name, lo, hi)] over Engine.grad_full = [guard words | gradients], in the order in which the backward pass
+        completes them: Linear + BatchNorm, then the LSTM layers from the top down; the bottom layer's chunk comes last
+        and carries the guard words in front of it (they are written at the very end of the pass).  Contiguous, disjoint,
+        covering the buffer: the data-parallel exchange may go chunk by chunk (sepkern.dist.GradReducer)."""
+        G = self.GUARD
+        start = [self.blocks["weight_ih_l%d" % l][0] for l in range(self.L)] + [self.blocks["lin.weight"][0]]
+        out = [("lin+bn", G + start[self.L], G + self.total)]
+        for l in range(self.L - 1, 0, -1):
+            out.append(("layer%d" % l, G + start[l], G + start[l + 1]))
+        out.append(("guard+layer0", 0, G + start[1]))
+        return out
+
     def view(self, flat, name):
         off, shape = self.blocks[name]
         n = 1
@@ -84,12 +99,15 @@ class Engine:
         self.layout = ParamLayout(in_dim, out_dim, hidden, layers)
         self.device = device
         self.flat = torch.zeros(self.layout.total, device=device)
-        # gradients + one trailing word: the recurrence's sticky status (sepkern/ops.lstm_sticky) is copied there at the
+        # [guard words | gradients]: the recurrence's sticky status (sepkern/ops.lstm_sticky) is copied into word 0 at the
         # end of every backward, so the data-parallel all-reduce of the buffer tells EVERY rank when any rank's
-        # persistent launch timed out, and the fused clip+Adam skips that step on the device (no host sync per step)
-        self.grad_full = torch.zeros(self.layout.total + 4, device=device)
-        self.grad = self.grad_full[:self.layout.total]
-        self.guard = self.grad_full[self.layout.total:self.layout.total + 1]
+        # persistent launch timed out, and the fused clip+Adam skips that step on the device (no host sync per step).
+        # In FRONT of the gradients: the bottom layer's gradients are the last to be complete, so in the chunked exchange
+        # (ParamLayout.grad_chunks) the guard travels with the last chunk.
+        G = ParamLayout.GUARD
+        self.grad_full = torch.zeros(G + self.layout.total, device=device)
+        self.grad = self.grad_full[G:]
+        self.guard = self.grad_full[0:1]
         self.running_mean = torch.zeros(2 * hidden, device=device)
         self.running_var = torch.ones(2 * hidden, device=device)
         self.eps, self.momentum = 1e-5, 0.1
@@ -295,8 +313,7 @@ class Engine:
                 wih_gi, bsum, Ip = weights_of(l, I)
                 inp2d = inp.view(R, I)
                 if Ip != I:
-                    inp2d = torch.zeros(R, Ip, device=dev)
-                    inp2d[:, :I] = inp.view(R, I)
+                    inp2d = ops.pad_rows(inp2d, Ip)          # one pass, no memset (F = 257 -> 260)
                 gx = torch.empty(T, B, 2, 4 * H, device=dev)
                 self._proj(cache, inp2d, wih_gi, gx.view(R, 8 * H), bsum)
             else:
@@ -366,9 +383,11 @@ class Engine:
         return mask, hn, cn, ctx
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ctx, dmask, dhn=None, dcn=None, want_dx=False, want_dstate=False):
+    def backward(self, ctx, dmask, dhn=None, dcn=None, want_dx=False, want_dstate=False, reducer=None):
         """Parameter gradients (into the flat gradient buffer) from dmask (T,B,out_dim) and, optionally, the
-        gradient wrt the final state (dhn, dcn (2L,B,H)).  Returns (dx (T,B,in_dim) or None, dh0, dc0 or None)."""
+        gradient wrt the final state (dhn, dcn (2L,B,H)).  Returns (dx (T,B,in_dim) or None, dh0, dc0 or None).
+        reducer (sepkern.dist.GradReducer, data-parallel runs with SEPKERN_DP_OVERLAP=1, last backward of a step only):
+        every chunk of ParamLayout.grad_chunks() is handed over as soon as the kernels that complete it are enqueued."""
         if ctx is None:
             raise SepkernError("backward called without a saved forward")
         if not ctx["training"]:
@@ -434,6 +453,9 @@ class Engine:
                 ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc, ws_tag="bn" + tag)
             keep.append(dz)
         del dz
+        chunks = {name: (lo, hi) for name, lo, hi in self.layout.grad_chunks()} if reducer is not None else None
+        if reducer is not None:
+            reducer.chunk(self.grad_full, *chunks["lin+bn"], stream)       # (bn.weight / bn.bias were put before the side stream forked)
         ws = None
         dh0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
         dc0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
@@ -502,11 +524,15 @@ class Engine:
                 put("bias_ih_l%d" % l, db.view(2, 4 * H))
                 put("bias_hh_l%d" % l, db.view(2, 4 * H))
                 keep += [db, dbias, dg_first, dgx, inp, y, gw_hh, gw_ih]
+            if reducer is not None and l > 0:
+                reducer.chunk(self.grad_full, *chunks["layer%d" % l], stream)
             if l > 0:
                 dy = dy_next
         if overlap:
             main.wait_stream(self.side)
         del keep, cache
         self.guard.copy_(ops.lstm_sticky(ws))      # int32 -> float: non-zero = this step's gradients are garbage
+        if reducer is not None:
+            reducer.chunk(self.grad_full, *chunks["guard+layer0"], main)
         self.grads_fresh = False
         return dx, dh0, dc0

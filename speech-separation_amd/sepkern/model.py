@@ -32,14 +32,19 @@ class NetFn(torch.autograd.Function):
     model = ctx.model
     want_dx = ctx.needs_input_grad[2]
     want_ds = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+    last = model._pending <= 1        # the last backward of the step: the gradients become final chunk by chunk
+    reducer = model._reducer() if (last and skdist.is_parallel() and skdist.overlap_enabled()) else None
     dx, dh0, dc0 = model._engine.backward(ctx.fwd, dmask.contiguous(),
                                           dhn.contiguous() if dhn is not None else None,
                                           dcn.contiguous() if dcn is not None else None,
-                                          want_dx=want_dx, want_dstate=want_ds)
+                                          want_dx=want_dx, want_dstate=want_ds, reducer=reducer)
     ctx.fwd = None
     model._pending -= 1
     if model._pending <= 0:
-      model._allreduce_grads()        # once per step, after the last pass's backward
+      if reducer is not None:
+        reducer.finish()              # the chunks went out during the pass (SEPKERN_DP_OVERLAP=1)
+      else:
+        model._allreduce_grads()      # once per step, after the last pass's backward
     return None, None, dx, None, dh0, dc0, None
 
 
@@ -127,6 +132,11 @@ class SepDNNBase(nn.Module):
     """(params, grads): the two flat fp32 buffers (for sepkern.optim.ClipAdam and the DP all-reduce)."""
     eng = self._bind()
     return eng.flat, eng.grad
+
+  def _reducer(self):
+    if getattr(self, "_grad_reducer", None) is None:
+      self._grad_reducer = skdist.GradReducer()
+    return self._grad_reducer
 
   def _allreduce_grads(self):
     skdist.allreduce_grads(self._engine.grad_full)  # one RCCL collective: every gradient + the status word

@@ -451,6 +451,15 @@ def colsum(x, R, Ccols, ld, out, accumulate=False, ws_tag="bn"):
     _lib.call("sk_colsum", _ptr(x), R, Ccols, ld, _ptr(out), int(accumulate), _ptr(bn_ws(R, Ccols, ws_tag)), _stream())
 
 
+def pad_rows(x2d, ld):
+    """(R, ld) copy of an (R, C) matrix with zero columns C..ld-1, one pass (sk_pad_rows)."""
+    _chk(x2d)
+    R, Cc = x2d.shape
+    out = torch.empty(R, ld, device=x2d.device)
+    _lib.call("sk_pad_rows", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(out), ld, _stream())
+    return out
+
+
 def sigmoid_bwd(dmask, m, dz):
     _lib.call("sk_sigmoid_bwd", _ptr(dmask), _ptr(m), _ptr(dz), dmask.numel(), _stream())
 

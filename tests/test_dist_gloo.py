@@ -85,6 +85,23 @@ def _worker(rank, world, port, q):
     skdist.allreduce_grads(flat)
     tot = torch.tensor([float(loss)], dtype=torch.float64)
     dist.all_reduce(tot)
+    # the chunked exchange (SEPKERN_DP_OVERLAP=1: sepkern.dist.GradReducer over engine.ParamLayout.grad_chunks) reduces
+    # every element of [guard words | gradients] exactly once: bit-identical to the single collective
+    from sepkern.engine import ParamLayout
+    lay = ParamLayout(33, 66, 12, 2)
+    chunks = lay.grad_chunks()
+    cover = sorted((lo, hi) for _, lo, hi in chunks)
+    assert cover[0][0] == 0 and cover[-1][1] == lay.total + ParamLayout.GUARD
+    assert all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    assert [n for n, _, _ in chunks] == ["lin+bn", "layer1", "guard+layer0"]          # completion order of the backward pass
+    buf = torch.randn(lay.total + ParamLayout.GUARD, generator=torch.Generator().manual_seed(100 + rank))
+    one, two = buf.clone(), buf.clone()
+    skdist.allreduce_grads(one)
+    red = skdist.GradReducer()
+    for _, lo, hi in chunks:
+        red.chunk(two, lo, hi)
+    red.finish()
+    assert torch.equal(one, two) and not torch.equal(one, buf)
     q.put((rank, gnorm, float(tot), flat.numpy()))
     dist.barrier()
     dist.destroy_process_group()

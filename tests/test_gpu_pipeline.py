@@ -226,7 +226,16 @@ def test_bench_launches_its_own_ranks_when_no_launcher_did():
     assert d["n_gpus"] == 2 and d["config"]["frames_per_step"] == 2 * 4 * 40 and d["value"] > 0
     dd = d["distributed"]
     assert dd["backend"] == "gloo" and dd["world_size"] == 2 and dd["distinct_devices"] == 1      # both ranks on cuda:0 here
-    assert dd["launcher"] == "self" and dd["grad_allreduce"] in ("single", "chunked-overlapped")
+    assert dd["launcher"] == "self" and dd["grad_allreduce"] == "single"
+    # the opt-in chunked exchange (SEPKERN_DP_OVERLAP=1: layer-ordered chunks on a communication stream while the backward
+    # pass is still running) gives the same training trajectory: every gradient element is summed exactly once
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--hidden", "64",
+                         "--layers", "2", "--batch", "4", "--frames", "40"], cwd=root, env=dict(env, SEPKERN_DP_OVERLAP="1"),
+                        capture_output=True, text=True, timeout=400)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert d2["distributed"]["grad_allreduce"] == "chunked-overlapped"
+    assert d2["config"]["mean_loss"] == d["config"]["mean_loss"]
     # a rank that fails takes the job down with a non-zero code instead of leaving the others in a collective
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--hidden", "63"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=400)
