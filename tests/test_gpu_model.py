@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, ROOT, fixture_samples
+from conftest import GOLDEN, PKG, ROOT, fixture_samples
 from oracle import stft as OS
 from oracle import upit as OU
 
