@@ -115,8 +115,24 @@ int sk_gemm_bf16_splitk(const float* A, const float* B, float* C, const float* b
 int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                     int ldc, int accumulate, int act, int batch, int64_t sA, int64_t sB, int64_t sC, int64_t sbias,
                     int splitk, void* ws, sk_stream_t stream);
+/* The same product with either operand optionally K-MAJOR in memory: a_kmajor: A is stored [K][M] (element (m, k) at
+ * A[k * lda + m], i.e. the TRANSPOSE of an (K, M) row-major matrix is the factor), likewise b_kmajor for B stored [K][N].
+ * This is what the weight-gradient products (both factors are activation / gradient matrices whose ROWS are the
+ * contraction index) and the data-gradient products (the weight matrix (N, K') is the K-major B of dout (R, N) x W) need:
+ * with it they read the same row-major bf16 copies as the forward products and no transposed copy is ever made (the
+ * tiles are DMA'd as they lie and the MFMA fragments are gathered by the transposed LDS read ds_read_b64_tr_b16).
+ * K-major operand: ld = elements between consecutive k rows, >= its dimension rounded up to 8 and a multiple of 8; the
+ * (ld - dim) padding elements of a row must be readable (finite or not: their products are never stored); K % 64 == 0
+ * as always -- rows [K', K) of a zero-padded factor must be zeros in at least one of the two factors. */
+int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                    int ldc, int a_kmajor, int b_kmajor, int accumulate, int act, int batch, int64_t sA, int64_t sB,
+                    int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream);
 /* dst[r][c] = bf16(src[r][c]) (round to nearest even) for c < C, 0 for C <= c < ld_dst; ld_dst % 8 == 0. */
 int sk_cast_bf16(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream);
+/* The same with R_pad >= R rows written, rows R .. R_pad-1 zero: a copy that also serves as a K-MAJOR factor of
+ * sk_gemm_bf16_mm (its rows are then the contraction index, read in whole K steps of 64 and, in the time-shifted
+ * recurrent weight gradient, a few rows past the end). */
+int sk_cast_bf16_rows(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, int R_pad, sk_stream_t stream);
 /* dst[c][r] = bf16(src[r][c]) for r < R, 0 for R <= r < ld_dst: the transposed copy, (C, ld_dst) row-major. */
 int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream);
 

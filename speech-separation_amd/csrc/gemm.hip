@@ -957,7 +957,43 @@ __device__ __forceinline__ void piece_src(int piece, int lane, int& row, int& ch
   chunk = v & 7;
 }
 
-template <int BN>
+// ---- K-major operands ([K][dim] in memory, dim contiguous: an activation or gradient matrix used as the TRANSPOSED
+// factor of a weight-gradient product, or a weight matrix in a data-gradient product) need no transposed copy: the tile
+// is DMA'd as it lies -- 64 k rows of DIM elements -- and the MFMA fragments (8 consecutive k of one dim per lane) are
+// gathered by ds_read_b64_tr_b16, the hardware-transposed LDS read: a 16-lane group reads a block of 4 k rows x 16 dims
+// and lane i gets dim i of the 4 rows; two such reads make one bf16x8 operand (same LDS cycles as one ds_read_b128).
+// Image: row r of the tile at r * 2 DIM bytes; inside a row the 32-byte chunk c (16 dims) sits at chunk c ^ f(r),
+// f(r) = (r & 3) | (((r >> 3) & 1) << 2): the 8 row segments a half-wave reads in one instruction (k rows 8o + q of the
+// two lane groups o, q = 0..3, same 16 dims) then fall on the 8 different 32-byte bank groups (conflict-free).  The DMA
+// writes lane-linearly, so the permutation is applied to the per-lane SOURCE address.
+template <int DIM>
+__device__ __forceinline__ void kmaj_piece_src(int piece, int lane, int& row, int& dim) {
+  constexpr int ROWB = 2 * DIM;
+  const int off = piece * 1024 + 16 * lane;
+  row = off / ROWB;
+  const int c16 = (off % ROWB) >> 4;
+  const int c32 = (c16 >> 1) ^ ((row & 3) | (((row >> 3) & 1) << 2));
+  dim = c32 * 16 + (c16 & 1) * 8;
+}
+// byte offset of this lane's transposed-read address for the 16-dim block `c32` of the tile, k rows 8 (lane>>4) + q
+// (add 32 s * ROWB for the K half s and 4 * ROWB for the second read of a fragment)
+template <int DIM>
+__device__ __forceinline__ int kmaj_frag_addr(int c32, int lane) {
+  const int o = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int f = q | ((o & 1) << 2);
+  return (8 * o + q) * (2 * DIM) + ((c32 ^ f) << 5) + 8 * p;
+}
+__device__ __forceinline__ bf16x8 kmaj_frag(const char* tile, int addr, int rowb) {
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + addr));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + addr + 4 * rowb));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// AKM / BKM: the operand is K-major in memory (A stored [K][M], lda = row stride of a k row; B stored [K][N]).
+template <int BN, bool AKM = false, bool BKM = false>
 __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(Args g) {
   constexpr int TM = 8, TN = BN / 64;            // MFMA tiles per wave
   constexpr int PA = BM / 8 / 8, PB = BN / 8 / 8;  // 1 KB pieces per wave per K step (A: 4, B: 4 or 2)
@@ -995,26 +1031,56 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(Args g) {
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     int r, c;
-    piece_src(w * PA + i, lane, r, c);
-    srcA[i] = A + (int64_t)min(m0 + r, g.M - 1) * g.lda + kbeg + c * 8;
+    if (AKM) {  // r = k row of the tile, c = first of 8 dims; dims past the padded width are clamped (never stored)
+      kmaj_piece_src<BM>(w * PA + i, lane, r, c);
+      srcA[i] = A + (int64_t)(kbeg + r) * g.lda + min(m0 + c, g.lda - 8);
+    } else {
+      piece_src(w * PA + i, lane, r, c);
+      srcA[i] = A + (int64_t)min(m0 + r, g.M - 1) * g.lda + kbeg + c * 8;
+    }
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     int r, c;
-    piece_src(w * PB + i, lane, r, c);
-    srcB[i] = B + (int64_t)min(n0 + r, g.N - 1) * g.ldb + kbeg + c * 8;
+    if (BKM) {
+      kmaj_piece_src<BN>(w * PB + i, lane, r, c);
+      srcB[i] = B + (int64_t)(kbeg + r) * g.ldb + min(n0 + c, g.ldb - 8);
+    } else {
+      piece_src(w * PB + i, lane, r, c);
+      srcB[i] = B + (int64_t)min(n0 + r, g.N - 1) * g.ldb + kbeg + c * 8;
+    }
   }
+  const int64_t stepA = AKM ? (int64_t)BK * g.lda : BK, stepB = BKM ? (int64_t)BK * g.ldb : BK;
+  // K-major instantiations issue the DMA as inline assembly: behind the LDS-DMA BUILTIN hipcc puts an s_waitcnt vmcnt(0) in
+  // front of the transposed LDS reads (it cannot prove them disjoint from the DMA's destination), which serialises the next
+  // K step's fetch with this step's products (measured: 20-30 % slower).  The kernel orders DMA and reads itself (vmcnt(0)
+  // + barrier at the top of every K step).  The NT instantiation keeps the builtin (its plain loads are proven disjoint).
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned pieceA = __builtin_amdgcn_readfirstlane(lds_base + w * PA * 1024);
+  const unsigned pieceB = __builtin_amdgcn_readfirstlane(lds_base + ABYTES + w * PB * 1024);
   auto stage = [&](int buf, int kt) {
     char* a = lds + buf * (ABYTES + BBYTES);
     char* b = a + ABYTES;
 #pragma unroll
-    for (int i = 0; i < PA; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(a + (w * PA + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < PA; ++i) {
+      if (AKM || BKM)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(srcA[i] + kt * stepA),
+                     "s"(pieceA + buf * (ABYTES + BBYTES) + i * 1024)
+                     : "memory");
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[i] + kt * stepA),
+                                         (__attribute__((address_space(3))) void*)(a + (w * PA + i) * 1024), 16, 0, 0);
+    }
 #pragma unroll
-    for (int i = 0; i < PB; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + kt * BK),
-                                       (__attribute__((address_space(3))) void*)(b + (w * PB + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < PB; ++i) {
+      if (AKM || BKM)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(srcB[i] + kt * stepB),
+                     "s"(pieceB + buf * (ABYTES + BBYTES) + i * 1024)
+                     : "memory");
+      else
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[i] + kt * stepB),
+                                         (__attribute__((address_space(3))) void*)(b + (w * PB + i) * 1024), 16, 0, 0);
+    }
   };
 
   f32x4 acc[TM][TN];
@@ -1027,6 +1093,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(Args g) {
   // a tile further down adds 16 rows = 2048 B (the rotation repeats every 16 rows), kstep 1 flips slot bit 2 (^ 64 B)
   const int fa = img(wm * 128 + (lane & 15), lane >> 4);
   const int fb = img(wn * (BN / 4) + (lane & 15), lane >> 4);
+  // K-major operands: one transposed-read address per 16-dim block of the wave's tile (the chunk rotation is per block)
+  int ka[AKM ? TM : 1], kb[BKM ? TN : 1];
+  if (AKM) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ka[i] = kmaj_frag_addr<BM>(wm * TM + i, lane);
+  }
+  if (BKM) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) kb[j] = kmaj_frag_addr<BN>(wn * TN + j, lane);
+  }
 
   if (nk > 0) stage(0, 0);
   int cur = 0;
@@ -1040,9 +1116,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(Args g) {
     for (int s = 0; s < 2; ++s) {
       bf16x8 af[TM], bfr[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a + ((fa ^ (s << 6)) + i * 2048));
+      for (int i = 0; i < TM; ++i) {
+        if (AKM)
+          af[i] = kmaj_frag(a, ka[i] + s * 32 * (2 * BM), 2 * BM);
+        else
+          af[i] = *reinterpret_cast<const bf16x8*>(a + ((fa ^ (s << 6)) + i * 2048));
+      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(b + ((fb ^ (s << 6)) + j * 2048));
+      for (int j = 0; j < TN; ++j) {
+        if (BKM)
+          bfr[j] = kmaj_frag(b, kb[j] + s * 32 * (2 * BN), 2 * BN);
+        else
+          bfr[j] = *reinterpret_cast<const bf16x8*>(b + ((fb ^ (s << 6)) + j * 2048));
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1077,13 +1163,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(Args g) {
 
 // fp32 (R, C) -> bf16 copy with leading dimension ldd >= C, columns C..ldd-1 zero (row-major), RNE
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, int R, int C, int lds_, __bf16* __restrict__ dst,
-                                                   int ldd) {
-  const int64_t n8 = (int64_t)R * (ldd / 8);
+                                                   int ldd, int Rpad) {
+  const int64_t n8 = (int64_t)Rpad * (ldd / 8);  // rows R .. Rpad-1 of the copy are zero
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / (ldd / 8)), c = (int)(i % (ldd / 8)) * 8;
     const float* s = src + (int64_t)r * lds_ + c;
     bf16x8 v;
-    if (c + 8 <= C && ((lds_ & 3) == 0) && (((uintptr_t)src & 15) == 0)) {
+    if (r >= R) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.f;
+    } else if (c + 8 <= C && ((lds_ & 3) == 0) && (((uintptr_t)src & 15) == 0)) {
       const float4 a = *reinterpret_cast<const float4*>(s), b = *reinterpret_cast<const float4*>(s + 4);
       v[0] = (__bf16)a.x; v[1] = (__bf16)a.y; v[2] = (__bf16)a.z; v[3] = (__bf16)a.w;
       v[4] = (__bf16)b.x; v[5] = (__bf16)b.y; v[6] = (__bf16)b.z; v[7] = (__bf16)b.w;
@@ -1304,18 +1393,27 @@ extern "C" int sk_gemm_bf16_splitk(const float* A, const float* B, float* C, con
                      sbias, splitk, ws, 0, stream);
 }
 
-// ---------------------------------------------------------------- bf16 operands in memory (NT form)
+// ---------------------------------------------------------------- bf16 operands in memory
 extern "C" int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda,
                                int ldb, int ldc, int accumulate, int act, int batch, int64_t sA, int64_t sB, int64_t sC,
                                int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
-  SK_CHECK_ARG(A && B && C, "sk_gemm_bf16_nt: null pointer");
-  SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm_bf16_nt: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
-  SK_CHECK_ARG(K % bf2::BK == 0, "sk_gemm_bf16_nt: K = %d must be a multiple of %d (pad the bf16 copies with zero columns)", K, bf2::BK);
-  SK_CHECK_ARG(lda >= K && ldb >= K && ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0,
-               "sk_gemm_bf16_nt: leading dimensions / batch strides must cover K and be multiples of 8 elements");
-  SK_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sk_gemm_bf16_nt: operands must be 16-byte aligned");
-  SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm_bf16_nt: bad splitk %d / missing workspace", splitk);
-  SK_CHECK_ARG(act == 0 || act == 1, "sk_gemm_bf16_nt: unknown activation %d", act);
+  return sk_gemm_bf16_mm(A, B, C, bias, M, N, K, lda, ldb, ldc, 0, 0, accumulate, act, batch, sA, sB, sC, sbias, splitk, ws,
+                         stream);
+}
+
+extern "C" int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda,
+                               int ldb, int ldc, int a_kmajor, int b_kmajor, int accumulate, int act, int batch, int64_t sA,
+                               int64_t sB, int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream) {
+  SK_CHECK_ARG(A && B && C, "sk_gemm_bf16_mm: null pointer");
+  SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm_bf16_mm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  SK_CHECK_ARG(K % bf2::BK == 0, "sk_gemm_bf16_mm: K = %d must be a multiple of %d (pad the bf16 copies with zeros)", K, bf2::BK);
+  SK_CHECK_ARG(ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && sA % 8 == 0 && sB % 8 == 0,
+               "sk_gemm_bf16_mm: leading dimensions / batch strides must be multiples of 8 elements");
+  SK_CHECK_ARG(lda >= (a_kmajor ? (M + 7) / 8 * 8 : K) && ldb >= (b_kmajor ? (N + 7) / 8 * 8 : K),
+               "sk_gemm_bf16_mm: leading dimension too small (K-major operands: the padded width of a k row)");
+  SK_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "sk_gemm_bf16_mm: operands must be 16-byte aligned");
+  SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm_bf16_mm: bad splitk %d / missing workspace", splitk);
+  SK_CHECK_ARG(act == 0 || act == 1, "sk_gemm_bf16_mm: unknown activation %d", act);
   bf2::Args g;
   g.A = (const __bf16*)A; g.B = (const __bf16*)B; g.C = C; g.bias = bias;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -1331,13 +1429,22 @@ extern "C" int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const flo
   const int bn = wide ? 256 : 128;
   g.tilesN = (int)sk_cdiv(N, bn);
   const int64_t tiles = sk_cdiv(M, bf2::BM) * g.tilesN;
-  SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm_bf16_nt: too many tiles");
+  SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm_bf16_mm: too many tiles");
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
-  if (wide)
-    hipLaunchKernelGGL((bf2::gemm_bf16_nt_kernel<256>), grid, dim3(bf2::NT), 0, st, g);
-  else
-    hipLaunchKernelGGL((bf2::gemm_bf16_nt_kernel<128>), grid, dim3(bf2::NT), 0, st, g);
+#define SK_BF2_LAUNCH(BNV, AK, BKV) hipLaunchKernelGGL((bf2::gemm_bf16_nt_kernel<BNV, AK, BKV>), grid, dim3(bf2::NT), 0, st, g)
+  if (wide) {
+    if (!a_kmajor && !b_kmajor) SK_BF2_LAUNCH(256, false, false);
+    else if (!a_kmajor) SK_BF2_LAUNCH(256, false, true);
+    else if (!b_kmajor) SK_BF2_LAUNCH(256, true, false);
+    else SK_BF2_LAUNCH(256, true, true);
+  } else {
+    if (!a_kmajor && !b_kmajor) SK_BF2_LAUNCH(128, false, false);
+    else if (!a_kmajor) SK_BF2_LAUNCH(128, false, true);
+    else if (!b_kmajor) SK_BF2_LAUNCH(128, true, false);
+    else SK_BF2_LAUNCH(128, true, true);
+  }
+#undef SK_BF2_LAUNCH
   SK_CHECK_LAUNCH("sk_gemm_bf16_nt");
   if (splitk > 1) {
     GemmArgs r;
@@ -1355,11 +1462,17 @@ extern "C" int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const flo
 }
 
 extern "C" int sk_cast_bf16(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream) {
-  SK_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C && ld_dst % 8 == 0 && ((uintptr_t)dst % 16) == 0,
+  return sk_cast_bf16_rows(src, R, C, ld_src, dst, ld_dst, R, stream);
+}
+
+extern "C" int sk_cast_bf16_rows(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, int R_pad,
+                                 sk_stream_t stream) {
+  SK_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C && ld_dst % 8 == 0 && ((uintptr_t)dst % 16) == 0 &&
+                   R_pad >= R,
                "sk_cast_bf16: bad arguments");
-  const int64_t n8 = (int64_t)R * (ld_dst / 8);
+  const int64_t n8 = (int64_t)R_pad * (ld_dst / 8);
   const unsigned nb = (unsigned)(sk_cdiv(n8, 256) > 4096 ? 4096 : sk_cdiv(n8, 256));
-  hipLaunchKernelGGL(bf2::cast_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, R, C, ld_src, (__bf16*)dst, ld_dst);
+  hipLaunchKernelGGL(bf2::cast_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, R, C, ld_src, (__bf16*)dst, ld_dst, R_pad);
   SK_CHECK_LAUNCH("sk_cast_bf16");
   return SK_OK;
 }

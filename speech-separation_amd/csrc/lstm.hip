@@ -60,6 +60,12 @@ constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 #ifndef SK_BF_DEPTH
 #define SK_BF_DEPTH 2
 #endif
+#ifndef SK_F32_NSB
+#define SK_F32_NSB 8
+#endif
+#ifndef SK_F32_DEPTH
+#define SK_F32_DEPTH 3
+#endif
 #ifndef SK_POLL_SLEEP
 #define SK_POLL_SLEEP 1
 #endif
@@ -224,6 +230,24 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // One 1 KB piece (one MFMA chunk's B-operand image) global -> LDS, write-through-coherent (sc1).
 __device__ __forceinline__ void dma_piece(const float* gsrc_piece, float* lds_piece, int lane) {
   __builtin_amdgcn_global_load_lds(SK_GLOBAL_PTR(gsrc_piece + lane * 4), SK_LDS_PTR(lds_piece), 16, 0, 16 /* sc1 */);
+}
+// The same as inline assembly, for the backward kernel's ring of sub-blocks (r03): behind an LDS-DMA BUILTIN hipcc puts
+// an `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot prove disjoint from the DMA's destination, which turned
+// every third counted wait of the ring (`vmcnt(8)`: this sub-block has landed, two more may fly) into a wait for ALL
+// sub-blocks in flight (`s_waitcnt vmcnt(8)` / `s_waitcnt vmcnt(0)` pairs in the ISA).  The kernel orders DMA and reads
+// itself (counted vmcnt waits).  Scalar base (a kernel argument) + one VGPR of byte offsets: the builtin's 64-bit VGPR
+// addresses also cost the kernel 20 registers (192 -> 172).  Measured, one call: 7.56 -> 7.20 us per step fp32, 4.38 ->
+// 4.14 bf16, 37.5 -> 36.9 ms per training step.  The forward kernels wait for all their pieces anyway and keep the
+// builtin (the extra scalar moves cost the bf16 forward chain 0.3 us per step).
+__device__ __forceinline__ void dma_piece_s(const float* base, unsigned byte_off, unsigned lds_addr, int lane) {
+#ifndef SK_DMA_BUILTIN
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" ::"v"(byte_off + (unsigned)lane * 16u), "s"(base),
+               "s"(lds_addr)
+               : "memory");
+#else
+  __builtin_amdgcn_global_load_lds(SK_GLOBAL_PTR(reinterpret_cast<const char*>(base) + byte_off + lane * 16),
+                                   (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr, 16, 0, 16 /* sc1 */);
+#endif
 }
 
 // Diagnostic build only (-DSK_LSTM_STAMPS, libsepkern_stamps.so): wave 0 of workgroup (0,0,0) accumulates the
@@ -921,20 +945,20 @@ __global__ __launch_bounds__(768) void lstm_fwd2_kernel(FwdArgs a) {
 template <int KS, bool BF>
 struct BwdCfg {
   static constexpr int NQ = BF ? KS / 4 : KS / 2;         // 1 KB chunks per wave (16 k' each in fp32, 32 in bf16)
-  static constexpr int NSB = BF ? SK_BF_NSB : 8;          // sub-blocks per step (ring = 2 sub-blocks per wave; fp32: 8 keeps
+  static constexpr int NSB = BF ? SK_BF_NSB : SK_F32_NSB;          // sub-blocks per step (ring = 2 sub-blocks per wave; fp32: 8 keeps
                                                           // the workgroup at 91 KB of LDS, bf16 measured faster with 4)
   static constexpr int SB = (NQ + NSB - 1) / NSB;         // chunks per sub-block (last may be short)
-  static constexpr int DEPTH = BF ? SK_BF_DEPTH : 3;      // sub-blocks in flight per wave (ring slots)
+  static constexpr int DEPTH = BF ? SK_BF_DEPTH : SK_F32_DEPTH;      // sub-blocks in flight per wave (ring slots)
   static constexpr int cnt(int sb) { return (sb * SB >= NQ) ? 0 : ((sb + 1) * SB <= NQ ? SB : NQ - sb * SB); }
 };
 
 template <int KS, bool BF, int SBI>
-__device__ __forceinline__ void bwd_issue(const float* xsrc, float* ring, int w, int lane) {
+__device__ __forceinline__ void bwd_issue(const float* xbase, unsigned xoff, unsigned ring_lds, int w, int lane) {
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
-  float* dst = ring + (SBI % C::DEPTH) * C::SB * 256;
+  const unsigned dst = ring_lds + (SBI % C::DEPTH) * C::SB * 1024;
 #pragma unroll
-  for (int j = 0; j < n; ++j) dma_piece(xsrc + (size_t)(w * C::NQ + SBI * C::SB + j) * 256, dst + j * 256, lane);
+  for (int j = 0; j < n; ++j) dma_piece_s(xbase, xoff + (unsigned)(w * C::NQ + SBI * C::SB + j) * 1024u, dst + j * 1024, lane);
 }
 
 // Register slice of W_hh^T of one wave: fp32 4 floats per chunk, bf16 8 bf16 (4 VGPRs) per chunk.
@@ -969,40 +993,53 @@ __device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* 
   }
 }
 
+template <int KS, bool BF>
+constexpr int bwd_younger(int I) {  // DMAs of the DEPTH-1 sub-blocks after sub-block I
+  int n = 0;
+  for (int d = 1; d < BwdCfg<KS, BF>::DEPTH; ++d) n += BwdCfg<KS, BF>::cnt(I + d);
+  return n;
+}
+template <int KS, bool BF, int I>
+__device__ __forceinline__ void bwd_prologue(const float* xbase, unsigned xoff, unsigned ring_lds, int w, int lane) {
+  if constexpr (I < BwdCfg<KS, BF>::DEPTH && I < BwdCfg<KS, BF>::NSB) {
+    bwd_issue<KS, BF, I>(xbase, xoff, ring_lds, w, lane);
+    bwd_prologue<KS, BF, I + 1>(xbase, xoff, ring_lds, w, lane);
+  }
+}
+
 // Sub-block I of the DEPTH-deep ring: wait until it has landed (only the DMAs of the next DEPTH-1 sub-blocks may
 // still be in flight), multiply, and refill its slot with sub-block I+DEPTH.
 template <int KS, bool BF, int I>
-__device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* xsrc, float* ring, int w, int lane,
-                                         f32x4& acc0, f32x4& acc1) {
+__device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
+                                         unsigned ring_lds, int w, int lane, f32x4& acc0, f32x4& acc1) {
   using C = BwdCfg<KS, BF>;
   if constexpr (I < C::NSB) {
-    constexpr int younger = C::cnt(I + 1) + (C::DEPTH > 2 ? C::cnt(I + 2) : 0) + (C::DEPTH > 3 ? C::cnt(I + 3) : 0);
+    constexpr int younger = bwd_younger<KS, BF>(I);
     wait_vmcnt<younger>();
     bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
     if constexpr (I + C::DEPTH < C::NSB) {
       if constexpr (C::cnt(I + C::DEPTH) > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this ring slot returned before it is refilled
         __builtin_amdgcn_sched_barrier(0);
-        bwd_issue<KS, BF, I + C::DEPTH>(xsrc, ring, w, lane);
+        bwd_issue<KS, BF, I + C::DEPTH>(xbase, xoff, ring_lds, w, lane);
       }
     }
-    bwd_ring<KS, BF, I + 1>(wreg, xsrc, ring, w, lane, acc0, acc1);
+    bwd_ring<KS, BF, I + 1>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1);
   }
 }
 
 // Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
 template <int KS, bool BF>
-__device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xsrc, float* ring,
+__device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
                                             float (*red)[16][17], int w, int lane) {
+  // xbase: the exchange buffer (kernel argument: scalar), xoff: byte offset of this stream's block of the step (uniform)
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   // The counted waits below assume the DMAs are the YOUNGEST vector-memory operations of this wave:
   // nothing may be scheduled into this region (the cell loads of the step were issued before it).
   __builtin_amdgcn_sched_barrier(0);
-  bwd_issue<KS, BF, 0>(xsrc, ring, w, lane);
-  bwd_issue<KS, BF, 1>(xsrc, ring, w, lane);
-  if constexpr (BwdCfg<KS, BF>::DEPTH > 2) bwd_issue<KS, BF, 2>(xsrc, ring, w, lane);
-  if constexpr (BwdCfg<KS, BF>::DEPTH > 3) bwd_issue<KS, BF, 3>(xsrc, ring, w, lane);
-  bwd_ring<KS, BF, 0>(wreg, xsrc, ring, w, lane, acc0, acc1);
+  bwd_prologue<KS, BF, 0>(xbase, xoff, ring_lds, w, lane);
+  bwd_ring<KS, BF, 0>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1);
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll
@@ -1032,7 +1069,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
 
   int ug, by, dir;
   decode_block((int)blockIdx.x, KS, a.nby, a.map, ug, by, dir);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: everything derived from it stays scalar
   const int T = a.T, B = a.B, H = a.H, NBG = a.NBG, G = a.G;
   float* const ring = &ring_all[w][0];
 
@@ -1138,7 +1176,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
           break;
         }
         SK_STAMP(0);
-        dh_rec = bwd_matmul<KS, BF>(wreg, ((s - 1) & 1) ? xb1 : xb0, ring, red, w, lane);
+        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, (unsigned)(((size_t)((((s - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4), ring, red, w, lane);
         SK_STAMP(2);
       }
       // 3. cell backward (owner waves)
@@ -1227,7 +1265,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       }
       __syncthreads();
       if (s_abort) return;
-      float dh_rec = bwd_matmul<KS, BF>(wreg, ((T - 1) & 1) ? xb1 : xb0, ring, red, w, lane);
+      float dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, (unsigned)(((size_t)((((T - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4), ring, red, w, lane);
       if (cellok) {
         dh_rec += st_carry[gi][oi];
         if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;

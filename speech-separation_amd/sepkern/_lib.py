@@ -30,7 +30,9 @@ PROTOTYPES = {
     "sk_gemm_f32_splitk": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _i, _p]),
     "sk_gemm_bf16_splitk": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "sk_gemm_bf16_nt": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
+    "sk_gemm_bf16_mm": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "sk_cast_bf16": (_i, [_p, _i, _i, _i, _p, _i, _p]),
+    "sk_cast_bf16_rows": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
     "sk_cast_bf16_t": (_i, [_p, _i, _i, _i, _p, _i, _p]),
     "sk_lstm_workspace_bytes": (_sz, [_i, _i, _i]),
     "sk_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

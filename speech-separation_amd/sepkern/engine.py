@@ -91,6 +91,11 @@ class Engine:
         # needs it so that every product is the one NT form of sk_gemm_bf16_nt); SEPKERN_BF16_NT=0 keeps the r01 kernel
         # that reads fp32 operands and rounds them on the way into LDS (same arithmetic, half the speed)
         self.nt = self.bf16 and os.environ.get("SEPKERN_BF16_NT", "1") == "1"
+        # ... and (r03) only ROW-MAJOR copies: a factor whose rows are the contraction index (both factors of a weight
+        # gradient, the weight matrix of a data gradient) enters the product K-major (sk_gemm_bf16_mm: the tile is DMA'd as
+        # it lies and transposed by ds_read_b64_tr_b16 on the way into the matrix cores), so the 12 transposed copies per
+        # step (sk_cast_bf16_t, 0.94 ms) are never made.  SEPKERN_BF16_KMAJOR=0 keeps the r02 path with transposed copies.
+        self.kmajor = self.nt and hidden % 8 == 0 and os.environ.get("SEPKERN_BF16_KMAJOR", "1") == "1"
         # data-parallel runs only: BatchNorm over the GLOBAL batch instead of per rank (sepkern/dist.py)
         self.sync_bn = bool(sync_bn) or os.environ.get("SEPKERN_SYNC_BN", "0") == "1"
         if hidden % 4 != 0 or hidden > 1024:
@@ -179,7 +184,10 @@ class Engine:
         cur = torch.cuda.current_stream()
         ent = cache.get(key)
         if ent is None:
-            c = ops.cast_bf16(t2d) if kind == "row" else ops.cast_bf16_t(t2d)
+            if kind == "rowk":     # row-major copy that also serves as a K-major factor: whole K steps of zero rows behind it
+                c = ops.cast_bf16(t2d, rows=ops.pad_to(t2d.shape[0], 64) + 64)
+            else:
+                c = ops.cast_bf16(t2d) if kind == "row" else ops.cast_bf16_t(t2d)
             ev = torch.cuda.Event()
             ev.record(cur)
             # the entry holds the fp32 SOURCE too: its address cannot be recycled for another tensor of the same shape
@@ -198,7 +206,8 @@ class Engine:
             ops.gemm(inp2d, w, out2d, R, N, K, inp2d.stride(0), K, N, transB=True, bias=bias, act=act, bf16=self.bf16,
                      variant=self.var_main)
             return
-        a, b = self._copy(cache, "row", inp2d), self._copy(cache, "row", w)
+        kind = "rowk" if self.kmajor else "row"            # the same copies serve the backward products K-major
+        a, b = self._copy(cache, kind, inp2d), self._copy(cache, kind, w)
         ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act)
 
     def _dgrad(self, cache, dout2d, w, out2d, ws_tag):
@@ -210,6 +219,12 @@ class Engine:
             # measured 125.5 TFLOP/s against 119-120 for two K slices of 128 x 128 tiles
             sk = 1 if (self.dgrad_unsplit and not self.bf16 and R >= 4096 and K >= 1024 and N % 16 == 0) else 0
             ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=sk, ws_tag=ws_tag, bf16=self.bf16, variant=self.var_main)
+            return
+        if self.kmajor:
+            # out = dout w: w (N, K) is the K-major B of the product as it lies (contraction over its rows, padded with
+            # zero rows up to dout's zero-padded width)
+            a, b = self._copy(cache, "rowk", dout2d), self._copy(cache, "rowk", w)
+            ops.gemm_bf16_mm(a, b, out2d, R, K, a.shape[1], a.shape[1], b.shape[1], K, b_kmajor=True, splitk=0, ws_tag=ws_tag)
             return
         a, bt = self._copy(cache, "row", dout2d), self._copy(cache, "t", w)      # w^T: (K, N padded)
         ops.gemm_bf16_nt(a, bt, out2d, R, K, a.shape[1], a.shape[1], bt.shape[1], K, splitk=0, ws_tag=ws_tag)
@@ -224,6 +239,12 @@ class Engine:
             ops.gemm(dout2d, inp2d, gw, N, K, R, N, inp2d.stride(0), K, transA=True, accumulate=acc, splitk=0,
                      ws_tag=ws_tag, bf16=self.bf16, variant=self.var_side if beside else self.var_main)
             return
+        if self.kmajor:
+            # gw = dout^T inp: both factors K-major as they lie (their rows are the contraction index)
+            a, b = self._copy(cache, "rowk", dout2d), self._copy(cache, "rowk", inp2d)
+            ops.gemm_bf16_mm(a, b, gw, N, K, ops.pad_to(R, 64), a.shape[1], b.shape[1], K, a_kmajor=True, b_kmajor=True,
+                             accumulate=acc, splitk=0, ws_tag=ws_tag)
+            return
         at, bt = self._copy(cache, "t", dout2d), self._copy(cache, "t", inp2d)    # (N, R padded), (K, R padded)
         ops.gemm_bf16_nt(at, bt, gw, N, K, ops.pad_to(R, 64), at.shape[1], bt.shape[1], K, accumulate=acc, splitk=0,
                          ws_tag=ws_tag)
@@ -235,6 +256,18 @@ class Engine:
         if not (self.nt and T > 1 and B % 8 == 0):
             ops.lstm_whh_grad(dgx2d, y2d, h0, dg_first, gw, T, B, H, accumulate=acc, bf16=self.bf16, ws_tag=ws_tag,
                               variant=self.var_side if beside else self.var_main)
+            return
+        if self.kmajor:
+            # the time shift is an offset of B ROWS into one of the K-major factors: direction 0 pairs dG rows from t = 1
+            # with y rows from t = 0, direction 1 dG rows from t = 0 with y rows from t = 1; the copies end in >= 64 zero
+            # rows, which absorb the rounding of K = (T-1) B up to 64
+            a, b = self._copy(cache, "rowk", dgx2d), self._copy(cache, "rowk", y2d)   # (R+, 8H), (R+, 2H)
+            lda, ldb = a.shape[1], b.shape[1]
+            ops.gemm_bf16_mm(a.view(-1)[B * lda:], b, gw, 4 * H, H, ops.pad_to((T - 1) * B, 64), lda, ldb, H, a_kmajor=True,
+                             b_kmajor=True, accumulate=acc, batch=2, sA=4 * H - B * lda, sB=B * ldb + H, sC=4 * H * H, splitk=0,
+                             ws_tag=ws_tag)
+            ops.gemm(dg_first, h0, gw, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=True, batch=2, sA=B * 4 * H, sB=B * H,
+                     sC=4 * H * H, ws_tag=ws_tag, bf16=True)
             return
         at, bt = self._copy(cache, "t", dgx2d), self._copy(cache, "t", y2d)       # (8H, ld), (2H, ld)
         ld = at.shape[1]
@@ -379,7 +412,10 @@ class Engine:
         ctx = None
         if save:
             ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, fold=fold, mask=mask, lens=lens, h0=h0,
-                       c0=c0, T=T, B=B, training=training)
+                       c0=c0, T=T, B=B, training=training,
+                       # bf16, K-major products: the backward pass multiplies the SAME row-major copies of the weights and
+                       # of every layer input (none of them is written in between), so they are made once per step
+                       cache=cache if self.kmajor else None)
         return mask, hn, cn, ctx
 
     # ------------------------------------------------------------------ backward
@@ -412,7 +448,7 @@ class Engine:
         keep = []                                        # tensors used on the side stream stay alive until the join
         dz = torch.empty_like(dmask)
         ops.sigmoid_bwd(dmask, ctx["mask"], dz)
-        cache = {}                                       # bf16 operand copies of this pass (see _copy)
+        cache = ctx.get("cache") or {}                   # bf16 operand copies (see _copy); with K-major products the forward's
         dz2d = dz.view(R, O)
         dxbn = torch.empty(R, 2 * H, device=dev)
         self._dgrad(cache, dz2d, self.p("lin.weight"), dxbn, "gemm")

@@ -138,15 +138,17 @@ def pad_to(n, m):
     return (n + m - 1) // m * m
 
 
-def cast_bf16(x2d, ld=None, out=None):
+def cast_bf16(x2d, ld=None, out=None, rows=None):
     """bf16 copy of an fp32 (R, C) matrix (row stride x2d.stride(0)), leading dimension ld >= C (default: C rounded
-    up to 64), extra columns zero.  Returns the (R, ld) bfloat16 tensor."""
+    up to 64), extra columns zero; rows >= R: that many rows are written, those past R zero (a copy that also serves as
+    a K-major factor, gemm_bf16_mm).  Returns the (rows or R, ld) bfloat16 tensor."""
     _chk(x2d)
     R, Cc = x2d.shape
     ld = pad_to(Cc, 64) if ld is None else ld
+    rows = R if rows is None else rows
     if out is None:
-        out = torch.empty(R, ld, dtype=torch.bfloat16, device=x2d.device)
-    _lib.call("sk_cast_bf16", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(out), ld, _stream())
+        out = torch.empty(rows, ld, dtype=torch.bfloat16, device=x2d.device)
+    _lib.call("sk_cast_bf16_rows", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(out), ld, rows, _stream())
     return out
 
 
@@ -177,6 +179,25 @@ def gemm_bf16_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, accumulate=False
     with _timed("gemm_bf16_nt_kernel", 2.0 * M * N * K * batch):
         _lib.call("sk_gemm_bf16_nt", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(accumulate),
                   int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws), _stream())
+
+
+def gemm_bf16_mm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, accumulate=False, act=0, batch=1,
+                 sA=0, sB=0, sC=0, sbias=0, splitk=1, ws_tag="gemm"):
+    """Cout[M,N] = act(opA opB + bias (+ Cout)) on bfloat16 operands in memory, either of them optionally K-MAJOR
+    (a_kmajor: A stored [K][M] with lda elements between k rows; b_kmajor: B stored [K][N]) -- sk_gemm_bf16_mm.  Row-major
+    operands: K-contiguous as in gemm_bf16_nt.  K % 64 == 0."""
+    _chk(A, torch.bfloat16)
+    _chk(B, torch.bfloat16)
+    _chk(Cout)
+    _chk(bias)
+    if splitk == 0:
+        splitk = pick_splitk_bf16(M, N, K, batch)
+    ws = None
+    if splitk > 1:
+        ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
+    with _timed("gemm_bf16_nt_kernel", 2.0 * M * N * K * batch):
+        _lib.call("sk_gemm_bf16_mm", _ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(a_kmajor), int(b_kmajor),
+                  int(accumulate), int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws), _stream())
 
 
 def pick_splitk_bf16(M, N, K, batch=1):

@@ -51,9 +51,48 @@ def bench_nt():
               (name, M, N, K, batch, used, ms, 2.0 * M * N * K * batch / ms / 1e9), flush=True)
 
 
+def bench_km():
+    """sk_gemm_bf16_mm: the backward products of the bf16 configuration on the row-major copies (K-major factors) next to
+    the same products in NT form on transposed copies."""
+    S3 = 771
+    shapes = [("dgrad L1/2", R, 2 * H, 8 * H, 1, 1, False, True), ("dgrad lin K=771->832", R, 2 * H, 832, 1, 1, False, True),
+              ("wgrad Wih", 8 * H, 2 * H, R, 1, 0, True, True), ("wgrad Whh batch2", 4 * H, H, R, 2, 0, True, True),
+              ("wgrad Wih0 N=257->320", 8 * H, 320, R, 1, 0, True, True), ("wgrad lin M=771->832", 832, 2 * H, R, 1, 0, True, True),
+              ("square 4096 TN", 4096, 4096, 4096, 1, 1, True, True), ("square 8192 TN", 8192, 8192, 8192, 1, 1, True, True),
+              ("square 8192 NN", 8192, 8192, 8192, 1, 1, False, True)]
+    if "--only" in sys.argv:
+        shapes = [shapes[int(sys.argv[sys.argv.index("--only") + 1])]]
+    for name, M, N, K, batch, sk, akm, bkm in shapes:
+        used = ops.pick_splitk_bf16(M, N, K, batch) if sk == 0 else sk
+        res = []
+        for form in ("km", "nt"):
+            ak, bk = (akm, bkm) if form == "km" else (False, False)
+            A = torch.randn((batch * K, M) if ak else (batch * M, K), device="cuda").bfloat16()
+            B = torch.randn((batch * K, N) if bk else (batch * N, K), device="cuda").bfloat16()
+            C = torch.empty(batch, M, N, device="cuda")
+            kw = dict(a_kmajor=ak, b_kmajor=bk, batch=batch, sA=M * K, sB=N * K, sC=M * N, splitk=used)
+            lda, ldb = (M if ak else K), (N if bk else K)
+            for _ in range(2):
+                ops.gemm_bf16_mm(A, B, C, M, N, K, lda, ldb, N, **kw)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10
+            e0.record()
+            for _ in range(n):
+                ops.gemm_bf16_mm(A, B, C, M, N, K, lda, ldb, N, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) / n)
+        print("%-24s M=%6d N=%5d K=%6d b=%d splitk=%2d  K-major %7.3f ms %7.1f TFLOP/s | NT %7.3f ms %7.1f TFLOP/s" %
+              (name, M, N, K, batch, used, res[0], 2.0 * M * N * K * batch / res[0] / 1e9, res[1], 2.0 * M * N * K * batch / res[1] / 1e9),
+              flush=True)
+
+
 def main():
     if "--nt" in sys.argv:
         return bench_nt()
+    if "--km" in sys.argv:
+        return bench_km()
     bf16 = "--bf16" in sys.argv
     variant = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 0   # sk_gemm_f32_splitk's variant
     shapes = SHAPES

@@ -646,6 +646,41 @@ def test_gemm_bf16_nt_splitk_batch_accumulate_and_transposed_copy(ops):
     assert float((C.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
+@pytest.mark.parametrize("akm,bkm", [(False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K,batch,splitk", [(512, 512, 256, 1, 1), (771, 1792, 1280, 1, 0), (7168, 257, 1024, 1, 4),
+                                                (300, 130, 192, 2, 1), (3584, 896, 640, 2, 2), (1000, 1800, 128, 1, 1)])
+def test_gemm_bf16_k_major_operands_equal_fp64_product_of_rounded_operands(ops, M, N, K, batch, splitk, akm, bkm):
+    """sk_gemm_bf16_mm: operands that are K-major in memory (activation / gradient matrices as the transposed factors of
+    a weight gradient, a weight matrix in a data gradient) are DMA'd as they lie and transposed by ds_read_b64_tr_b16 on
+    the way into the matrix cores: same product as the NT form on transposed copies.  Ragged M / N against padded leading
+    dimensions (771 -> 776, 257 -> 264), batches, accumulation, split-K; the padding columns hold NaN (never stored)."""
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    pad8 = lambda n: (n + 7) // 8 * 8
+    A = torch.randn(batch, M, K, generator=g).bfloat16()
+    Bm = torch.randn(batch, N, K, generator=g).bfloat16()
+    ref = torch.einsum("zmk,znk->zmn", A.double(), Bm.double())
+    if akm:
+        lda = pad8(M) + 8
+        Ad = torch.full((batch, K, lda), float("nan")).bfloat16()
+        Ad[:, :, :M] = A.transpose(1, 2)
+        sA = K * lda
+    else:
+        lda, Ad, sA = K, A, M * K
+    if bkm:
+        ldb = pad8(N)
+        Bd = torch.full((batch, K, ldb), float("nan")).bfloat16()
+        Bd[:, :, :N] = Bm.transpose(1, 2)
+        sB = K * ldb
+    else:
+        ldb, Bd, sB = K, Bm, N * K
+    C0 = torch.randn(batch, M, N, generator=g)
+    C = C0.clone().cuda()
+    ops.gemm_bf16_mm(Ad.contiguous().cuda(), Bd.contiguous().cuda(), C, M, N, K, lda, ldb, N, a_kmajor=akm, b_kmajor=bkm,
+                     accumulate=True, batch=batch, sA=sA, sB=sB, sC=M * N, splitk=splitk)
+    err = float((C.cpu().double() - (ref + C0.double())).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+
+
 @pytest.mark.parametrize("T,B,H,lens", [(9, 32, 896, [9] * 20 + [7] * 8 + [2] * 4), (7, 40, 600, [7] * 17 + [5] * 20 + [1] * 3),
                                         (6, 16, 64, [6] * 10 + [3] * 6)])
 def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H, lens):
