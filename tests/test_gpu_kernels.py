@@ -175,13 +175,15 @@ def test_gemm_splitk_is_deterministic_and_matches_fp64(ops, M, N, K, S):
     assert torch.equal(outs[0], outs[1])                     # fixed-order slab reduction: bitwise reproducible
 
 
-@pytest.mark.parametrize("variant", [3, 4])
+@pytest.mark.parametrize("variant", [3, 4, 5])
 @pytest.mark.parametrize("M,N,K,tA,tB,S", [(300, 260, 512, False, True, 1), (700, 260, 528, False, False, 1), (516, 132, 1024, True, False, 1),
                                             (1000, 772, 1792, False, True, 1), (517, 1792, 3584, False, False, 2),
-                                            (1028, 132, 4096, True, False, 4), (256, 128, 16, False, True, 1)])
+                                            (1028, 132, 4096, True, False, 4), (256, 128, 16, False, True, 1),
+                                            (1030, 1796, 528, False, False, 1), (772, 516, 1040, True, False, 1), (256, 256, 32, False, True, 1)])
 def test_gemm_dma_kernels_forced(ops, variant, M, N, K, tA, tB, S):
-    """sk_gemm_f32_splitk variant 3 (the LDS-DMA kernel wherever it applies; two LDS stages for N/T, three for N/N and T/N):
-    ragged edges in M and N, bias, accumulate, in-kernel split-K; against fp64 and run-to-run identical."""
+    """sk_gemm_f32_splitk variant 3 (the LDS-DMA kernel wherever it applies; two LDS stages for N/T, three for N/N and T/N),
+    4 (256 x 128 block tiles) and 5 (256 x 256 block tiles, unsplit products of at least one tile; r03): ragged edges in M
+    and N, bias, accumulate, in-kernel split-K; against fp64 and run-to-run identical."""
     g = torch.Generator().manual_seed(M + 3 * N + variant)
     A = torch.randn((K, M) if tA else (M, K), generator=g)
     B = torch.randn((N, K) if tB else (K, N), generator=g)
