@@ -1298,26 +1298,31 @@ __global__ __launch_bounds__(256) void first_dg_kernel(const float* __restrict__
 //   back == 0: dst[4u + g] = src[g H + u]            (weights and biases -> the order gx / gates / dgx are kept in)
 //   back == 1: dst[g H + u] (+)= src[4u + g]         (weight gradients -> the order of the parameter tensors)
 __global__ __launch_bounds__(256) void gate_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int H,
-                                                        int C, int ld_src, int ld_dst, int back, int accumulate) {
+                                                        int C, int ld_src, int ld_dst, int back, int accumulate, int nrows) {
   const int rows4 = 4 * H;
-  const int blk = blockIdx.x / rows4, r = blockIdx.x % rows4;        // r: interleaved index 4u + g
-  const size_t ri = (size_t)blk * rows4 + r, rg = (size_t)blk * rows4 + (size_t)(r & 3) * H + (r >> 2);
-  const float* s = src + (back ? ri : rg) * ld_src;
-  float* d = dst + (back ? rg : ri) * ld_dst;
-  if (((C | ld_src | ld_dst) & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
-    for (int c = threadIdx.x * 4; c < C; c += 1024) {
-      float4 v = *reinterpret_cast<const float4*>(s + c);
-      if (accumulate) {
-        const float4 o = *reinterpret_cast<const float4*>(d + c);
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+  const bool vec = ((C | ld_src | ld_dst) & 3) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+  // a block walks rows blockIdx.x, + gridDim.x, ...: a few hundred fat blocks instead of one per row (r03: the weight-
+  // gradient reorders run on the side stream beside a persistent grid, where 7168 one-row blocks took up to 1.3 ms)
+  for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int blk = row / rows4, r = row % rows4;  // r: interleaved index 4u + g
+    const size_t ri = (size_t)blk * rows4 + r, rg = (size_t)blk * rows4 + (size_t)(r & 3) * H + (r >> 2);
+    const float* s = src + (back ? ri : rg) * ld_src;
+    float* d = dst + (back ? rg : ri) * ld_dst;
+    if (vec) {
+      for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        float4 v = *reinterpret_cast<const float4*>(s + c);
+        if (accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(d + c);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(d + c) = v;
       }
-      *reinterpret_cast<float4*>(d + c) = v;
+    } else {
+      for (int c = threadIdx.x; c < C; c += 256) d[c] = accumulate ? d[c] + s[c] : s[c];
     }
-  } else {
-    for (int c = threadIdx.x; c < C; c += 256) d[c] = accumulate ? d[c] + s[c] : s[c];
+    if (!accumulate)  // padding columns of a destination with a wider leading dimension read as zero
+      for (int c = C + threadIdx.x; c < ld_dst; c += 256) d[c] = 0.f;
   }
-  if (!accumulate)  // padding columns of a destination with a wider leading dimension read as zero
-    for (int c = C + threadIdx.x; c < ld_dst; c += 256) d[c] = 0.f;
 }
 
 template <int KS, bool BF>
@@ -1572,8 +1577,9 @@ extern "C" int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C
                             int accumulate, sk_stream_t stream) {
   SK_CHECK_ARG(src && dst && src != dst && nblk > 0 && H > 0 && C > 0 && ld_src >= C && ld_dst >= C,
                "sk_gate_rows: bad arguments");
-  hipLaunchKernelGGL(gate_rows_kernel, dim3((unsigned)(nblk * 4 * H)), dim3(256), 0, (hipStream_t)stream, src, dst, H, C,
-                     ld_src, ld_dst, back, accumulate);
+  const int nrows = nblk * 4 * H;
+  hipLaunchKernelGGL(gate_rows_kernel, dim3((unsigned)(nrows < 512 ? nrows : 512)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     H, C, ld_src, ld_dst, back, accumulate, nrows);
   SK_CHECK_LAUNCH("sk_gate_rows");
   return SK_OK;
 }
