@@ -208,38 +208,40 @@ __global__ __launch_bounds__(256, BINMAJOR ? 2 : 4) void stft_kernel(const void*
     }
     fft256_g16(z, xch[4 * wave + g], tw, j);
 
-    // real-FFT split: X[k] = Xe + W^k Xo, Xe = (Z[k] + conj Z[256-k])/2, Xo = -i (Z[k] - conj Z[256-k])/2,
-    // k = j + 16 k2.  Z[256-k] is register 15-k2 of lane (16-j)%16 of this group (register (16-k2)%16 of lane 0
-    // itself when j == 0).
-    // frame-major output row of this group's frame; lane j writes bins j, j+16, ... at constant offsets
-    float* const orow = (float*)out + (CPLX ? 2 : 1) * (ooff + (int64_t)(t0 + fr) * st) + (CPLX ? 2 : 1) * j;
-    const float z0x = z[0].x, z0y = z[0].y;
+    // real-FFT split: X[k] = Xe + W^k Xo, Xe = (Z[k] + conj Z[256-k])/2, Xo = -i (Z[k] - conj Z[256-k])/2, k = j + 16 k2.
+    // Z[256-k] is register 15-k2 of lane (16-j)%16 of this group (register (16-k2)%16 of lane 0 itself when j == 0).
+    // r03: the bins k and 256-k of a pair are formed by ONE lane from shared terms -- Xe[256-k] = conj Xe[k],
+    // Xo[256-k] = conj Xo[k], W^(256-k) = -conj W^k, so with A = Xe[k], Bt = W^k Xo[k]:  X[k] = A + Bt,  X[256-k] = conj(A - Bt).
+    // Lane j takes k2 = 0..7 (its partner's k2 = 8..15 are the mirrors of lane 16-j's 0..7): 16 shuffles, 8 twiddles and 8
+    // complex products per lane instead of 32 / 16 / 16; lane 0 adds the self-paired bin 128 (k2 = 0 gives bins 0 and 256).
+    // frame-major output row of this group's frame: lane j writes bins j + 16 k2 and 256 - j - 16 k2 at constant offsets
+    constexpr int CW = CPLX ? 2 : 1;
+    float* const orow = (float*)out + CW * (ooff + (int64_t)(t0 + fr) * st) + CW * j;
+    float* const orow2 = (float*)out + CW * (ooff + (int64_t)(t0 + fr) * st) + CW * (256 - j);
+    auto emit = [&](v2f x, int k, float* dstp) {
+      if (BINMAJOR)
+        st2(&ost[fr][k], x);
+      else if (CPLX)
+        *reinterpret_cast<v2f*>(dstp) = x;
+      else
+        *dstp = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
+    };
     if (active) {  // uniform over the 16-lane group, which is all the shuffles below reach
 #pragma unroll
-      for (int k2 = 0; k2 < 16; ++k2) {
+      for (int k2 = 0; k2 < 8; ++k2) {
         v2f zc;
         zc.x = __shfl(z[15 - k2].x, partner, 64);
         zc.y = __shfl(z[15 - k2].y, partner, 64);
         if (j == 0) zc = z[(16 - k2) & 15];
         const v2f zk = z[k2], cz = conj(zc);
         const int k = j + 16 * k2;
-        // X = (Zk + conj Zc)/2 + W^k (-i)(Zk - conj Zc)/2
-        const v2f x = 0.5f * (zk + cz) + cmul(ld2(&tw[k]), 0.5f * mul_mi(zk - cz));
-        if (BINMAJOR)
-          st2(&ost[fr][k], x);
-        else if (CPLX)
-          *reinterpret_cast<v2f*>(orow + 32 * k2) = x;
-        else
-          orow[16 * k2] = __builtin_amdgcn_sqrtf(x.x * x.x + x.y * x.y);
+        const v2f A = 0.5f * (zk + cz), Bt = cmul(ld2(&tw[k]), 0.5f * mul_mi(zk - cz));
+        emit(A + Bt, k, orow + CW * 16 * k2);
+        emit(conj(A - Bt), 256 - k, orow2 - CW * 16 * k2);
       }
-      if (j == 0) {  // k = 256: Re Z[0] - Im Z[0]
-        const v2f x = {z0x - z0y, 0.f};
-        if (BINMAJOR)
-          st2(&ost[fr][256], x);
-        else if (CPLX)
-          *reinterpret_cast<v2f*>(orow + 512) = x;
-        else
-          orow[256] = fabsf(x.x);
+      if (j == 0) {  // bin 128 pairs with itself
+        const v2f zk = z[8], cz = conj(zk);
+        emit(0.5f * (zk + cz) + cmul(ld2(&tw[128]), 0.5f * mul_mi(zk - cz)), 128, orow + CW * 128);
       }
     }
     __syncthreads();  // every wave is done with smp (and ost is complete)
