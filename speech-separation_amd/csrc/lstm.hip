@@ -153,6 +153,7 @@ struct BwdArgs {
   unsigned* sticky;
   int T, B, H, NBG, G, s_begin, s_end, final_mm;
   int map, nby, poll_delay;
+  int tagged;  // fp32: the data is the flag (epoch in the two low mantissa bits of every exchanged dG word)
 };
 
 // Flag replication (opt bit 1): every producer raises its flag in NREP copies with ONE store instruction (NREP lanes,
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
           h = a.h0[((size_t)dir * B + b) * H + unit];
         } else {
           c = a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
-          if (BF)
+          if (BF || (a.opt & 8))
             h = a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
           else
             h = __hip_atomic_load(a.xbuf + ((size_t)(((a.s_begin - 1) & 1) * 2 + dir) * NBG + bg) * xblk + xoff, SK_RLX, SK_AGENT);
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
 
   const int fs = (a.opt & 4) ? FSPREAD : 1;  // option: every flag in a 128-byte line of its own (flag stores do not serialise on a line)
   bool aborted = false;
+  long long t_self = 0;  // tagged hand-off: when this wave was done with the previous step
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? T - 1 - s : s;
     for (int gi = 0; gi < G; ++gi) {
@@ -427,6 +429,57 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       // barrier in between.  fp32: all 8 waves pull (56 pieces); bf16 (28 pieces, latency-bound): only the four
       // waves that own no cells, so nothing of the hand-off queues behind the owners' bulk stores (measured:
       // the split costs 2 % in fp32 and gains 1.5 % in bf16).
+      const bool tagged = !BF && (a.opt & 8);
+      if (tagged && s > 0) {
+        // option (mode bit 29, fp32): THE DATA IS THE FLAG.  Every exchanged word carries the step's epoch in its two low
+        // mantissa bits ((s + 1) & 3 for h_s: 3 ulp at most, the product then runs on the tagged values), producers publish
+        // without drain / barrier / flag, consumers hold back, pull their pieces, check every word's epoch in LDS and pull
+        // again whatever was not there yet.  Two buffers by step parity + a 2-bit epoch: what a buffer held two steps ago
+        // carries another epoch, and the buffers are zeroed (epoch 0, expected 1 first) when a sequence starts.
+        if (s > a.s_begin && a.poll_delay) {
+          const long long nb = t_self + 10LL * a.poll_delay;
+          while (wall_clock64() - nb < 0) __builtin_amdgcn_s_sleep(1);
+        }
+        constexpr int NPW = (NCH + NW - 1) / NW;  // pieces per wave
+        const unsigned want = (unsigned)s & 3u;
+        const float* src = ((s - 1) & 1) ? xb1 : xb0;
+        unsigned pend = 0;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i)
+          if (w + NW * i < NCH) pend |= 1u << i;
+        const long long t0 = wall_clock64();
+        bool ok = true;
+        for (unsigned it = 0; pend; ++it) {
+#pragma unroll
+          for (int i = 0; i < NPW; ++i)
+            if (pend & (1u << i)) dma_piece(src + (w + NW * i) * 256, hs + (w + NW * i) * 256, lane);
+          wait_vmcnt<0>();
+          unsigned still = 0;
+#pragma unroll
+          for (int i = 0; i < NPW; ++i)
+            if (pend & (1u << i)) {
+              const u32x4 v = *reinterpret_cast<const u32x4*>(&hs[(w + NW * i) * 256 + lane * 4]);
+              const bool fresh = (((v[0] ^ want) | (v[1] ^ want) | (v[2] ^ want) | (v[3] ^ want)) & 3u) == 0u;
+              if (!__all(fresh)) still |= 1u << i;
+            }
+          pend = still;
+          if (pend) {
+            if ((it & 15u) == 15u) {
+              if (__hip_atomic_load(a.ctrl, SK_RLX, SK_AGENT) != 0u) ok = false;
+              if (wall_clock64() - t0 > SPIN_TICKS) {
+                if (lane == 0) {
+                  __hip_atomic_store(a.ctrl, 1u, SK_RLX, SK_AGENT);
+                  __hip_atomic_store(a.ctrl - 64, 1u, SK_RLX, SK_AGENT);  // the sticky word
+                }
+                ok = false;
+              }
+              if (!ok) break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        if (!ok && lane == 0) s_abort = 1;
+      } else
       if ((a.opt & 1) && s > a.s_begin && s > 0) {
         // option: ONE polling wave per workgroup (8x fewer pollers on the flag lines, one more barrier)
         if (w == 0 && !wait_flags(myflags, NUG, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL, fs) &&
@@ -454,6 +507,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
             *reinterpret_cast<float4*>(&hs[(c * 16 + bb) * 4]) = v;
           }
         }
+      } else if (tagged) {
+        // (pulled and validated above)
       } else if (!BF || !owner) {
         constexpr int PP = NUG / NCH;            // unit groups (flags) per 1 KB piece
         constexpr int NCW = BF ? NW / 2 : NW;    // consumer waves
@@ -541,11 +596,14 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs,
                                                   (unsigned)(bf_img(ug * (4 * MT) + 4 * mt, bl) * 2), 0, 16 /* sc1 */);
           }
+        } else if (tagged) {
+          const unsigned hb = (__builtin_bit_cast(unsigned, cellok ? h_reg : 0.f) & ~3u) | ((unsigned)(s + 1) & 3u);
+          __hip_atomic_store(reinterpret_cast<unsigned*>(((s & 1) ? xb1 : xb0) + xoff), hb, SK_RLX, SK_AGENT);
         } else {
           __hip_atomic_store(((s & 1) ? xb1 : xb0) + xoff, cellok ? h_reg : 0.f, SK_RLX, SK_AGENT);
         }
         SK_STAMP(4);
-        wait_vmcnt<0>();
+        if (!tagged) wait_vmcnt<0>();  // tagged words need no ordering: nobody is told anything
         SK_STAMP(5);
         acc[0] = gi_;
         acc[1] = gf;
@@ -554,9 +612,13 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         y_out = valid ? h_new : 0.f;
         c_out = c_new;
       }
-      __syncthreads();
-      raise_flag(flags0 + (size_t)ug * fs, rep_stride, a.opt, tid, (unsigned)(s + 1));
-      if (tid == 0) st_tpub[gi] = wall_clock64();  // read back by this same wave when it polls for the next step
+      if (tagged) {
+        t_self = wall_clock64();  // every wave holds its next pull back from here (the owners: their publish)
+      } else {
+        __syncthreads();
+        raise_flag(flags0 + (size_t)ug * fs, rep_stride, a.opt, tid, (unsigned)(s + 1));
+        if (tid == 0) st_tpub[gi] = wall_clock64();  // read back by this same wave when it polls for the next step
+      }
       // 7. ... then the bulk stores of the step, off the critical path
       if (cellok) {
         a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = y_out;
@@ -579,7 +641,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = st_c[gi][oi];
       } else {
         a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_c[gi][oi];
-        if (BF) a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_h[gi][oi];
+        if (BF || (a.opt & 8)) a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_h[gi][oi];
       }
     }
   }
@@ -968,12 +1030,15 @@ struct BwdW {
   bf16x8 b[BF ? BwdCfg<KS, BF>::NQ : 1];
 };
 
+// Returns (tagged hand-off only) a per-lane word whose two low bits are non-zero if a word of this sub-block did not carry
+// the epoch `want`.
 template <int KS, bool BF, int SBI>
-__device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* ring, int lane, f32x4& acc0,
-                                            f32x4& acc1) {
+__device__ __forceinline__ unsigned bwd_consume(const BwdW<KS, BF>& W, const float* ring, int lane, f32x4& acc0,
+                                                f32x4& acc1, unsigned want = 0u) {
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
   const float* src = ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4;
+  unsigned bad = 0u;
 #pragma unroll
   for (int j = 0; j < n; ++j) {
     const int q = SBI * C::SB + j;
@@ -989,8 +1054,27 @@ __device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* 
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 1], db.y, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 2], db.z, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 3], db.w, acc1, 0, 0, 0);
+      bad |= (__builtin_bit_cast(unsigned, db.x) ^ want) | (__builtin_bit_cast(unsigned, db.y) ^ want) |
+             (__builtin_bit_cast(unsigned, db.z) ^ want) | (__builtin_bit_cast(unsigned, db.w) ^ want);
     }
   }
+  return bad & 3u;
+}
+
+// Tagged hand-off: OR of (word ^ epoch) over this lane's words of sub-block SBI; the two low bits are zero iff all of them
+// carry the epoch `want`.
+template <int KS, bool BF, int SBI>
+__device__ __forceinline__ unsigned bwd_check(const float* ring, int lane, unsigned want) {
+  using C = BwdCfg<KS, BF>;
+  constexpr int n = C::cnt(SBI);
+  const u32x4* src = reinterpret_cast<const u32x4*>(ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4);
+  unsigned bad = 0u;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    const u32x4 v = src[j * 64];
+    bad |= (v[0] ^ want) | (v[1] ^ want) | (v[2] ^ want) | (v[3] ^ want);
+  }
+  return bad & 3u;
 }
 
 template <int KS, bool BF>
@@ -1009,14 +1093,48 @@ __device__ __forceinline__ void bwd_prologue(const float* xbase, unsigned xoff, 
 
 // Sub-block I of the DEPTH-deep ring: wait until it has landed (only the DMAs of the next DEPTH-1 sub-blocks may
 // still be in flight), multiply, and refill its slot with sub-block I+DEPTH.
-template <int KS, bool BF, int I>
+// TG (tagged hand-off, fp32): the products of a sub-block are formed speculatively while its words' epochs are checked
+// beside them; if a word was not there yet, the accumulators go back to their values before the sub-block, everything in
+// flight is drained, the sub-block is pulled again and re-checked (bounded; `*ok` false on a time-out or a peer's abort).
+template <int KS, bool BF, bool TG, int I>
 __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
-                                         unsigned ring_lds, int w, int lane, f32x4& acc0, f32x4& acc1) {
+                                         unsigned ring_lds, int w, int lane, f32x4& acc0, f32x4& acc1, unsigned want,
+                                         unsigned* ctrl, bool* ok) {
   using C = BwdCfg<KS, BF>;
   if constexpr (I < C::NSB) {
     constexpr int younger = bwd_younger<KS, BF>(I);
     wait_vmcnt<younger>();
-    bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
+    if constexpr (TG) {
+      // check the sub-block's words first (a second pass of LDS reads: no snapshot of the accumulators, the kernel must stay
+      // within 192 VGPRs), pull it again until they are this step's, then multiply
+      unsigned bad = bwd_check<KS, BF, I>(ring, lane, want);
+      if (__any(bad != 0u) && *ok) {
+        const long long t0 = wall_clock64();
+        for (unsigned it = 0;; ++it) {
+          wait_vmcnt<0>();
+          __builtin_amdgcn_s_sleep(2);
+          bwd_issue<KS, BF, I>(xbase, xoff, ring_lds, w, lane);
+          wait_vmcnt<0>();
+          bad = bwd_check<KS, BF, I>(ring, lane, want);
+          if (!__any(bad != 0u)) break;
+          if ((it & 15u) == 15u) {
+            if (__hip_atomic_load(ctrl, SK_RLX, SK_AGENT) != 0u) *ok = false;
+            if (wall_clock64() - t0 > SPIN_TICKS) {
+              if (lane == 0) {
+                __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
+                __hip_atomic_store(ctrl - 64, 1u, SK_RLX, SK_AGENT);  // the sticky word
+              }
+              *ok = false;
+            }
+            if (!*ok) break;
+          }
+        }
+      }
+      asm volatile("" ::: "memory");  // the products read the sub-block again (values are not kept in registers)
+      bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
+    } else {
+      bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
+    }
     if constexpr (I + C::DEPTH < C::NSB) {
       if constexpr (C::cnt(I + C::DEPTH) > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this ring slot returned before it is refilled
@@ -1024,14 +1142,15 @@ __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* 
         bwd_issue<KS, BF, I + C::DEPTH>(xbase, xoff, ring_lds, w, lane);
       }
     }
-    bwd_ring<KS, BF, I + 1>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1);
+    bwd_ring<KS, BF, TG, I + 1>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, want, ctrl, ok);
   }
 }
 
 // Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
-template <int KS, bool BF>
+template <int KS, bool BF, bool TG = false>
 __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
-                                            float (*red)[16][17], int w, int lane) {
+                                            float (*red)[16][17], int w, int lane, unsigned want = 0u, unsigned* ctrl = nullptr,
+                                            int* abort_word = nullptr) {
   // xbase: the exchange buffer (kernel argument: scalar), xoff: byte offset of this stream's block of the step (uniform)
   const unsigned ring_lds = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1039,7 +1158,9 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
   // nothing may be scheduled into this region (the cell loads of the step were issued before it).
   __builtin_amdgcn_sched_barrier(0);
   bwd_prologue<KS, BF, 0>(xbase, xoff, ring_lds, w, lane);
-  bwd_ring<KS, BF, 0>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1);
+  bool ok = true;
+  bwd_ring<KS, BF, TG, 0>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, want, ctrl, &ok);
+  if (TG && !ok && lane == 0) *abort_word = 1;  // seen by every wave behind the reduce barriers below
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll
@@ -1056,8 +1177,9 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
 // Keep this kernel at 192 VGPRs or fewer (bias-gradient sums live in LDS for that reason): two waves per SIMD then leave 128 registers per lane for ONE co-resident GEMM wave (the
 // weight-gradient GEMMs of the layer above run next to this recurrence on the same CUs, sepkern/engine.py); at 200+
 // no GEMM block fits beside it and the co-scheduling is lost (measured: 39.3 -> 40.9 ms per step).
-template <int KS, bool BF>
-__global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
+template <int KS, bool BF, bool TG = false>
+__global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) void lstm_bwd_kernel(BwdArgs a) {
+  static_assert(!(BF && TG), "the tagged hand-off steals mantissa bits of fp32 words");
   using C = BwdCfg<KS, BF>;
   constexpr int HP = 16 * KS, NQ = C::NQ;
   __shared__ __attribute__((aligned(16))) float ring_all[8][C::DEPTH * C::SB * 256];
@@ -1133,6 +1255,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
 
   if (owner) *reinterpret_cast<f32x4*>(&st_db[oi][0]) = f32x4{0.f, 0.f, 0.f, 0.f};  // read and written by the same lane only
   bool aborted = false;
+  long long t_self = 0;  // tagged hand-off: when this wave was done with the previous step
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
     for (int gi = 0; gi < G; ++gi) {
@@ -1164,19 +1287,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       // 2. recurrent gradient from the step processed before this one
       float dh_rec = 0.f;
       if (s > 0) {
-        // one wave polls for the whole workgroup: letting every wave wait for just the unit groups of its own
-        // eighth of k' (no barrier before the product) measured SLOWER here (fp32 9.4 -> 10.0 ms, bf16 5.6 -> 5.9)
-        if (s > a.s_begin && w == 0) {
-          if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL, fs) && lane == 0)
-            s_abort = 1;
+        const unsigned xo = (unsigned)(((size_t)((((s - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4);
+        if constexpr (TG) {
+          // THE DATA IS THE FLAG (mode bit 29, fp32; see lstm_fwd_kernel): no flags, no barrier -- every wave holds its pull
+          // back by itself and checks the epoch ((s) & 3 for dG_{s-1}) of every word it multiplies
+          if (s > a.s_begin && a.poll_delay) {
+            const long long nb = t_self + 10LL * a.poll_delay;
+            while (wall_clock64() - nb < 0) __builtin_amdgcn_s_sleep(1);
+          }
+          SK_STAMP(0);
+          dh_rec = bwd_matmul<KS, BF, true>(wreg, a.xbuf, xo, ring, red, w, lane, (unsigned)s & 3u, a.ctrl, &s_abort);
+          if (s_abort) {  // (set before the reduce barriers inside the product: every wave sees it)
+            aborted = true;
+            break;
+          }
+        } else {
+          // one wave polls for the whole workgroup: letting every wave wait for just the unit groups of its own
+          // eighth of k' (no barrier before the product) measured SLOWER here (fp32 9.4 -> 10.0 ms, bf16 5.6 -> 5.9)
+          if (s > a.s_begin && w == 0) {
+            if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL, fs) && lane == 0)
+              s_abort = 1;
+          }
+          __syncthreads();
+          if (s_abort) {
+            aborted = true;
+            break;
+          }
+          SK_STAMP(0);
+          dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
         }
-        __syncthreads();
-        if (s_abort) {
-          aborted = true;
-          break;
-        }
-        SK_STAMP(0);
-        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, (unsigned)(((size_t)((((s - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4), ring, red, w, lane);
         SK_STAMP(2);
       }
       // 3. cell backward (owner waves)
@@ -1209,16 +1348,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
           bf16x4 pk;
           pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, (unsigned)(xoff * 2), 0, 16 /* sc1 */);
+        } else if (TG) {
+          u32x4 tg = __builtin_bit_cast(u32x4, dpre);
+          const unsigned ep = (unsigned)(s + 1) & 3u;
+          tg[0] = (tg[0] & ~3u) | ep; tg[1] = (tg[1] & ~3u) | ep; tg[2] = (tg[2] & ~3u) | ep; tg[3] = (tg[3] & ~3u) | ep;
+          __builtin_amdgcn_raw_buffer_store_b128(tg, rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
         } else {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
         }
-        wait_vmcnt<0>();
+        if (!TG) wait_vmcnt<0>();  // tagged words need no ordering: nobody is told anything
         SK_STAMP(5);
       }
-      __syncthreads();
-      if (tid == 0) {
-        __hip_atomic_store(myflags + (size_t)ug * fs, (unsigned)(s + 1), SK_RLX, SK_AGENT);
-        st_tpub[gi] = wall_clock64();
+      if constexpr (TG) {
+        t_self = wall_clock64();
+      } else {
+        __syncthreads();
+        if (tid == 0) {
+          __hip_atomic_store(myflags + (size_t)ug * fs, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+          st_tpub[gi] = wall_clock64();
+        }
       }
       // 5. ... then the bulk store of the step (dgx, zero at padded positions)
       if (cellok) {
@@ -1260,12 +1408,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_kernel(BwdArgs a) {
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
       const int fs = (a.map & 4) ? FSPREAD : 1;
       const unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS * fs;
-      if (T > a.s_begin && w == 0) {
-        if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane, 0LL, fs) && lane == 0) s_abort = 1;
+      const unsigned xo = (unsigned)(((size_t)((((T - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4);
+      float dh_rec;
+      if constexpr (TG) {
+        dh_rec = bwd_matmul<KS, BF, true>(wreg, a.xbuf, xo, ring, red, w, lane, (unsigned)T & 3u, a.ctrl, &s_abort);
+        if (s_abort) return;
+      } else {
+        if (T > a.s_begin && w == 0) {
+          if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane, 0LL, fs) && lane == 0) s_abort = 1;
+        }
+        __syncthreads();
+        if (s_abort) return;
+        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
       }
-      __syncthreads();
-      if (s_abort) return;
-      float dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, (unsigned)(((size_t)((((T - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4), ring, red, w, lane);
       if (cellok) {
         dh_rec += st_carry[gi][oi];
         if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
@@ -1335,6 +1490,12 @@ int launch_fwd(const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
 }
 template <int KS, bool BF>
 int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
+  if constexpr (!BF) {
+    if (a.tagged) {
+      hipLaunchKernelGGL((lstm_bwd_kernel<KS, false, true>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
+      return 0;
+    }
+  }
   hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
   return 0;
 }
@@ -1402,7 +1563,7 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 29) == 0,
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 30) == 0,
                "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
@@ -1440,6 +1601,8 @@ extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float*
   int opt = (mode >> 20) & 7;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD;
                                         // bit 22: one flag per 128-byte line
   if (opt & 4) opt &= ~2;              // one flag per line: no replicas on top (the flag block is sized for either)
+  const bool tagged = ((mode >> 29) & 1) && !((mode >> 16) & 1) && !((mode >> 17) & 1);  // bit 29 (fp32, 8-wave workgroups)
+  if (tagged) opt |= 8;                // the data is the flag (lstm_fwd_kernel)
   int poll_delay = (mode >> 23) & 31;  // bits 23..27: FwdArgs::poll_delay, units of 0.1 us; 0 = choose, 31 = none
   const bool dual = (mode >> 28) & 1;  // bit 28: two-stream workgroups (8 units x both directions), where the shape allows
   mode &= 0xff;
@@ -1465,6 +1628,8 @@ extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float*
   a.map = map; a.nby = nby; a.opt = opt; a.poll_delay = poll_delay;
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));  // per-launch status word + flags (not the sticky word)
+  if ((opt & 8) && s_begin == 0 && (mode & 0xff) != 2)  // tagged words: a new sequence must not find an old one's epochs in the buffers
+    SK_CHECK_HIP(hipMemsetAsync(base + L.xbuf, 0, L.state - L.xbuf, st));
   if (dual && !bf && !half && mode != 2 && gmin <= 1 && fwd2_supported(L.KS) && 2 * L.KS * L.NBG <= num_cus()) {
     // one 768-thread workgroup per CU (131-147 KB of LDS): 2 KS unit groups x NBG batch groups, both directions each
     a.G = 1; a.nby = L.NBG; a.s_begin = s_begin; a.s_end = s_end;
@@ -1516,6 +1681,7 @@ extern "C" int sk_lstm_bwd_range(const float* dy, const float* dhn, const float*
   // (7.59 -> 7.50 us/step) and not kept
   const int map = ((mode >> 18) & 3) | (((mode >> 22) & 1) << 2);
   int poll_delay = (mode >> 23) & 31;  // as sk_lstm_fwd; 0 = none here until measured otherwise
+  const bool tagged = ((mode >> 29) & 1) && !bf;  // bit 29 (fp32): the data is the flag
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -1533,10 +1699,12 @@ extern "C" int sk_lstm_bwd_range(const float* dy, const float* dhn, const float*
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
   if (poll_delay == 31) poll_delay = 0;
-  a.map = map; a.nby = nby; a.poll_delay = poll_delay;
+  a.map = map; a.nby = nby; a.poll_delay = poll_delay; a.tagged = tagged ? 1 : 0;
   dim3 grid((unsigned)L.KS, (unsigned)nby, 2);
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_bwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));
+  if (tagged && s_begin == 0)  // tagged words: a new sequence must not find an old one's epochs in the exchange buffers
+    SK_CHECK_HIP(hipMemsetAsync(base + L.xbuf, 0, L.state - L.xbuf, st));
   if (dbias && s_begin == 0)  // (the kernels ADD their sums: a sequence advanced in several launches accumulates)
     SK_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)L.NBG * 8 * H * sizeof(float), st));  // rows >= grid y stay 0
   const bool last = s_end == T;

@@ -121,12 +121,16 @@ class Engine:
         # map 0..2: block id -> stream assignment (csrc/lstm.hip::decode_block)
         def variant(env, default):
             v = [int(x) for x in os.environ.get(env, default).split(",")]
-            v += [0] * (7 - len(v))
-            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5], dual=bool(v[6]))
-        # "half,map,poll1,repflags,spread,delay[,dual]" (dual: the two-stream forward kernel, 5c).  Forward: streams dealt to XCD groups, one polling wave,
+            v += [0] * (8 - len(v))
+            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5], dual=bool(v[6]), tagged=bool(v[7]))
+        # "half,map,poll1,repflags,spread,delay[,dual[,tagged]]" (dual: the two-stream forward kernel, tagged:
+        # the data-is-the-flag hand-off, both 5c).  Forward: streams dealt to XCD groups, one polling wave,
         # first poll held back (delay 0 = the library's choice); r02: 7.33 -> 6.0 us/step in fp32, 4.0 -> 3.0 in bf16, where
         # one flag per 128-byte line is worth another 5 %.  Backward: the XCD map only (8.00 -> 7.25; it polls later anyway).
-        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0" if self.bf16 else "0,1,1,0,0,0")
+        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0" if self.bf16 else "0,1,1,0,0,8,0,1")
+        # fp32 forward (r03): the data is the flag (tagged = 1, mode bit 29; hold-back 0.8 us): the exchanged h carries the
+        # step's epoch in its two low mantissa bits, no drain / barrier / flag / poll: 7.44 -> 7.02 ms of forward recurrences
+        # per training step (37.1 -> 36.6 ms), h entering the next step's product perturbed by at most 3 ulp
         self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31")
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one.
         # SEPKERN_OVERLAP=2 (default): the recurrence keeps its one-workgroup-per-CU grid and the GEMM blocks

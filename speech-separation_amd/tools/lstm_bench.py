@@ -7,7 +7,7 @@ or rounding-order level).
     python tools/lstm_bench.py [--bf16] [--T 400] [--B 32] [--H 896] [--rounds 7] [--fwd "0,0;1,0;1,2"] [--bwd "0;1"]
 
 --fwd / --bwd: lists of "half,map,poll1,repflags" (sk_lstm_fwd / sk_lstm_bwd mode bits 17, 18..19, 20, 21; trailing
-fields default to 0); 5th field: minimum number of batch groups per workgroup (mode bits 8..15); 6th: one flag per 128-byte line; 7th: hold-back of the first poll after the own flag store, x 0.1 us (0 = library's choice, 31 = none); 8th (forward): two streams per workgroup (mode bit 28).
+fields default to 0); 5th field: minimum number of batch groups per workgroup (mode bits 8..15); 6th: one flag per 128-byte line; 7th: hold-back of the first poll after the own flag store, x 0.1 us (0 = library's choice, 31 = none); 8th (forward): two streams per workgroup (mode bit 28); 9th (forward): tagged data instead of flags (mode bit 29).
 """
 import argparse
 import os
@@ -45,12 +45,12 @@ def main():
         for s in spec.split(";"):
             if s:
                 v = [int(x) for x in s.split(",")]
-                out.append(tuple(v + [0] * (8 - len(v))))
+                out.append(tuple(v + [0] * (9 - len(v))))
         return out
     fwd_vars, bwd_vars = parse(a.fwd), parse(a.bwd)
 
     def bits(var):
-        return ops.lstm_variant_bits(bool(var[0]), var[1], bool(var[2]), bool(var[3]), bool(var[5]), var[6], dual=bool(var[7])) | (var[4] << 8)
+        return ops.lstm_variant_bits(bool(var[0]), var[1], bool(var[2]), bool(var[3]), bool(var[5]), var[6], dual=bool(var[7]), tagged=bool(var[8])) | (var[4] << 8)
 
     def run_fwd(var):
         g = gx.clone()
@@ -99,10 +99,10 @@ def main():
     print("BLSTM recurrence, T=%d B=%d H=%d %s%s: us per step (median / min over %d rounds), max |diff| vs first variant"
           % (T, B, H, "bf16" if bf else "fp32", " ragged" if a.ragged else "", a.rounds))
     for v in fwd_vars:
-        print("  fwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d dual=%d : %7.3f / %7.3f   diff %.3g"
+        print("  fwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d dual=%d tagged=%d : %7.3f / %7.3f   diff %.3g"
               % (v + (1e3 * statistics.median(tf[v]) / T, 1e3 * min(tf[v]) / T, df[v])))
     for v in bwd_vars:
-        print("  bwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d dual=%d : %7.3f / %7.3f   diff %.3g"
+        print("  bwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d dual=%d tagged=%d : %7.3f / %7.3f   diff %.3g"
               % (v + (1e3 * statistics.median(tb[v]) / T, 1e3 * min(tb[v]) / T, db[v])))
 
 

@@ -69,7 +69,11 @@ def main():
         return
     bf = "--bf16" in sys.argv
     # the geometry / protocol the engine ships (sepkern/engine.py: fwd_bits, bwd_bits); --legacy: the r01 one (all zero)
-    if "--legacy" in sys.argv:
+    if "--tagged" in sys.argv:                       # forward: tagged data instead of flags (mode bit 29), hold-back x 0.1 us
+        d = int(sys.argv[sys.argv.index("--tagged") + 1])
+        fbits = ops.lstm_variant_bits(False, 1, True, False, False, d, tagged=True)
+        bbits = ops.lstm_variant_bits(False, 1, False, False, False, 31)
+    elif "--legacy" in sys.argv:
         fbits = bbits = 0
     else:
         fbits = ops.lstm_variant_bits(False, 1, True, False, bf, 0)

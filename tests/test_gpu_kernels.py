@@ -772,6 +772,44 @@ def test_lstm_two_stream_forward_kernel(ops, T, B, H, lens, delay):
         assert torch.equal(a, c_) and torch.equal(a, e)
 
 
+@pytest.mark.parametrize("T,B,H,lens,delay", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1], 0), (30, 16, 896, [30] * 9 + [17] * 7, 31),
+                                              (9, 100, 600, [9] * 60 + [4] * 40, 4), (7, 20, 300, [7] * 7 + [4] * 13, 8), (11, 3, 64, [11, 5, 1], 0)])
+def test_lstm_forward_tagged_hand_off(ops, T, B, H, lens, delay):
+    """Mode bit 29 (fp32 forward): the exchanged h carries the step's epoch in its two low mantissa bits, producers publish
+    without drain / barrier / flag, consumers pull, check every word and pull again what was not there yet.  The product
+    then runs on h with its two low bits replaced (3 ulp): results within 2e-6 of the flag protocol's, bit-reproducible from
+    run to run (also with NO hold-back, where first pulls regularly come too early and are repeated), step ranges
+    bit-identical to one launch, stale epochs of an earlier sequence in the workspace never accepted (T = 30 after T = 12
+    on one workspace: 30 % 4 == 2 is the colliding case without the zeroing)."""
+    g = torch.Generator().manual_seed(11 * H + T)
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+
+    def fwd(bits, ranges=(None,)):
+        gg = gx.clone()
+        y = torch.full((T, B, 2 * H), float("nan")).cuda()
+        cs = torch.zeros(T, B, 2, H).cuda()
+        hn, cn = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+        for r in ranges:
+            ws = ops.lstm_fwd(gg, whh, h0, c0, lens_d, y, gg, cs, hn, cn, T, B, H, 1 | bits, steps=r)
+        ops.lstm_status(ws)
+        return y, gg, cs, hn, cn
+
+    valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
+    ref = fwd(ops.lstm_variant_bits(False, 1, True, False, False, 0))
+    tg = ops.lstm_variant_bits(False, 1, True, False, False, delay, tagged=True)
+    out, again = fwd(tg), fwd(tg)
+    cut = fwd(tg, [(0, T // 3), (T // 3, T)])
+    for a, b, c_, e in zip(out, ref, again, cut):
+        if a.dim() == 4:                                                          # gates / cs: defined at valid steps only
+            a, b, c_, e = a[valid], b[valid], c_[valid], e[valid]
+        assert torch.isfinite(a).all()
+        assert float((a - b).abs().max()) < 2e-6
+        assert torch.equal(a, c_) and torch.equal(a, e)
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("T,B,H,lens,cuts", [(10, 32, 896, [10] * 20 + [7] * 8 + [2] * 4, (5,)), (9, 20, 300, [9] * 7 + [4] * 13, (2, 7)),
@@ -806,6 +844,51 @@ def test_lstm_forward_in_step_ranges_equals_one_launch(ops, mode, bf16, T, B, H,
         assert torch.equal(a, b)
     with pytest.raises(Exception):
         ops.lstm_fwd(gx, whh, h0, c0, lens_d, out[0], None, None, None, None, T, B, H, mode, steps=(3, 3))
+
+
+@pytest.mark.parametrize("T,B,H,lens,delay", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1], 31), (30, 16, 896, [30] * 9 + [17] * 7, 6),
+                                              (9, 100, 600, [9] * 60 + [4] * 40, 31), (7, 20, 300, [7] * 7 + [4] * 13, 8), (11, 3, 64, [11, 5, 1], 31)])
+def test_lstm_backward_tagged_hand_off(ops, T, B, H, lens, delay):
+    """Mode bit 29 in the backward recurrence (fp32): dG carries the step's epoch in the two low mantissa bits of its words,
+    producers publish without drain / barrier / flag, every wave checks each sub-block of its ring before multiplying it and
+    pulls it again while words are missing.  Results within 2e-6 relative of the flag protocol's (dG enters the product with
+    two bits replaced), bit-reproducible, step ranges bit-identical to one launch, dh0 / dc0 / bias sums / dg_first included."""
+    g = torch.Generator().manual_seed(13 * H + T)
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
+    dhn, dcn = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+    gates = gx.clone()
+    y, cs = torch.zeros(T, B, 2 * H).cuda(), torch.zeros(T, B, 2, H).cuda()
+    ws = ops.lstm_fwd(gates, whh, h0, c0, lens_d, y, gates, cs, None, None, T, B, H, 1)
+    ops.lstm_status(ws)
+
+    def bwd(bits, ranges=(None,)):
+        gg = gates.clone()
+        dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+        dbias = torch.zeros((B + 15) // 16, 2, 4 * H).cuda()
+        dgf = torch.zeros(2, B, 4 * H).cuda()
+        for r in ranges:
+            w = ops.lstm_bwd(dy, whh, gg, cs, c0, lens_d, gg, dh0, dc0, T, B, H, 1 | bits, dhn=dhn, dcn=dcn, dbias=dbias, dg_first=dgf,
+                             steps=r)
+        ops.lstm_status(w)
+        return gg, dh0, dc0, dbias, dgf
+
+    ref = bwd(ops.lstm_variant_bits(False, 1, False, False, False, 31))
+    tg = ops.lstm_variant_bits(False, 1, False, False, False, delay, tagged=True)
+    out, again = bwd(tg), bwd(tg)
+    cut = bwd(tg, [(0, T // 3), (T // 3, T)])
+    for i, (a, b, c_, e) in enumerate(zip(out, ref, again, cut)):
+        assert torch.isfinite(a).all()
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) / scale < 2e-6, i
+        assert torch.equal(a, c_)
+        if i == 3:          # dbias: per-launch sums are added (another rounding than one sum)
+            assert torch.allclose(a, e, rtol=1e-5, atol=1e-5)
+        else:
+            assert torch.equal(a, e), i
 
 
 @pytest.mark.parametrize("bf16", [False, True])
