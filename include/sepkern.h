@@ -162,7 +162,12 @@ int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld
  * directions and works on one direction's step while the other direction's h_t travels (lstm_fwd2_kernel) -- taken
  * where the shape allows it (H padded to 320 / 896 / 1024, 2 * ceil(H/8)-ish workgroups per 16 rows co-resident),
  * otherwise the call silently uses the one-stream kernel; results differ from it by the rounding of summing four K
- * quarters instead of two K halves. */
+ * quarters instead of two K halves;
+ * bit 29 (fp32; forward and backward): "the data is the flag" -- every exchanged word (h_t forward, dG_t backward) carries
+ * the step's epoch in its two low mantissa bits, producers publish without drain / barrier / flag, consumers hold back,
+ * pull, check every word and pull again what was not complete; the next step's product runs on the tagged words (<= 3 ulp
+ * = 3.6e-7 relative), everything stored (y, gates, cs, dgx, states) is exact.  The exchange buffers of the workspace are
+ * zeroed by a call that starts a sequence (s_begin == 0).  The engine ships it for the fp32 forward recurrence. */
 size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
