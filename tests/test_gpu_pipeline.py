@@ -240,3 +240,32 @@ def test_bench_launches_its_own_ranks_when_no_launcher_did():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--hidden", "63"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=400)
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_line_carries_the_contract_fields():
+    """One small `python bench.py` run on the GPU: ONE JSON line with the driver's contract fields, the `roofline` object
+    (dominant class + every MFMA-bound class under `by_kernel`, the recurrences with their MFMA floor and hand-off share)
+    and -- on request -- the CPU baseline."""
+    import json
+    root = os.path.dirname(PKG)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--hidden", "320", "--layers", "2",
+                        "--batch", "32", "--frames", "60", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "frames/s" and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["config"]["frames_per_step"] == 32 * 60 and "workload" in d["config"]
+    assert abs(d["value"] - 32 * 60 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] <= 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "traffic" in rf and rf["top_kernel"] in rf["by_kernel"]
+    by = rf["by_kernel"]
+    assert {"gemm_f32_kernel", "lstm_fwd_kernel", "lstm_bwd_kernel"} <= set(by)
+    ms = [v["ms_per_step"] for v in by.values()]
+    assert ms == sorted(ms, reverse=True)                          # largest share of the step first
+    for k in ("lstm_fwd_kernel", "lstm_bwd_kernel"):
+        assert by[k]["us_per_time_step"] > by[k]["mfma_floor_us"] > 0 and by[k]["handoff_us"] > 0
