@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 110
+#define SK_VERSION 111
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -88,8 +88,14 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * the recurrence more of the matrix pipe); 2 = exact three-way bf16 split of both operands on the bf16 matrix pipe
  * (nine exact piece products per element pair, fp32 accumulators: an fp32 product in another summation order; power-
  * bound on MI355X, opt-in); 3 = the 128 x 128-tile LDS-DMA kernel wherever it applies, 4 = its 256 x 128-tile, 8-wave form
- * wherever that applies (diagnostics; 0 picks among 1, 3 and 4 by shape). */
+ * wherever that applies (diagnostics; 0 picks among 1, 3 and 4 by shape); 5 = 256 x 256 tiles, one workgroup per CU
+ * (unsplit products; opt-in for variant 0 by SEPKERN_GEMM_SQUARE=1); 6 = the same kernel PERSISTENT with a stream-K cut
+ * of the last partial round of tiles (unsplit, unbatched products; splitk = 1 and ws >= sk_gemm_streamk_workspace_bytes(),
+ * zero-filled before its first use and left with zeroed counters by every launch; without ws it is variant 5; variant 0
+ * chooses it for the large N/T and N/N products when splitk = 1 and a ws is given, SEPKERN_GEMM_STREAMK=0: never).  Tiles of the cut are summed piece by piece in a fixed order:
+ * deterministic, fp32 summation order differs from the other variants. */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
+size_t sk_gemm_streamk_workspace_bytes(void);
 /* Zero the ticket counters at the head of a split-K workspace (once, before its first use; a buffer that was allocated
  * zero-filled needs no call). */
 int sk_gemm_workspace_init(void* ws, sk_stream_t stream);

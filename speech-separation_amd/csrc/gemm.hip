@@ -38,6 +38,7 @@ struct GemmArgs {
   unsigned* counters;  // one ticket counter per (batch, tile), zero between launches: the fp32 kernels reduce the slabs
                        // themselves (finish_splitk); nullptr = the separate splitk_reduce_kernel does
   int64_t sA, sB, sC, sbias;
+  int sk_tiles, sk_full;  // stream-K kernel: tiles of the product, data-parallel rounds before the stream-K region
 };
 constexpr size_t COUNTER_BYTES = 65536;  // head of a split-K workspace: 16384 counters
 
@@ -669,6 +670,213 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_dma256x256(GemmArgs g)
   for (int h = 0; h < 2; ++h) {  // the wave's two 64-column halves through the 64 x 64 epilogue
     const f32x16 part[2][2] = {{acc[0][2 * h], acc[0][2 * h + 1]}, {acc[1][2 * h], acc[1][2 * h + 1]}};
     store_tile(g, part, C, g.ldc, bias, false, m0 + wm * 64, n0 + wn * 128 + 64 * h, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// The 256 x 256 kernel as a PERSISTENT stream-K kernel (r03, variant 6; unsplit, unbatched products): one workgroup per
+// CU, P = gridDim.x of them.  With one workgroup per CU a partial last round of tiles costs a whole round (1400 tiles on
+// 256 CUs: 6 rounds for 5.47 of work), which is what kept the 256 x 256 kernel off the training step.  Here workgroup b
+// first takes the tiles b, P + b, ... of `sk_full` whole rounds in the usual XCD-aware order, then its share of the
+// REMAINING r = tiles - sk_full P tiles: their r nk K steps are laid end to end and cut into P equal ranges, so a
+// workgroup's range covers pieces of at most two tiles.  A piece goes to the workgroup's slab in the workspace
+// (write-through stores), a ticket is drawn from the tile's counter, and the workgroup that draws the LAST ticket adds
+// the tile's pieces in workgroup order (deterministic), applies bias / accumulate / act and stores: nobody ever waits for
+// anybody, so the grid need not be co-resident.  The K steps of consecutive segments form ONE software pipeline: the
+// next segment's first two stages are in flight while a tile is stored.
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
+  constexpr int BMW = 256, BNW = 256;
+  constexpr int TILE = BMW * BK * 4, STAGE = 2 * TILE;
+  constexpr int NST = 3;
+  constexpr int SLAB = BMW * BNW;  // floats per piece
+  __shared__ __attribute__((aligned(1024))) char lds[NST][STAGE];
+  __shared__ int s_fix[4];  // last ticket?, first and last contributor, which piece of the first
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int P = gridDim.x, b = blockIdx.x;
+  const int nk = g.K / BK, nt = g.sk_tiles, full = g.sk_full;
+  const int64_t R = (int64_t)(nt - full * P) * nk;
+  const int64_t beg = b * R / P, end = (b + 1) * R / P;
+  const int t0 = (int)(beg / nk);                                        // first stream-K tile this workgroup touches
+  const int nseg = full + (end > beg ? (int)((end - 1) / nk) - t0 + 1 : 0);  // + 0, 1 or 2 pieces
+
+  // segment i of this workgroup: position v in the tile order, K steps [kb, ke)
+  auto segment = [&](int i, int& v, int& kb, int& ke) {
+    if (i < full) {
+      v = i * P + b; kb = 0; ke = nk;
+    } else {
+      const int t = t0 + (i - full);
+      const int64_t lo = (int64_t)t * nk;
+      v = full * P + t;
+      kb = (int)(max(beg, lo) - lo);
+      ke = (int)(min(end, lo + nk) - lo);
+    }
+  };
+  // the tile order of the other kernels (each XCD walks its own run of the list; 8-row groups column-wise inside it)
+  auto origin = [&](int v, int& m0, int& n0) {
+    const int q = nt >> 3, rem = nt & 7, x = v & 7, j = v >> 3;
+    const int tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+    constexpr int GM = GROUP_M / 2;
+    const int tilesM = nt / g.tilesN, per = GM * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GM;
+    const int gsz = min(GM, tilesM - first);
+    m0 = (first + rem2 % gsz) * BMW;
+    n0 = (rem2 / gsz) * BNW;
+  };
+
+  // DMA cursor: two K steps ahead of the products, across segment boundaries
+  const int64_t stepA = TA ? (int64_t)BK * g.lda : BK, stepB = !TB ? (int64_t)BK * g.ldb : BK;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
+  const unsigned pa = __builtin_amdgcn_readfirstlane(lds_base + 2 * wave * 1024);
+  const float* srcA[2];
+  const float* srcB[2];
+  int di = 0, dk = 0, dke = 0;
+  auto dma_open = [&]() {
+    int v, kb, ke, m0, n0;
+    segment(di, v, kb, ke);
+    origin(v, m0, n0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      srcA[i] = dma_src_w256<TA>(g.A, g.lda, m0, g.M, kb * BK, 2 * wave + i, lane);
+      srcB[i] = dma_src_w256<!TB>(g.B, g.ldb, n0, g.N, kb * BK, 2 * wave + i, lane);
+    }
+    dk = kb;
+    dke = ke;
+  };
+  auto fetch = [&](int buf) {
+    if (di >= nseg) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dma_1k(srcA[i], pa + buf * STAGE + i * 1024);
+      dma_1k(srcB[i], pa + buf * STAGE + TILE + i * 1024);
+      srcA[i] += stepA;
+      srcB[i] += stepB;
+    }
+    if (++dk == dke && ++di < nseg) dma_open();
+  };
+
+  f32x16 acc[2][4];
+  auto clear = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto store = [&](int m0, int n0) {  // the wave's two 64-column halves through the 64 x 64 epilogue
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x16 part[2][2] = {{acc[0][2 * h], acc[0][2 * h + 1]}, {acc[1][2 * h], acc[1][2 * h + 1]}};
+      store_tile(g, part, g.C, g.ldc, g.bias, false, m0 + wm * 64, n0 + wn * 128 + 64 * h, lane);
+    }
+  };
+  clear();
+
+  int fa[2], fb[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa[i] = frag_base_w<TA, BMW>(wm * 64 + 32 * i, lane);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb[j] = frag_base_w<!TB, BNW>(wn * 128 + 32 * j, lane);
+
+  const int64_t F = (int64_t)full * nk + (end - beg);  // K steps of this workgroup, all segments
+  if (nseg > 0) dma_open();
+  fetch(0);
+  fetch(1);
+  int ci = 0, cv = 0, ck = 0, cke = 0;
+  if (nseg > 0) segment(0, cv, ck, cke);
+  int cur = 0;
+  for (int64_t f = 0; f < F; ++f) {
+    // step f has landed when at most the 4 instructions of step f + 1 are in flight (loads return in order; stores of an
+    // epilogue in between only make the wait conservative)
+    if (f + 1 < F)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    fetch((cur + 2) % NST);
+    const char* ai = lds[cur];
+    const char* bi = lds[cur] + TILE;
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp) {
+      float a[2][4], bb[4][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) frag_load_w<TA, BMW>(ai, fa[i], cp, a[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) frag_load_w<!TB, BNW>(bi, fb[j], cp, bb[j]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], bb[j][k], acc[i][j], 0, 0, 0);
+    }
+    cur = (cur + 1) % NST;
+    if (++ck < cke) continue;
+
+    // ---- end of a segment
+    int m0, n0;
+    origin(cv, m0, n0);
+    if (ci < full) {
+      store(m0, n0);
+    } else {
+      const int t = cv - full * P;
+      float* mine = g.slabs + (size_t)(2 * b + (t - t0)) * SLAB;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __hip_atomic_store(mine + ((i * 4 + j) * 16 + r) * 512 + tid, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        // the workgroup whose range holds K step i of the region: the largest w with floor(w R / P) <= i
+        const int w0 = (int)((((int64_t)t * nk + 1) * P - 1) / R), w1 = (int)((((int64_t)(t + 1) * nk) * P - 1) / R);
+        const unsigned old = __hip_atomic_fetch_add(g.counters + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (unsigned)(w1 - w0);
+        if (last) __hip_atomic_store(g.counters + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_fix[0] = last; s_fix[1] = w0; s_fix[2] = w1;
+        s_fix[3] = (w0 * R / P < (int64_t)t * nk) ? 1 : 0;  // the first contributor's piece is its second one unless its range starts here
+      }
+      __syncthreads();
+      if (s_fix[0]) {
+        // memory -> memory: element q * 512 + tid of a piece is accumulator register q of thread tid.  Piece of workgroup w:
+        // slab 2 w (+ 1 for the first contributor when the tile is the second one of its range)
+        const int w0 = s_fix[1], w1 = s_fix[2];
+        const float* sl0 = g.slabs + (size_t)(2 * w0 + s_fix[3]) * SLAB + tid;
+        const int kh = lane >> 5, col = n0 + wn * 128 + (lane & 31), row = m0 + wm * 64 + 4 * kh;
+        // 32 values per thread and round trip: the accumulators are dead here, and the tile waits on latency, not bandwidth
+        for (int q0 = 0; q0 < 128; q0 += 32) {
+          float v[32];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) v[u] = __hip_atomic_load(sl0 + (q0 + u) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int w = w0 + 1; w <= w1; ++w) {
+            const float* sl = g.slabs + (size_t)(2 * w) * SLAB + tid;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] += __hip_atomic_load(sl + (q0 + u) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int u = 0; u < 32; ++u) {
+            const int q = q0 + u, i = q >> 6, j = (q >> 4) & 3, r = q & 15;
+            const int c = col + 32 * j, rw = row + 32 * i + (r & 3) + 8 * (r >> 2);
+            if (c < g.N && rw < g.M) {
+              float* cp = g.C + (int64_t)rw * g.ldc + c;
+              float x = v[u];
+              if (g.bias) x += g.bias[c];
+              if (g.accumulate) x += *cp;
+              if (g.act == 1) x = sk_sigmoid(x);
+              *cp = x;
+            }
+          }
+        }
+      }
+    }
+    clear();
+    if (++ci < nseg) segment(ci, cv, ck, cke);
   }
 }
 
@@ -1357,6 +1565,24 @@ extern "C" int sk_gemm_workspace_init(void* ws, sk_stream_t stream) {
   return SK_OK;
 }
 
+namespace {
+int gemm_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+  }
+  return n;
+}
+// workgroups of the stream-K kernel: one per CU, a multiple of 8 (the tile order counts on blockIdx & 7 = XCD)
+int streamk_wgs() { return gemm_cus() & ~7; }
+}  // namespace
+
+extern "C" size_t sk_gemm_streamk_workspace_bytes(void) {
+  return COUNTER_BYTES + (size_t)2 * streamk_wgs() * 256 * 256 * sizeof(float);
+}
+
 extern "C" size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk) {
   if (splitk <= 1) return 0;
   return COUNTER_BYTES + sk_align((size_t)M * N * batch * splitk * sizeof(float), 256);
@@ -1393,7 +1619,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                 int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
-  SK_CHECK_ARG(variant >= 0 && variant <= 5, "sk_gemm: unknown variant %d", variant);
+  SK_CHECK_ARG(variant >= 0 && variant <= 6, "sk_gemm: unknown variant %d", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
@@ -1407,6 +1633,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
   g.tilesN = (int)sk_cdiv(N, BN);
   g.sA = sA; g.sB = sB; g.sC = sC; g.sbias = sbias;
+  g.sk_tiles = 0; g.sk_full = 0;
   g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), bk) * bk);
   splitk = (int)sk_cdiv(K, g.kchunk);  // slices that actually hold work
   g.splitk = splitk;
@@ -1420,9 +1647,25 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   // products): the same operand forms as `wide`, unsplit only
   static const bool square_ok = [] { const char* e = getenv("SEPKERN_GEMM_SQUARE"); return e && e[0] == '1'; }();
   const bool square = !bf16 && M >= 256 && N >= 256 && splitk == 1 && dma_ok(g, transA, transB) &&
-                      (variant == 5 || (variant == 0 && square_ok && !transA && M >= 4096 && N >= 1024));
-  if (square) g.tilesN = (int)sk_cdiv(N, 256);
-  const int64_t tiles = sk_cdiv(M, (wide || square) ? 256 : BM) * g.tilesN;
+                      (variant == 5 || variant == 6 || (variant == 0 && square_ok && !transA && M >= 4096 && N >= 1024));
+  // the same kernel persistent with a stream-K cut of the last partial round: variant 6, or chosen (variant 0) for the large
+  // unsplit N/T and N/N products when the caller passes the workspace of sk_gemm_streamk_workspace_bytes() -- measured
+  // 124.4 vs 121.5 TFLOP/s on the input projections, 134.6 vs 125.5 on the data gradients, 36.05 vs 36.63 ms on the training
+  // step (three alternations).  SEPKERN_GEMM_STREAMK=0 (diagnostics): never chosen.
+  static const bool streamk_ok = [] { const char* e = getenv("SEPKERN_GEMM_STREAMK"); return !(e && e[0] == '0'); }();
+  bool streamk = !bf16 && ws && batch == 1 && M >= 256 && N >= 256 && splitk == 1 && dma_ok(g, transA, transB) &&
+                 (variant == 6 || (variant == 0 && streamk_ok && !transA && M >= 4096 && N >= 1024));
+  if (streamk) {
+    const int P = streamk_wgs();
+    const int64_t nt = sk_cdiv(M, 256) * sk_cdiv(N, 256), nk = K / BK;
+    g.sk_tiles = (int)nt;
+    g.sk_full = (int)(nt / P);
+    const int64_t R = (nt - (int64_t)g.sk_full * P) * nk;
+    // a remainder too short to give every workgroup a K step goes to whole tiles (the plain kernel's last round)
+    if (P < 8 || nt >= (1 << 24) || nk < 8 || (R > 0 && R < P) || nt - (int64_t)g.sk_full * P > 16384) streamk = false;
+  }
+  if (square || streamk) g.tilesN = (int)sk_cdiv(N, 256);
+  const int64_t tiles = sk_cdiv(M, (wide || square || streamk) ? 256 : BM) * g.tilesN;
   SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm: too many tiles");
   // workspace = [ticket counters | slabs]; the fp32 kernels reduce in-kernel when the counters cover every (batch, tile)
   g.slabs = ws ? (float*)((char*)ws + COUNTER_BYTES) : nullptr;
@@ -1439,6 +1682,15 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, false>), grid, dim3(256), 0, st, g);
     else
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<true, true>), grid, dim3(256), 0, st, g);
+  } else if (streamk) {
+    g.counters = (unsigned*)ws;
+    const dim3 pgrid((unsigned)streamk_wgs());
+    if (!transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, false>), pgrid, dim3(512), 0, st, g);
+    else if (!transA && transB)
+      hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, true>), pgrid, dim3(512), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel_streamk<true, false>), pgrid, dim3(512), 0, st, g);
   } else if (square) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_dma256x256<false, false>), grid, dim3(512), 0, st, g);

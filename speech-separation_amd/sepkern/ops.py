@@ -82,6 +82,7 @@ def device_info():
 
 # ----------------------------------------------------------------------------- GEMM
 _NUM_CUS = None
+_STREAMK = __import__('os').environ.get('SEPKERN_GEMM_STREAMK', '1') != '0'    # variant 0 may choose the stream-K kernel
 _SPLITK_MAX = int(__import__('os').environ.get('SEPKERN_SPLITK_MAX', '32'))   # diagnostic: cap the K slices
 
 
@@ -117,7 +118,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     choose) splits K into deterministic partial slabs -- for weight gradients.  bf16=True rounds A and B to
     bf16 on the way into the matrix cores (fp32 accumulate; everything in memory stays fp32).  variant (fp32 only,
     sk_gemm_f32_splitk's `variant`): 0 choose, 1 the register-staged kernel even where the LDS-DMA one applies,
-    2 exact three-way bf16 split of both operands on the bf16 matrix pipe (fp32 products, another summation order)."""
+    2 exact three-way bf16 split of both operands on the bf16 matrix pipe (fp32 products, another summation order),
+    3 / 4 / 5 the 128 x 128 / 256 x 128 / 256 x 256-tile LDS-DMA kernels, 6 the persistent stream-K form of 5."""
     for t in (A, B, Cout, bias):
         _chk(t)
     if splitk == 0:
@@ -125,6 +127,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     ws = None
     if splitk > 1:
         ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
+    elif not bf16 and batch == 1 and (variant == 6 or (variant == 0 and _STREAMK and not transA and M >= 4096 and N >= 1024)):
+        ws = workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), ws_tag + "_sk")    # pieces of the stream-K cut
     with _timed("gemm_bf16_kernel" if bf16 else "gemm_f32_kernel", 2.0 * M * N * K * batch):
         args = (_ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA), int(transB), int(accumulate),
                 int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws))

@@ -200,6 +200,34 @@ def test_gemm_dma_kernels_forced(ops, variant, M, N, K, tA, tB, S):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K,tA,tB", [(1000, 772, 1792, False, True),      # 16 tiles, no whole round: every tile in 16 pieces
+                                         (4352, 4096, 256, False, True),      # 272 tiles: one round + 16 tiles cut at every K step
+                                         (5000, 3800, 528, False, False),     # 300 tiles, ragged edges, ranges that span two tiles
+                                         (3800, 5000, 528, True, False),      # the T/N form
+                                         (4096, 4096, 64, False, True),       # a whole number of rounds: no cut at all
+                                         (300, 260, 64, False, True)])        # remainder too short to cut: the plain 256 x 256 kernel
+def test_gemm_stream_k_kernel(ops, M, N, K, tA, tB):
+    """sk_gemm_f32_splitk variant 6 (r03): the persistent 256 x 256-tile kernel with a stream-K cut of the last partial round.
+    Against fp64 with bias and accumulate, run-to-run identical (pieces are added in workgroup order), counters left zeroed."""
+    from sepkern import _lib
+    g = torch.Generator().manual_seed(M + 3 * N)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    bias, C0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = (A.double().t() if tA else A.double()) @ (B.double().t() if tB else B.double()) + bias.double() + C0.double()
+    outs = []
+    for _ in range(2):
+        C = dev(C0.clone())
+        ops.gemm(dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N, transA=tA, transB=tB, bias=dev(bias), accumulate=True, variant=6,
+                 ws_tag="t_sk")
+        torch.cuda.synchronize()
+        outs.append(C.cpu())
+    np.testing.assert_allclose(outs[0].numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
+    assert torch.equal(outs[0], outs[1])
+    ws = ops.workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), "t_sk_sk")
+    assert int(ws[:65536].max()) == 0
+
+
 def test_gemm_splitk_workspace_from_a_c_caller(ops):
     """A split-K workspace that did NOT come zero-filled (a C caller's own allocation): sk_gemm_workspace_init zeroes the
     ticket counters at its head once; launches then leave them zeroed (two launches in a row give the same, right result)."""
