@@ -552,6 +552,13 @@ class Engine:
                 ws = ops.lstm_bwd(*bargs, steps=(T // 2, T), **bkw)
             else:
                 ws = ops.lstm_bwd(*bargs, **bkw)
+            # The layer's weight-gradient products need the recurrence's dgx only: the side stream is released BEFORE the data
+            # gradient is issued on the main stream, so its blocks fill what that launch leaves free (its tail, the launch gaps)
+            # instead of starting behind it (r03: 35.85-35.97 vs 36.00-36.07 ms per step; SEPKERN_WGRAD_EARLY=0: as before).
+            # fp32 only: the bf16 products are short and share operand copies across the two streams -- 14.0 vs 13.55 ms there
+            early = overlap and l > 0 and not split and not self.bf16 and os.environ.get("SEPKERN_WGRAD_EARLY", "1") == "1"
+            if early:
+                self.side.wait_stream(main)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
                 dy_next = torch.empty(R, Ip, device=dev)
                 self._dgrad(cache, dgx.view(R, 8 * H), wih_gi, dy_next, "gemm_dgrad")
@@ -559,7 +566,8 @@ class Engine:
                     dx = (dy_next if Ip == I else dy_next[:, :I].contiguous()).view(T, B, I)
             stream = self.side if (overlap and l > 0) else main
             if stream is not main:
-                stream.wait_stream(main)
+                if not early:
+                    stream.wait_stream(main)
             elif overlap and split:
                 main.wait_stream(self.side)      # layer 0 adds its second half onto the half sums the side stream made
             # (unsplit: layer 0's products share nothing with the side stream's but bf16 operand copies, which carry their
