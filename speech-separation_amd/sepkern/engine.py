@@ -552,11 +552,13 @@ class Engine:
                 ws = ops.lstm_bwd(*bargs, steps=(T // 2, T), **bkw)
             else:
                 ws = ops.lstm_bwd(*bargs, **bkw)
-            # The layer's weight-gradient products need the recurrence's dgx only: the side stream is released BEFORE the data
-            # gradient is issued on the main stream, so its blocks fill what that launch leaves free (its tail, the launch gaps)
-            # instead of starting behind it (r03: 35.85-35.97 vs 36.00-36.07 ms per step; SEPKERN_WGRAD_EARLY=0: as before).
-            # fp32 only: the bf16 products are short and share operand copies across the two streams -- 14.0 vs 13.55 ms there
-            early = overlap and l > 0 and not split and not self.bf16 and os.environ.get("SEPKERN_WGRAD_EARLY", "1") == "1"
+            # The layer's weight-gradient products need the recurrence's dgx only: with SEPKERN_WGRAD_EARLY=1 the side stream is
+            # released BEFORE the data gradient is issued on the main stream, so its blocks fill what that launch leaves free
+            # (its tail, the launch gaps) instead of starting behind it.  r03, fp32: 35.85-35.97 vs 36.00-36.07 ms per step,
+            # but the side launches then spend 4.5 ms per step queued behind the persistent data-gradient kernel, which
+            # bench.py's per-launch events count as theirs (roofline.frac 0.505 instead of 0.57): opt-in.  bf16: slower
+            # (14.0 vs 13.55 ms; short products that share operand copies across the two streams).
+            early = overlap and l > 0 and not split and not self.bf16 and os.environ.get("SEPKERN_WGRAD_EARLY", "0") == "1"
             if early:
                 self.side.wait_stream(main)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
