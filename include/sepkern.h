@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 111
+#define SK_VERSION 112
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -216,6 +216,14 @@ int sk_lstm_bwd_range(const float* dy, const float* dhn, const float* dcn, const
                       const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
                       float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, int s_begin, int s_end,
                       sk_stream_t stream);
+/* sk_lstm_bwd_range that ALSO writes dgx as bf16 (r03, the bf16 configuration): dgx_bf16[(t B + b) ld_bf16 + d 4H + 4u + g],
+ * the row-major operand copy the layer's data- and weight-gradient products read, so that no cast pass over dgx runs between
+ * the recurrence and those products.  ld_bf16 >= 8H, a multiple of 4; only the (T B) x 8H entries are written: padding
+ * columns / rows a product expects to be zero are the caller's.  dgx_bf16 = NULL: exactly sk_lstm_bwd_range. */
+int sk_lstm_bwd_twin(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
+                     const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
+                     float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, int s_begin, int s_end,
+                     void* dgx_bf16, int ld_bf16, sk_stream_t stream);
 /* Reorder the rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g H + u inside each block of 4H
  * rows) and the gate-interleaved order of gx / gates / dgx (row 4u + g).  back = 0: dst[4u+g] = src[gH+u] (weights,
  * biases -> interleaved); back = 1: dst[gH+u] (+)= src[4u+g] (weight gradients back to the parameter order,

@@ -154,6 +154,8 @@ struct BwdArgs {
   int T, B, H, NBG, G, s_begin, s_end, final_mm;
   int map, nby, poll_delay;
   int tagged;  // fp32: the data is the flag (epoch in the two low mantissa bits of every exchanged dG word)
+  __bf16* dgx_bf;  // optional bf16 twin of dgx (rows (t, b), ld_bf elements apart), written with the fp32 values; may be NULL
+  int ld_bf;
 };
 
 // Flag replication (opt bit 1): every producer raises its flag in NREP copies with ONE store instruction (NREP lanes,
@@ -1371,6 +1373,11 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
       // 5. ... then the bulk store of the step (dgx, zero at padded positions)
       if (cellok) {
         *reinterpret_cast<f32x4*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit) = dpre;
+        if (a.dgx_bf) {  // the operand copy the data- and weight-gradient products of the bf16 configuration read (no cast pass)
+          bf16x4 pk;
+          pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
+          *reinterpret_cast<bf16x4*>(a.dgx_bf + ((size_t)t * B + b) * a.ld_bf + (size_t)dir * 4 * H + 4 * (size_t)unit) = pk;
+        }
       }
       SK_STAMP(6);
     }
@@ -1670,7 +1677,17 @@ extern "C" int sk_lstm_bwd_range(const float* dy, const float* dhn, const float*
                                  const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
                                  float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
                                  int mode, int s_begin, int s_end, sk_stream_t stream) {
+  return sk_lstm_bwd_twin(dy, dhn, dcn, whh, gates, cs, c0, lens, dgx, dh0, dc0, dbias, dg_first, ws, T, B, H, mode, s_begin,
+                          s_end, nullptr, 0, stream);
+}
+
+extern "C" int sk_lstm_bwd_twin(const float* dy, const float* dhn, const float* dcn, const float* whh,
+                                const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
+                                float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
+                                int mode, int s_begin, int s_end, void* dgx_bf16, int ld_bf16, sk_stream_t stream) {
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
+  SK_CHECK_ARG(!dgx_bf16 || (ld_bf16 >= 8 * H && ld_bf16 % 4 == 0 && ((uintptr_t)dgx_bf16 % 8) == 0),
+               "sk_lstm_bwd: bf16 twin needs ld >= 8H, ld %% 4 == 0, 8-byte alignment");
   SK_CHECK_ARG(s_begin >= 0 && s_begin < s_end && s_end <= T, "sk_lstm_bwd: bad step range [%d, %d) of %d", s_begin, s_end, T);
   SK_CHECK_ARG(((uintptr_t)gates % 16) == 0 && ((uintptr_t)dgx % 16) == 0, "sk_lstm_bwd: gates / dgx must be 16-byte aligned");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
@@ -1690,6 +1707,7 @@ extern "C" int sk_lstm_bwd_range(const float* dy, const float* dhn, const float*
   a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens;
   a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0; a.dhn = dhn; a.dcn = dcn;
   a.dbias = dbias;
+  a.dgx_bf = (__bf16*)dgx_bf16; a.ld_bf = ld_bf16;
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;

@@ -96,6 +96,8 @@ class Engine:
         # it lies and transposed by ds_read_b64_tr_b16 on the way into the matrix cores), so the 12 transposed copies per
         # step (sk_cast_bf16_t, 0.94 ms) are never made.  SEPKERN_BF16_KMAJOR=0 keeps the r02 path with transposed copies.
         self.kmajor = self.nt and hidden % 8 == 0 and os.environ.get("SEPKERN_BF16_KMAJOR", "1") == "1"
+        # ... and the backward recurrence writes the bf16 copy of dgx itself (sk_lstm_bwd_twin); SEPKERN_BF16_TWIN=0: cast pass
+        self.bf16_twin = os.environ.get("SEPKERN_BF16_TWIN", "1") == "1"
         # data-parallel runs only: BatchNorm over the GLOBAL batch instead of per rank (sepkern/dist.py)
         self.sync_bn = bool(sync_bn) or os.environ.get("SEPKERN_SYNC_BN", "0") == "1"
         if hidden % 4 != 0 or hidden > 1024:
@@ -551,7 +553,20 @@ class Engine:
                     self._wgrad_half(1, dgx, y, inp, gw_hh, gw_ih, T, B, Ip, "gemm_side", True)
                 ws = ops.lstm_bwd(*bargs, steps=(T // 2, T), **bkw)
             else:
-                ws = ops.lstm_bwd(*bargs, **bkw)
+                # bf16 (r03): the recurrence writes dgx a second time as bf16 -- the operand copy its three products read
+                # (data gradient, dW_ih, dW_hh) -- instead of a cast pass over 4 x the bytes between recurrence and products
+                twin = None
+                if self.kmajor and self.bf16_twin:
+                    rows, ld = ops.pad_to(R, 64) + 64, ops.pad_to(8 * H, 64)
+                    twin = (torch.empty if ld == 8 * H else torch.zeros)(rows, ld, dtype=torch.bfloat16, device=dev)
+                    if ld == 8 * H:
+                        twin[R:].zero_()                 # whole K steps of zero rows behind the data (K-major factor)
+                ws = ops.lstm_bwd(*bargs, dgx_bf16=twin, **bkw)
+                if twin is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    d2 = dgx.view(R, 8 * H)
+                    cache[("rowk", d2.data_ptr(), tuple(d2.shape))] = (twin, ev, main, d2)
             # The layer's weight-gradient products need the recurrence's dgx only: with SEPKERN_WGRAD_EARLY=1 the side stream is
             # released BEFORE the data gradient is issued on the main stream, so its blocks fill what that launch leaves free
             # (its tail, the launch gaps) instead of starting behind it.  r03, fp32: 35.85-35.97 vs 36.00-36.07 ms per step,

@@ -523,19 +523,23 @@ def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=
 
 
 def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=None, dcn=None, bf16=False,
-             dbias=None, dg_first=None, steps=None):
+             dbias=None, dg_first=None, steps=None, dgx_bf16=None):
     """dbias ((B+15)//16, 2, 4H) and dg_first (2, B, 4H): optional by-products (include/sepkern.h) from which the
     caller gets the bias gradients and, with lstm_whh_grad, dW_hh without another pass over dgx.  steps=(s0, s1): only
-    that range of processing steps (sk_lstm_bwd_range: consecutive calls on the same workspace advance one sequence)."""
+    that range of processing steps (sk_lstm_bwd_range: consecutive calls on the same workspace advance one sequence).
+    dgx_bf16: a (rows >= T*B, ld >= 8H) bfloat16 tensor that receives dgx as bf16 as well (sk_lstm_bwd_twin)."""
     ws = lstm_ws(T, B, H)
     mode = int(mode) | (0x10000 if bf16 else 0)
     for t in (dbias, dg_first):
         _chk(t)
+    _chk(dgx_bf16, torch.bfloat16)
+    if dgx_bf16 is not None and (dgx_bf16.dim() != 2 or dgx_bf16.shape[0] < T * B or dgx_bf16.stride(1) != 1):
+        raise _lib.SepkernError("lstm_bwd: the bf16 twin must be a row-major (>= T*B, ld) matrix")
     s0, s1 = (0, T) if steps is None else steps
     with _timed("lstm_bwd_kernel", 2.0 * (s1 - s0) * B * 2 * 4 * H * H):
-        _lib.call("sk_lstm_bwd_range", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
+        _lib.call("sk_lstm_bwd_twin", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
                   _ptr(lens), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(dbias), _ptr(dg_first), _ptr(ws), T, B, H, mode,
-                  s0, s1, _stream())
+                  s0, s1, _ptr(dgx_bf16), 0 if dgx_bf16 is None else dgx_bf16.stride(0), _stream())
     return ws
 
 

@@ -839,6 +839,36 @@ def test_lstm_forward_tagged_hand_off(ops, T, B, H, lens, delay):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("T,B,H,lens", [(9, 32, 896, [9] * 20 + [7] * 8 + [2] * 4), (6, 20, 304, [6] * 7 + [4] * 13), (5, 3, 64, [5, 3, 1])])
+def test_lstm_backward_bf16_twin_of_dgx(ops, T, B, H, lens, bf16):
+    """sk_lstm_bwd_twin (r03): the backward recurrence also writes dgx as bf16 into a caller-supplied (rows, ld) matrix.  The twin
+    equals the RNE rounding of the fp32 dgx of the same launch entry by entry (zero rows past a sequence's end included), what lies
+    outside the (T B) x 8H block is not touched, and the fp32 results are those of the launch without a twin."""
+    g = torch.Generator().manual_seed(7 * H + T)
+    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
+    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+    gates = gx.clone()
+    y, cs = torch.zeros(T, B, 2 * H).cuda(), torch.zeros(T, B, 2, H).cuda()
+    ops.lstm_status(ops.lstm_fwd(gates, whh, h0, c0, lens_d, y, gates, cs, None, None, T, B, H, 1, bf16=bf16))
+    R, ld = T * B, 8 * H + 64
+    outs = []
+    for twin in (None, torch.full((R + 5, ld), 7.0, dtype=torch.bfloat16).cuda()):
+        gg = gates.clone()
+        dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+        ops.lstm_status(ops.lstm_bwd(dy, whh, gg, cs, c0, lens_d, gg, dh0, dc0, T, B, H, 1, bf16=bf16, dgx_bf16=twin))
+        outs.append((gg, dh0, dc0))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    dgx = outs[1][0].view(R, 8 * H)
+    assert torch.equal(twin[:R, :8 * H], dgx.to(torch.bfloat16))
+    assert float(dgx.abs().max()) > 0
+    assert bool((twin[R:] == 7).all()) and bool((twin[:, 8 * H:] == 7).all())
+
+
+@pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("T,B,H,lens,cuts", [(10, 32, 896, [10] * 20 + [7] * 8 + [2] * 4, (5,)), (9, 20, 300, [9] * 7 + [4] * 13, (2, 7)),
                                              (8, 16, 64, [8] * 10 + [3] * 6, (1, 4))])
