@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 112
+#define SK_VERSION 113
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -129,7 +129,11 @@ int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const float* bias, i
  * tiles are DMA'd as they lie and the MFMA fragments are gathered by the transposed LDS read ds_read_b64_tr_b16).
  * K-major operand: ld = elements between consecutive k rows, >= its dimension rounded up to 8 and a multiple of 8; the
  * (ld - dim) padding elements of a row must be readable (finite or not: their products are never stored); K % 64 == 0
- * as always -- rows [K', K) of a zero-padded factor must be zeros in at least one of the two factors. */
+ * as always -- rows [K', K) of a zero-padded factor must be zeros in at least one of the two factors.
+ * splitk = 1 WITH ws != NULL (>= sk_gemm_streamk_workspace_bytes(), zero-filled before its first use; r03): the product
+ * may run as the persistent stream-K form of the 256 x 256-tile kernel (unbatched, N % 256 == 0 or N > 1024, K >= 512):
+ * one workgroup per CU, the last partial round of tiles cut along K, pieces added in a fixed order (deterministic) --
+ * instead of K slabs of the whole matrix and a reduce launch.  Not for products meant to run beside a recurrence. */
 int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                     int ldc, int a_kmajor, int b_kmajor, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                     int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream);

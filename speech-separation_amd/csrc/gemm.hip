@@ -1257,6 +1257,8 @@ struct Args {
   int splitk, kchunk;  // K range of slice y: [y * kchunk, min(K, (y + 1) * kchunk)), kchunk a multiple of BK
   float* slabs;
   int64_t sA, sB, sC, sbias;
+  unsigned* counters;     // stream-K kernel: one ticket counter per tile of the cut (head of the workspace)
+  int sk_tiles, sk_full;  // stream-K kernel: tiles of the product, data-parallel rounds before the stream-K region
 };
 
 // byte offset of (row r, 16-byte chunk c) in a tile image
@@ -1472,6 +1474,240 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf16_nt_kernel(Args g) {
           *cp = v;
         }
       }
+  }
+}
+
+// The 256 x 256 instantiation as a PERSISTENT stream-K kernel (r03): the schedule, piece / ticket protocol and fix-up of
+// gemm_f32_kernel_streamk above (one workgroup per CU; whole rounds of tiles data-parallel, the K steps of the remaining
+// tiles laid end to end and cut into gridDim.x equal ranges; pieces through slabs, last ticket adds them in workgroup
+// order), on this kernel's images, fragments and two LDS buffers.  It replaces split-K for the unbatched products with
+// few tiles (data gradients: 350 tiles, weight gradients: 196): no K slabs of the whole matrix, no second launch.
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(NT, 2) void gemm_bf16_streamk_kernel(Args g) {
+  constexpr int BN = 256, TM = 8, TN = 4, PA = 4, PB = 4;
+  constexpr int ABYTES = BM * BK * 2, BBYTES = BN * BK * 2, STAGE = ABYTES + BBYTES;
+  constexpr int SLAB = BM * BN;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * STAGE];
+  __shared__ int s_fix[4];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w >> 2, wn = w & 3;
+  const int P = gridDim.x, b = blockIdx.x;
+  const int nk = g.K / BK, nt = g.sk_tiles, full = g.sk_full;
+  const int64_t R = (int64_t)(nt - full * P) * nk;
+  const int64_t beg = b * R / P, end = (b + 1) * R / P;
+  const int t0 = (int)(beg / nk);
+  const int nseg = full + (end > beg ? (int)((end - 1) / nk) - t0 + 1 : 0);
+
+  auto segment = [&](int i, int& v, int& kb, int& ke) {
+    if (i < full) {
+      v = i * P + b; kb = 0; ke = nk;
+    } else {
+      const int t = t0 + (i - full);
+      const int64_t lo = (int64_t)t * nk;
+      v = full * P + t;
+      kb = (int)(max(beg, lo) - lo);
+      ke = (int)(min(end, lo + nk) - lo);
+    }
+  };
+  auto origin = [&](int v, int& m0, int& n0) {
+    const int q = nt >> 3, rem = nt & 7, x = v & 7, j = v >> 3;
+    const int tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+    const int tilesM = nt / g.tilesN, per = GROUP_M * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GROUP_M;
+    const int gsz = min(GROUP_M, tilesM - first);
+    m0 = (first + rem2 % gsz) * BM;
+    n0 = (rem2 / gsz) * BN;
+  };
+
+  // DMA cursor: one K step ahead of the products, across segment boundaries
+  const int64_t stepA = AKM ? (int64_t)BK * g.lda : BK, stepB = BKM ? (int64_t)BK * g.ldb : BK;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const unsigned pieceA = __builtin_amdgcn_readfirstlane(lds_base + w * PA * 1024);
+  const unsigned pieceB = __builtin_amdgcn_readfirstlane(lds_base + ABYTES + w * PB * 1024);
+  const __bf16* srcA[PA];
+  const __bf16* srcB[PB];
+  int di = 0, dk = 0, dke = 0;
+  auto dma_open = [&]() {
+    int v, kb, ke, m0, n0;
+    segment(di, v, kb, ke);
+    origin(v, m0, n0);
+    const int kbeg = kb * BK;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      int r, c;
+      if (AKM) {
+        kmaj_piece_src<BM>(w * PA + i, lane, r, c);
+        srcA[i] = g.A + (int64_t)(kbeg + r) * g.lda + min(m0 + c, g.lda - 8);
+      } else {
+        piece_src(w * PA + i, lane, r, c);
+        srcA[i] = g.A + (int64_t)min(m0 + r, g.M - 1) * g.lda + kbeg + c * 8;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      int r, c;
+      if (BKM) {
+        kmaj_piece_src<BN>(w * PB + i, lane, r, c);
+        srcB[i] = g.B + (int64_t)(kbeg + r) * g.ldb + min(n0 + c, g.ldb - 8);
+      } else {
+        piece_src(w * PB + i, lane, r, c);
+        srcB[i] = g.B + (int64_t)min(n0 + r, g.N - 1) * g.ldb + kbeg + c * 8;
+      }
+    }
+    dk = kb;
+    dke = ke;
+  };
+  auto fetch = [&](int buf) {
+    if (di >= nseg) return;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(srcA[i]), "s"(pieceA + buf * STAGE + i * 1024)
+                   : "memory");
+      srcA[i] += stepA;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(srcB[i]), "s"(pieceB + buf * STAGE + i * 1024)
+                   : "memory");
+      srcB[i] += stepB;
+    }
+    if (++dk == dke && ++di < nseg) dma_open();
+  };
+
+  f32x4 acc[TM][TN];
+  auto clear = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  clear();
+
+  const int fa = img(wm * 128 + (lane & 15), lane >> 4);
+  const int fb = img(wn * (BN / 4) + (lane & 15), lane >> 4);
+  int ka[AKM ? TM : 1], kb_[BKM ? TN : 1];
+  if (AKM) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) ka[i] = kmaj_frag_addr<BM>(wm * TM + i, lane);
+  }
+  if (BKM) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) kb_[j] = kmaj_frag_addr<BN>(wn * TN + j, lane);
+  }
+
+  const int64_t F = (int64_t)full * nk + (end - beg);
+  if (nseg > 0) dma_open();
+  fetch(0);
+  int ci = 0, cv = 0, ck = 0, cke = 0;
+  if (nseg > 0) segment(0, cv, ck, cke);
+  int cur = 0;
+  for (int64_t f = 0; f < F; ++f) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of step f have landed (and an epilogue's stores) ...
+    __syncthreads();                                   // ... and everybody's; all reads of the other buffer are done
+    fetch(cur ^ 1);
+    const char* a = lds + cur * STAGE;
+    const char* bt = a + ABYTES;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (AKM)
+          af[i] = kmaj_frag(a, ka[i] + s * 32 * (2 * BM), 2 * BM);
+        else
+          af[i] = *reinterpret_cast<const bf16x8*>(a + ((fa ^ (s << 6)) + i * 2048));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (BKM)
+          bfr[j] = kmaj_frag(bt, kb_[j] + s * 32 * (2 * BN), 2 * BN);
+        else
+          bfr[j] = *reinterpret_cast<const bf16x8*>(bt + ((fb ^ (s << 6)) + j * 2048));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    cur ^= 1;
+    if (++ck < cke) continue;
+
+    // ---- end of a segment.  C/D layout of the 16x16 MFMA: col = lane & 15, row = 4 * (lane >> 4) + reg
+    int m0, n0;
+    origin(cv, m0, n0);
+    const int col0 = n0 + wn * (BN / 4) + (lane & 15), row0 = m0 + wm * 128 + 4 * (lane >> 4);
+    if (ci < full) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 16;
+        if (col >= g.N) continue;
+        const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = row0 + i * 16 + r;
+            if (row < g.M) {
+              float* cp = g.C + (int64_t)row * g.ldc + col;
+              float v = acc[i][j][r] + bv;
+              if (g.accumulate) v += *cp;
+              if (g.act == 1) v = sk_sigmoid(v);
+              *cp = v;
+            }
+          }
+      }
+    } else {
+      const int t = cv - full * P;
+      float* mine = g.slabs + (size_t)(2 * b + (t - t0)) * SLAB + tid;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_store(mine + ((i * TN + j) * 4 + r) * 512, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int w0 = (int)((((int64_t)t * nk + 1) * P - 1) / R), w1 = (int)((((int64_t)(t + 1) * nk) * P - 1) / R);
+        const unsigned old = __hip_atomic_fetch_add(g.counters + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (unsigned)(w1 - w0);
+        if (last) __hip_atomic_store(g.counters + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_fix[0] = last; s_fix[1] = w0; s_fix[2] = w1;
+        s_fix[3] = (w0 * R / P < (int64_t)t * nk) ? 1 : 0;
+      }
+      __syncthreads();
+      if (s_fix[0]) {
+        const int w0 = s_fix[1], w1 = s_fix[2];
+        const float* sl0 = g.slabs + (size_t)(2 * w0 + s_fix[3]) * SLAB + tid;
+        for (int q0 = 0; q0 < 128; q0 += 32) {
+          float v[32];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) v[u] = __hip_atomic_load(sl0 + (q0 + u) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int ww = w0 + 1; ww <= w1; ++ww) {
+            const float* sl = g.slabs + (size_t)(2 * ww) * SLAB + tid;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) v[u] += __hip_atomic_load(sl + (q0 + u) * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int u = 0; u < 32; ++u) {
+            const int q = q0 + u, i = q >> 4, j = (q >> 2) & 3, r = q & 3;
+            const int col = col0 + j * 16, row = row0 + i * 16 + r;
+            if (col < g.N && row < g.M) {
+              float* cp = g.C + (int64_t)row * g.ldc + col;
+              float x = v[u];
+              if (g.bias) x += g.bias[col];
+              if (g.accumulate) x += *cp;
+              if (g.act == 1) x = sk_sigmoid(x);
+              *cp = x;
+            }
+          }
+        }
+      }
+    }
+    clear();
+    if (++ci < nseg) segment(ci, cv, ck, cke);
   }
 }
 
@@ -1794,9 +2030,21 @@ extern "C" int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const flo
   splitk = (int)sk_cdiv(K, g.kchunk);
   g.splitk = splitk;
   g.slabs = ws ? (float*)((char*)ws + COUNTER_BYTES) : nullptr;  // (the head of a workspace belongs to the fp32 kernels' counters)
+  g.counters = (unsigned*)ws; g.sk_tiles = 0; g.sk_full = 0;
+  // splitk = 1 WITH a workspace (>= sk_gemm_streamk_workspace_bytes, zero-filled before its first use): the persistent
+  // stream-K kernel where it applies (unbatched, 256-wide column tiles, at least 8 K steps) -- r03
+  bool streamk = splitk == 1 && ws && batch == 1 && M >= 256 && (N % 256 == 0 || N > 1024);
+  if (streamk) {
+    const int P = streamk_wgs();
+    const int64_t nt = sk_cdiv(M, bf2::BM) * sk_cdiv(N, 256), nk = K / bf2::BK;
+    g.sk_tiles = (int)nt;
+    g.sk_full = (int)(nt / P);
+    const int64_t rem = nt - (int64_t)g.sk_full * P, R = rem * nk;
+    if (P < 8 || nt >= (1 << 24) || nk < 8 || (R > 0 && R < P) || rem > 16384) streamk = false;
+  }
   // 256-wide column tiles unless N is small enough that they would leave most of the chip idle
   const int64_t tiles256 = sk_cdiv(M, bf2::BM) * sk_cdiv(N, 256) * splitk * batch;
-  const bool wide = (N % 256 == 0 || N > 1024) && tiles256 >= 2 * 256;
+  const bool wide = streamk || ((N % 256 == 0 || N > 1024) && tiles256 >= 2 * 256);
   const int bn = wide ? 256 : 128;
   g.tilesN = (int)sk_cdiv(N, bn);
   const int64_t tiles = sk_cdiv(M, bf2::BM) * g.tilesN;
@@ -1804,7 +2052,14 @@ extern "C" int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const flo
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
 #define SK_BF2_LAUNCH(BNV, AK, BKV) hipLaunchKernelGGL((bf2::gemm_bf16_nt_kernel<BNV, AK, BKV>), grid, dim3(bf2::NT), 0, st, g)
-  if (wide) {
+#define SK_BF2_STREAMK(AK, BKV) \
+  hipLaunchKernelGGL((bf2::gemm_bf16_streamk_kernel<AK, BKV>), dim3((unsigned)streamk_wgs()), dim3(bf2::NT), 0, st, g)
+  if (streamk) {
+    if (!a_kmajor && !b_kmajor) SK_BF2_STREAMK(false, false);
+    else if (!a_kmajor) SK_BF2_STREAMK(false, true);
+    else if (!b_kmajor) SK_BF2_STREAMK(true, false);
+    else SK_BF2_STREAMK(true, true);
+  } else if (wide) {
     if (!a_kmajor && !b_kmajor) SK_BF2_LAUNCH(256, false, false);
     else if (!a_kmajor) SK_BF2_LAUNCH(256, false, true);
     else if (!b_kmajor) SK_BF2_LAUNCH(256, true, false);
@@ -1816,6 +2071,7 @@ extern "C" int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const flo
     else SK_BF2_LAUNCH(128, true, true);
   }
 #undef SK_BF2_LAUNCH
+#undef SK_BF2_STREAMK
   SK_CHECK_LAUNCH("sk_gemm_bf16_nt");
   if (splitk > 1) {
     GemmArgs r;

@@ -214,7 +214,7 @@ class Engine:
             return
         kind = "rowk" if self.kmajor else "row"            # the same copies serve the backward products K-major
         a, b = self._copy(cache, kind, inp2d), self._copy(cache, kind, w)
-        ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act)
+        ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act, streamk=True)
 
     def _dgrad(self, cache, dout2d, w, out2d, ws_tag):
         """out (R, K) = dout (R, N) w (N, K)."""
@@ -230,7 +230,8 @@ class Engine:
             # out = dout w: w (N, K) is the K-major B of the product as it lies (contraction over its rows, padded with
             # zero rows up to dout's zero-padded width)
             a, b = self._copy(cache, "rowk", dout2d), self._copy(cache, "rowk", w)
-            ops.gemm_bf16_mm(a, b, out2d, R, K, a.shape[1], a.shape[1], b.shape[1], K, b_kmajor=True, splitk=0, ws_tag=ws_tag)
+            ops.gemm_bf16_mm(a, b, out2d, R, K, a.shape[1], a.shape[1], b.shape[1], K, b_kmajor=True, splitk=0, ws_tag=ws_tag,
+                             streamk=True)
             return
         a, bt = self._copy(cache, "row", dout2d), self._copy(cache, "t", w)      # w^T: (K, N padded)
         ops.gemm_bf16_nt(a, bt, out2d, R, K, a.shape[1], a.shape[1], bt.shape[1], K, splitk=0, ws_tag=ws_tag)
@@ -249,7 +250,7 @@ class Engine:
             # gw = dout^T inp: both factors K-major as they lie (their rows are the contraction index)
             a, b = self._copy(cache, "rowk", dout2d), self._copy(cache, "rowk", inp2d)
             ops.gemm_bf16_mm(a, b, gw, N, K, ops.pad_to(R, 64), a.shape[1], b.shape[1], K, a_kmajor=True, b_kmajor=True,
-                             accumulate=acc, splitk=0, ws_tag=ws_tag)
+                             accumulate=acc, splitk=0, ws_tag=ws_tag, streamk=not beside)
             return
         at, bt = self._copy(cache, "t", dout2d), self._copy(cache, "t", inp2d)    # (N, R padded), (K, R padded)
         ops.gemm_bf16_nt(at, bt, gw, N, K, ops.pad_to(R, 64), at.shape[1], bt.shape[1], K, accumulate=acc, splitk=0,

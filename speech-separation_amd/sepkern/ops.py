@@ -82,6 +82,7 @@ def device_info():
 
 # ----------------------------------------------------------------------------- GEMM
 _NUM_CUS = None
+_STREAMK_BF16 = __import__('os').environ.get('SEPKERN_BF16_STREAMK', '1') != '0'
 _STREAMK = __import__('os').environ.get('SEPKERN_GEMM_STREAMK', '1') != '0'    # variant 0 may choose the stream-K kernel
 _SPLITK_MAX = int(__import__('os').environ.get('SEPKERN_SPLITK_MAX', '32'))   # diagnostic: cap the K slices
 
@@ -169,15 +170,19 @@ def cast_bf16_t(x2d, ld=None, out=None):
 
 
 def gemm_bf16_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, accumulate=False, act=0, batch=1, sA=0, sB=0, sC=0,
-                 sbias=0, splitk=1, ws_tag="gemm"):
-    """Cout[M,N] = act(A[M,K] B[N,K]^T + bias (+ Cout)) with A, B bfloat16 tensors (K-contiguous, K % 64 == 0)."""
+                 sbias=0, splitk=1, ws_tag="gemm", streamk=False):
+    """Cout[M,N] = act(A[M,K] B[N,K]^T + bias (+ Cout)) with A, B bfloat16 tensors (K-contiguous, K % 64 == 0).
+    streamk: as gemm_bf16_mm."""
     _chk(A, torch.bfloat16)
     _chk(B, torch.bfloat16)
     _chk(Cout)
     _chk(bias)
+    ws = None
+    if streamk and _STREAMK_BF16 and batch == 1 and splitk in (0, 1) and M >= 256 and (N % 256 == 0 or N > 1024) and K >= 512:
+        splitk = 1
+        ws = workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), ws_tag + "_sk")
     if splitk == 0:
         splitk = pick_splitk_bf16(M, N, K, batch)
-    ws = None
     if splitk > 1:
         ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
     with _timed("gemm_bf16_nt_kernel", 2.0 * M * N * K * batch):
@@ -186,17 +191,21 @@ def gemm_bf16_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, accumulate=False
 
 
 def gemm_bf16_mm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, bias=None, accumulate=False, act=0, batch=1,
-                 sA=0, sB=0, sC=0, sbias=0, splitk=1, ws_tag="gemm"):
+                 sA=0, sB=0, sC=0, sbias=0, splitk=1, ws_tag="gemm", streamk=False):
     """Cout[M,N] = act(opA opB + bias (+ Cout)) on bfloat16 operands in memory, either of them optionally K-MAJOR
     (a_kmajor: A stored [K][M] with lda elements between k rows; b_kmajor: B stored [K][N]) -- sk_gemm_bf16_mm.  Row-major
-    operands: K-contiguous as in gemm_bf16_nt.  K % 64 == 0."""
+    operands: K-contiguous as in gemm_bf16_nt.  K % 64 == 0.  streamk=True (unbatched products that have the chip to
+    themselves): the persistent stream-K kernel instead of K slices where it applies (SEPKERN_BF16_STREAMK=0: never)."""
     _chk(A, torch.bfloat16)
     _chk(B, torch.bfloat16)
     _chk(Cout)
     _chk(bias)
+    ws = None
+    if streamk and _STREAMK_BF16 and batch == 1 and splitk in (0, 1) and M >= 256 and (N % 256 == 0 or N > 1024) and K >= 512:
+        splitk = 1
+        ws = workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), ws_tag + "_sk")
     if splitk == 0:
         splitk = pick_splitk_bf16(M, N, K, batch)
-    ws = None
     if splitk > 1:
         ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
     with _timed("gemm_bf16_nt_kernel", 2.0 * M * N * K * batch):

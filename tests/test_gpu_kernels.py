@@ -711,6 +711,49 @@ def test_gemm_bf16_k_major_operands_equal_fp64_product_of_rounded_operands(ops, 
     assert err < 2e-6, err
 
 
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(1000, 772 + 512, 1792),      # 24 tiles, no whole round: every tile in ~10 pieces
+                                   (4352, 4096, 512),            # 272 tiles: one round + 16 tiles cut at every K step
+                                   (5000, 3800, 1088),           # 300 tiles, ragged edges, ranges that span two tiles
+                                   (4096, 4096, 512)])           # a whole number of rounds: no cut at all
+def test_gemm_bf16_stream_k_kernel(ops, M, N, K, akm, bkm):
+    """sk_gemm_bf16_mm with splitk = 1 and a stream-K workspace (r03): the persistent 256 x 256-tile bf16 kernel with the last
+    partial round of tiles cut along K.  All four operand forms, bias + accumulate, against the fp64 product of the bf16
+    operands; run-to-run identical; ticket counters left zeroed."""
+    from sepkern import _lib
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    pad8 = lambda n: (n + 7) // 8 * 8
+    A = torch.randn(M, K, generator=g).bfloat16()
+    Bm = torch.randn(N, K, generator=g).bfloat16()
+    bias, C0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = A.double() @ Bm.double().t() + bias.double() + C0.double()
+    if akm:
+        lda = pad8(M) + 8
+        Ad = torch.full((K, lda), float("nan")).bfloat16()
+        Ad[:, :M] = A.t()
+    else:
+        lda, Ad = K, A
+    if bkm:
+        ldb = pad8(N)
+        Bd = torch.full((K, ldb), float("nan")).bfloat16()
+        Bd[:, :N] = Bm.t()
+    else:
+        ldb, Bd = K, Bm
+    Ad, Bd, bias_d = Ad.contiguous().cuda(), Bd.contiguous().cuda(), bias.cuda()
+    outs = []
+    for _ in range(2):
+        C = C0.clone().cuda()
+        ops.gemm_bf16_mm(Ad, Bd, C, M, N, K, lda, ldb, N, a_kmajor=akm, b_kmajor=bkm, bias=bias_d, accumulate=True, ws_tag="t_bsk",
+                         streamk=True)
+        torch.cuda.synchronize()
+        outs.append(C.cpu())
+    err = float((outs[0].double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    assert torch.equal(outs[0], outs[1])
+    ws = ops.workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), "t_bsk_sk")
+    assert int(ws[:65536].max()) == 0
+
+
 @pytest.mark.parametrize("T,B,H,lens", [(9, 32, 896, [9] * 20 + [7] * 8 + [2] * 4), (7, 40, 600, [7] * 17 + [5] * 20 + [1] * 3),
                                         (6, 16, 64, [6] * 10 + [3] * 6)])
 def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H, lens):
