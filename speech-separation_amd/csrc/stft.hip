@@ -89,10 +89,12 @@ __device__ __forceinline__ void dft16(v2f (&x)[16]) {
 // on exit z[k2] = Z[j + 16 k2].  xch: this GROUP's 16 x XLD float2 transpose area in LDS; tw = e^{-2 pi i m/512}.
 // The transpose goes through a 16 x XLD FLOAT plane, real parts first, then imaginary parts: half the LDS of a
 // complex plane (the STFT workgroup then fits four times per CU instead of three) for twice the LDS instructions.
-__device__ __forceinline__ void fft256_g16(v2f (&z)[16], float* xch, const float2* tw, int j) {
+// t256[16 k1 + j] = W256^(j k1): the inter-stage twiddles laid out so that the 16 lanes of a group read 128 contiguous
+// bytes (read from the 512-entry table at (2 j k1) & 511 the even k1 are 2- to 8-way bank conflicts: r03).
+__device__ __forceinline__ void fft256_g16(v2f (&z)[16], float* xch, const float2* t256, int j) {
   dft16(z);  // over n1: z[k1] = A[k1][n2 = j]
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], ld2(&tw[(2 * j * k1) & 511]));  // W256^(j k1)
+  for (int k1 = 1; k1 < 16; ++k1) z[k1] = cmul(z[k1], ld2(&t256[16 * k1 + j]));  // W256^(j k1)
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) xch[k1 * XLD + j] = z[k1].x;
   wave_sync();
@@ -122,6 +124,7 @@ __global__ __launch_bounds__(256, BINMAJOR ? 2 : 4) void stft_kernel(const void*
   __shared__ __attribute__((aligned(16))) float smp[NFFT + (FPB - 1) * HOP];
   __shared__ __attribute__((aligned(16))) float win[NFFT];
   __shared__ float2 tw[NFFT];
+  __shared__ float2 t256[256];
   __shared__ float xch[16][16 * XLD];  // one transpose plane per 16-lane group
   __shared__ float2 ost[BINMAJOR ? FPB : 1][BINMAJOR ? NBIN : 1];
 
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(256, BINMAJOR ? 2 : 4) void stft_kernel(const void*
     tw[i] = g_tw512[i];
     win[i] = g_hann512[i];
   }
+  t256[tid] = g_tw512[(2 * (tid & 15) * (tid >> 4)) & 511];
   float pre[SPT];
   fetch(tile0 * FPB, pre);
   stash(pre);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, BINMAJOR ? 2 : 4) void stft_kernel(const void*
       const v2f w = *reinterpret_cast<const v2f*>(&win[32 * n1 + 2 * j]);
       z[n1] = sm * w;
     }
-    fft256_g16(z, xch[4 * wave + g], tw, j);
+    fft256_g16(z, xch[4 * wave + g], t256, j);
 
     // real-FFT split: X[k] = Xe + W^k Xo, Xe = (Z[k] + conj Z[256-k])/2, Xo = -i (Z[k] - conj Z[256-k])/2, k = j + 16 k2.
     // Z[256-k] is register 15-k2 of lane (16-j)%16 of this group (register (16-k2)%16 of lane 0 itself when j == 0).
@@ -272,7 +276,12 @@ __global__ __launch_bounds__(256, BINMAJOR ? 2 : 4) void stft_kernel(const void*
 }
 
 constexpr int RING = FPB + 3;  // row slots of the iSTFT ring: one tile of frames + the 3 frames before it
-constexpr int RLD = NBIN + 1;  // float2 per slot: a 257-bin spectrum, then the FFT's 16 x 17 float transpose plane, then 512 samples
+// float2 per slot: a 257-bin spectrum, then the FFT's 16 x 17 float transpose plane, then 512 samples.  272 (r03; was 258):
+// consecutive slots lie 544 dwords = 32 banks (mod 64) apart, so the two frames a 32-lane group of ds_read_b64 covers fall
+// on opposite halves of the bank row; and bin k of frame t sits at index k ^ ((t + 3) & 15) -- a permutation inside each
+// aligned group of 16 bins -- so that the 16 FRAMES x one bin a 16-lane group of the tile load writes (rows now a multiple
+// of 32 banks apart) land on 16 different bank pairs.  Both were 2-way conflicts (35 % of the kernel's LDS cycles, r02 PMC).
+constexpr int RLD = 272;
 
 // Masked spectra of frames [tfirst, tfirst + COUNT) into their ring slots (zeros outside [0, T)).
 template <int COUNT>
@@ -298,18 +307,19 @@ __device__ __forceinline__ void istft_load(float2 (*rows)[RLD], int tfirst, int 
         x.y *= m;
       }
     }
-    rows[(t + 3) % RING][k] = x;
+    rows[(t + 3) % RING][k ^ ((t + 3) & 15)] = x;
   }
 }
 
 // Inverse real FFT of frame t by one 16-lane group; the windowed 512 samples replace the spectrum in the slot.
-__device__ __forceinline__ void istft_frame(float2* row, const float2* tw, const float* win, int j) {
+// key = (t + 3) & 15: the slot's bin permutation (RLD).
+__device__ __forceinline__ void istft_frame(float2* row, const float2* tw, const float2* t256, const float* win, int j, int key) {
   v2f z[16];
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) {
     const int k = 16 * n1 + j;
-    v2f a = ld2(&row[k]);
-    v2f b = ld2(&row[256 - k]);
+    v2f a = ld2(&row[k ^ key]);
+    v2f b = ld2(&row[(256 - k) ^ key]);
     if (k == 0) {  // irfft ignores Im X[0] and Im X[256]
       a.y = 0.f;
       b.y = 0.f;
@@ -321,7 +331,9 @@ __device__ __forceinline__ void istft_frame(float2* row, const float2* tw, const
     z[n1] = (v2f){xe.x - xo.y, -(xe.y + xo.x)};
   }
   wave_sync();  // the spectrum is in registers: the slot now serves as the transpose area, then as the output
-  fft256_g16(z, reinterpret_cast<float*>(row), tw, j);
+  // transpose plane: the odd one of the two groups that share a 32-lane half sits 16 banks further (slots are a multiple
+  // of 32 banks apart), so the two groups' column writes / row reads never meet on a bank
+  fft256_g16(z, reinterpret_cast<float*>(row) + 16 * ((threadIdx.x >> 4) & 1), t256, j);
   float* tf = reinterpret_cast<float*>(row);
 #pragma unroll
   for (int k2 = 0; k2 < 16; ++k2) {  // z[k2] = Y[n], n = j + 16 k2; x[2n] = Re Y / 256, x[2n+1] = -Im Y / 256
@@ -357,7 +369,7 @@ __device__ __forceinline__ void istft_fetch(TileRegs& r, int t0, int T, const fl
 
 __device__ __forceinline__ void istft_stash(const TileRegs& r, float2 (*rows)[RLD], int t0) {
   const int fr = threadIdx.x & 15, k0 = threadIdx.x >> 4;
-  float2* row = rows[(t0 + fr + 3) % RING] + k0;
+  float2* row = rows[(t0 + fr + 3) % RING] + (k0 ^ ((t0 + fr + 3) & 15));
 #pragma unroll
   for (int q = 0; q < 17; ++q)
     if (q < 16 || k0 == 0) row[16 * q] = make_float2(r.x[q].x * r.m[q], r.x[q].y * r.m[q]);
@@ -370,11 +382,12 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(
     const int64_t* __restrict__ mix_sf, const float* __restrict__ mask, const int64_t* __restrict__ mask_offs,
     const int64_t* __restrict__ mask_st, const int64_t* __restrict__ mask_sf, const int32_t* __restrict__ nframes,
     int S, float* __restrict__ wav_out, int16_t* __restrict__ pcm_out, const int64_t* __restrict__ out_offs, int tpb) {
-  // 45 KB: three workgroups per CU.  (Reading the 6 KB of tables through the vector L1 instead would fit four, but
+  // 48.4 KB: three workgroups per CU.  (Reading the 6 KB of tables through the vector L1 instead would fit four, but
   // the 64-bit gather addresses push the kernel over 128 VGPRs into scratch: measured 2.7 -> 4.9 ms.)
   __shared__ __attribute__((aligned(16))) float2 rows[RING][RLD];
   __shared__ __attribute__((aligned(16))) float win[NFFT];
   __shared__ float2 tw[NFFT];
+  __shared__ float2 t256[256];
 
   const int us = blockIdx.y;
   const int u = us / S;
@@ -397,11 +410,12 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(
     tw[i] = g_tw512[i];
     win[i] = g_hann512[i];
   }
+  t256[tid] = g_tw512[(2 * (tid & 15) * (tid >> 4)) & 511];
   if (tile0 > 0) {  // the 3 frames before this block's first tile
     const int tf = tile0 * FPB - 3;
     istft_load<3>(rows, tf, T, mix, mo, mst, msf, mask, ko, kst, ksf);
     __syncthreads();
-    if (fr < 3) istft_frame(rows[(tf + fr + 3) % RING], tw, win, j);
+    if (fr < 3) istft_frame(rows[(tf + fr + 3) % RING], tw, t256, win, j, (tf + fr + 3) & 15);
   }
   // overlap-add roles: thread (m0 = tid & 127, hsel = tid >> 7) produces sample m0 of hops t0 + hsel + 2q, q = 0..7.
   // With all four taps inside [0, T) the window-sum-square is a constant of the thread.
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(
       istft_load<FPB>(rows, t0, T, mix, mo, mst, msf, mask, ko, kst, ksf);
     __syncthreads();
     if (binmajor && tile + 1 < tile1) istft_fetch(pre, t0 + FPB, T, mix, mo, msf, mask, ko, ksf);  // travels under the FFTs
-    istft_frame(rows[(t0 + fr + 3) % RING], tw, win, j);
+    istft_frame(rows[(t0 + fr + 3) % RING], tw, t256, win, j, (t0 + fr + 3) & 15);
     __syncthreads();
     // overlap-add in increasing frame order, window-sum-square normalisation, trim, convert
     int slot = (t0 + hsel) % RING;  // ring slot of frame hp - 3 (frame t lives in slot (t + 3) % RING)
