@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(
   if (tile0 >= ntiles) return;
   const int tile1 = min(ntiles, tile0 + tpb);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j = lane & 15, fr = 4 * wave + (lane >> 4);
+  const int j = lane & 15, fr = 4 * __builtin_amdgcn_readfirstlane(wave) + (lane >> 4);
   const int64_t mo = mix_offs[u], mst = mix_st[u], msf = mix_sf[u];
   const int64_t ko = mask ? mask_offs[us] : 0, kst = mask ? mask_st[u] : 0, ksf = mask ? mask_sf[u] : 0;
   const int64_t oo = out_offs[us];
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(
   }
   // overlap-add roles: thread (m0 = tid & 127, hsel = tid >> 7) produces sample m0 of hops t0 + hsel + 2q, q = 0..7.
   // With all four taps inside [0, T) the window-sum-square is a constant of the thread.
-  const int m0 = tid & (HOP - 1), hsel = tid >> 7;
+  const int m0 = tid & (HOP - 1), hsel = __builtin_amdgcn_readfirstlane(tid >> 7);  // wave-uniform: the slot arithmetic stays scalar
   float wss_full = 0.f;
   __syncthreads();  // win is complete
 #pragma unroll
