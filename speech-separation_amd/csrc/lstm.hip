@@ -1411,8 +1411,6 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
     const bool cellok = owner && unit < H && b < B;
     if (a.final_mm) {
       // gradient wrt the initial state: one more product with the last published dG (s_end == T)
-      float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
-      float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
       const int fs = (a.map & 4) ? FSPREAD : 1;
       const unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS * fs;
       const unsigned xo = (unsigned)(((size_t)((((T - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4);
