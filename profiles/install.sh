@@ -11,4 +11,5 @@ cp $(ls $O/prof_${T}_trace/runc/*kernel_stats.csv | tail -1) profiles/${T}_kerne
 cp $(ls $O/prof_${T}_bf16_trace/runc/*kernel_stats.csv | tail -1) profiles/${T}_bf16_kernel_stats.csv
 python profiles/summarize.py $T $O/prof_${T}_trace $O/prof_${T}_f32_FETCH_SIZE $O/prof_${T}_f32_WRITE_SIZE > profiles/${T}_summary.txt
 python profiles/summarize.py ${T}_bf16 $O/prof_${T}_bf16_trace $O/prof_${T}_bf16_FETCH_SIZE $O/prof_${T}_bf16_WRITE_SIZE > profiles/${T}_bf16_summary.txt
-python profiles/pmc_traffic.py $T | tail -3
+cp $O/pmc_traffic_$T.json profiles/pmc_traffic.json   # made on the box from the same sources (kernel_source_id), before the bench lines
+tail -3 $O/pmc_traffic_$T.txt
