@@ -226,6 +226,13 @@ def test_gemm_stream_k_kernel(ops, M, N, K, tA, tB):
     assert torch.equal(outs[0], outs[1])
     ws = ops.workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), "t_sk_sk")
     assert int(ws[:65536].max()) == 0
+    if M == 5000:      # the other epilogue: sigmoid(product + bias), no accumulate, rows of the result 8 floats apart from N
+        Cw = torch.full((M, N + 8), 7.0).cuda()
+        ops.gemm(dev(A), dev(B), Cw, M, N, K, A.shape[1], B.shape[1], N + 8, transA=tA, transB=tB, bias=dev(bias), act=1, variant=6,
+                 ws_tag="t_sk")
+        want = torch.sigmoid(ref - C0.double())
+        assert float((Cw[:, :N].cpu().double() - want).abs().max()) < 1e-4      # fp32 pre-activations of magnitude sqrt(K)
+        assert bool((Cw[:, N:] == 7).all())
 
 
 def test_gemm_splitk_workspace_from_a_c_caller(ops):
