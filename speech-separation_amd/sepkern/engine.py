@@ -214,7 +214,10 @@ class Engine:
             return
         kind = "rowk" if self.kmajor else "row"            # the same copies serve the backward products K-major
         a, b = self._copy(cache, kind, inp2d), self._copy(cache, kind, w)
-        ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act, streamk=True)
+        # (not the stream-K kernel: with 1400 tiles of 28 K steps its fix-up costs more than the sixth partial round it saves --
+        # main-stream products 3.03 vs 3.11 ms per step; the data gradients' 350 tiles of 112 steps are where it pays)
+        ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act,
+                         streamk=os.environ.get("SEPKERN_BF16_PROJ_SK", "0") == "1")
 
     def _dgrad(self, cache, dout2d, w, out2d, ws_tag):
         """out (R, K) = dout (R, N) w (N, K)."""
