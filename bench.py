@@ -11,6 +11,9 @@ PIT-MSE loss -> full backward -> [N>1: RCCL all-reduce of the flat gradient] -> 
 Workload (BASELINE.json configs[1]): uPIT 3x896 BLSTM, 2 speakers, 512-pt STFT features (257 bins),
 batch 32 x 400 frames PER GPU (weak scaling), fp32.  frames = sum of valid STFT frames per step.
 The features are produced before the timed region by the STFT kernel from synthetic 8 kHz PCM.
+--ragged: the WSJ0-2mix-SHAPED variant of the same workload (SURVEY.md 8d's variable-length set): utterance lengths
+U(24 000, 64 000) samples from a fixed seed, 32 utterances per step, a DIFFERENT batch every step, frames = the valid
+frames only; not the headline line (that stays the T = 400 configuration BASELINE.json quotes the metric on).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline      the dominant kernel (fp32 MFMA GEMM): algorithmic FLOP / HIP-event time, live in the timed region
@@ -54,6 +57,11 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: BASELINE configs[3] arithmetic (bf16 matrix-core inputs for the non-recurrent GEMMs, "
                          "fp32 accumulate); the headline metric is quoted on f32")
+    ap.add_argument("--ragged", action="store_true",
+                    help="variable-length utterances, U(24k, 64k) samples (188..501 frames), a different batch every step")
+    ap.add_argument("--padded-rows", action="store_true",
+                    help="diagnostic A/B for --ragged: run every product and recurrence step over the zero-PADDED (T_max, B) grid "
+                         "(the r03 layout's cost) instead of the packed rows; frames still count the valid ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--aux", action="store_true", help="also time the STFT / iSTFT kernels (extra JSON fields)")
@@ -62,26 +70,37 @@ def parse():
     return ap.parse_args()
 
 
-def make_batch(torch, ops, synth, B, T, S, rank):
-    """Synthetic PCM -> STFT magnitudes on the GPU, time-major (T,B,257), all utterances T frames."""
-    n = 128 * (T - 1) + 64
-    pcms = synth.pcm_batch(B, n_samples=n, num_spk=S, first_utt=rank * B)
+def make_batch(torch, ops, synth, B, T, S, first_utt, nsamp=None, padded_rows=False):
+    """Synthetic PCM -> STFT magnitudes on the GPU as PACKED rows (PackedSequence.data layout, sepkern.packing): mix (R,257),
+    sources [(R,257)], their Packing, the padded mix (T,B,257) and the PCM.  nsamp = None: all utterances T frames; else the
+    per-utterance sample counts (sorted longest first, as the reference's collator sorts a batch, archs/uPIT.py:39)."""
+    from sepkern.packing import Packing
+    if nsamp is None:
+        nsamp = [128 * (T - 1) + 64] * B
+    nsamp = sorted((int(v) for v in nsamp), reverse=True)
+    pcms = synth.pcm_batch(B, num_spk=S, first_utt=first_utt, lengths=nsamp)
+    frames = [1 + n // 128 for n in nsamp]
+    pk = Packing.from_lens(frames, "cuda")
     F = 257
-    feats = []
+    feats, padded_mix = [], None
     for k in range(S + 1):
-        out = torch.zeros(T, B, F, device="cuda")
+        out = torch.zeros(pk.T, B, F, device="cuda")
         ops.stft_batch([torch.from_numpy(p[k]).cuda() for p in pcms], out=out, out_offs=[b * F for b in range(B)],
                        stride_t=[B * F] * B, stride_f=[1] * B)
-        feats.append(out)
-    lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
-    return feats[0], feats[1:], lens, pcms
+        padded_mix = out if k == 0 else padded_mix
+        feats.append(out.view(pk.T * B, F) if padded_rows else pk.pack(out))
+    if padded_rows:        # the network sees B utterances of T_max frames each (zeros past an utterance's end)
+        grid = Packing.from_lens([pk.T] * B, "cuda")
+        grid.R_valid = pk.R
+        pk = grid
+    return feats[0], feats[1:], pk, padded_mix, pcms
 
 
-def cpu_baseline(H, L, S, B, T, budget_s=60.0):
+def cpu_baseline(H, L, S, B, T, budget_s=300.0):
     """The oracle's train step (same torch-CPU ops as the reference loop, steps/train_qsub.py:116-122: nn.LSTM,
     BatchNorm1d, Linear, PIT-MSE, clip_grad_norm_, Adam) timed at the WORKLOAD'S OWN batch shape, B x T frames:
-    up to 3 steps after a short warm-up on a small batch (thread pool, allocator), as many as fit in `budget_s`
-    (at least one)."""
+    3 steps after a short warm-up on a small batch (thread pool, allocator) -- fewer only if the next one
+    would not fit in `budget_s` (at least one); min / median per step reported."""
     import numpy as np
     import torch
     from oracle import upit as OU
@@ -108,15 +127,18 @@ def cpu_baseline(H, L, S, B, T, budget_s=60.0):
     OU.train_step(model, opt, batch(4, 20), model.init_hidden(4))        # warm-up, not the measured shape
     full = batch(B, T)
     t0 = time.time()
-    n = 0
-    # torch's CPU nn.LSTM backward is slow at this size (measured: 84 s per 32 x 400 step on the GPU box's 16-thread
-    # share): one step is the bounded sample then; up to 3 when they fit in `budget_s`
-    while n < 3 and (n == 0 or (time.time() - t0) * (n + 1) / n <= budget_s):
+    per = []
+    # torch's CPU nn.LSTM backward is slow at this size (measured: 76-84 s per 32 x 400 step on the GPU box's 16-thread
+    # share): three steps are about four minutes
+    while len(per) < 3 and (not per or (time.time() - t0) * (len(per) + 1) / len(per) <= budget_s):
+        t1 = time.time()
         OU.train_step(model, opt, full, model.init_hidden(B))
-        n += 1
-    dt = time.time() - t0
+        per.append(time.time() - t1)
+        log("CPU baseline step %d: %.1f s" % (len(per), per[-1]))
+    dt, n = time.time() - t0, len(per)
     return {"value": round(n * B * T / dt, 1), "unit": "frames/s", "cores": threads, "kind": "port",
-            "seconds_per_step": round(dt / n, 2),
+            "seconds_per_step": round(dt / n, 2), "seconds_per_step_min": round(min(per), 2),
+            "seconds_per_step_median": round(sorted(per)[n // 2], 2), "steps": n,
             "sample": "oracle train step (torch-CPU nn.LSTM/BN/Linear + PIT-MSE + clip + Adam), same %dx%d model, the "
                       "workload's own batch of %d x %d frames, %d steps after a small-batch warm-up" % (L, H, B, T, n)}
 
@@ -218,21 +240,40 @@ def main():
     model.hidden_generator = torch.Generator(device="cuda")
     model.hidden_generator.manual_seed(1234 + rank)       # per-rank h0/c0 stream
     opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
-    log("model ready (%dx%d, %d speakers); building the synthetic batch" % (L, H, S))
-    mix, srcs, lens, pcms = make_batch(torch, ops, synth, B, T, S, rank)
-    log("batch resident in HBM: %d x %d frames" % (B, T))
-    frames_per_step = int(lens.sum().item()) * world
+    log("model ready (%dx%d, %d speakers); building the synthetic batch%s" % (L, H, S, "es" if args.ragged else ""))
+    if args.ragged and args.arch != "upit":
+        sys.exit("bench: --ragged is the uPIT workload")
+    import numpy as np
+    if args.ragged:
+        # SURVEY.md 8d's variable-length set: U(24 000, 64 000) samples (3-8 s at 8 kHz = 188..501 frames), fixed seed; one
+        # batch per step of the run, all of them resident in HBM before the timed region starts
+        rng = np.random.default_rng(2024 + rank)
+        n_batches = min(64, args.steps + args.warmup)
+        pool = [make_batch(torch, ops, synth, B, T, S, (rank * n_batches + i) * B, nsamp=rng.integers(24000, 64001, B),
+                           padded_rows=args.padded_rows) for i in range(n_batches)]
+    else:
+        pool = [make_batch(torch, ops, synth, B, T, S, rank * B)]
+    pcms, mix_padded = pool[0][4], pool[0][3]
+    log("%d batch(es) resident in HBM: %d utterances, %s frames each" %
+        (len(pool), B, "/".join(str(b[2].R) for b in pool[:4]) + ("/..." if len(pool) > 4 else "")))
     loss_acc = torch.zeros(2, device="cuda")
+    counters = {"i": 0, "frames": 0, "T": 0}
 
     if args.arch == "rsh":
-        combos = torch.cat([mix, torch.ones_like(mix)], 2).contiguous()        # [mixture | attention = 1] (archs/RSH.py:104-106)
-        groups = [(S, combos, srcs, lens)]
+        lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
+        srcs_padded = [pool[0][2].unpack(s_) for s_ in pool[0][1]]
+        combos = torch.cat([mix_padded, torch.ones_like(mix_padded)], 2).contiguous()   # [mixture | attention = 1] (archs/RSH.py:104-106)
+        groups = [(S, combos, srcs_padded, lens)]
 
     def step():
+        mix, srcs, pk = pool[counters["i"] % len(pool)][:3]
+        counters["i"] += 1
+        counters["frames"] += getattr(pk, "R_valid", pk.R)
+        counters["T"] += pk.T
         if args.arch == "rsh":
             loss, norm = arch_mod.compute_loss_padded(model, groups)
         else:
-            loss, norm = uPIT.compute_loss_padded(model, mix, srcs, lens)
+            loss, norm = uPIT.compute_loss_packed(model, mix, srcs, pk)   # packed rows, as the collator's PackedSequences hold them
         loss_acc[0] += loss.detach() * norm               # epoch loss bookkeeping stays on the device
         loss_acc[1] += norm
         loss.backward()
@@ -270,6 +311,7 @@ def main():
         ops.PROF = {}
     if world > 1:
         skdist.TIMING = []
+    counters["frames"] = counters["T"] = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -278,6 +320,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    frames_timed, T_mean = counters["frames"], counters["T"] / float(args.steps)     # this rank's valid frames in the timed region
     log("timed region done: %.3f ms/step" % (1000.0 * dt / args.steps))
     prof = ops.prof_summary()
     ops.PROF = None
@@ -315,7 +358,15 @@ def main():
         mine_dev = torch.tensor([h], device="cuda", dtype=torch.int64)
         every_dev = [torch.zeros_like(mine_dev) for _ in range(world)]
         dist.all_gather(every_dev, mine_dev)
+        fr = torch.tensor([frames_timed], device="cuda", dtype=torch.int64)
+        dist.all_reduce(fr)
+        frames_timed = int(fr.item())
+        # per-rank recurrence mode: a rank that fell back to per-step launches sets the pace of the whole job
+        fb = torch.tensor([1 if model._engine.lstm_mode == 2 else 0], device="cuda", dtype=torch.int64)
+        every_fb = [torch.zeros_like(fb) for _ in range(world)]
+        dist.all_gather(every_fb, fb)
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "lstm_per_step_launches_by_rank": [int(t.item()) for t in every_fb],
                      "distinct_devices": len({int(t.item()) for t in every_dev}),
                      "launcher": os.environ.get("SEPKERN_BENCH_LAUNCHER", "external (torch.distributed.run)"),
                      "grad_allreduce": skdist.overlap_mode_name(),
@@ -325,6 +376,7 @@ def main():
                      "allreduce_busbw_GBs": round(2.0 * (world - 1) / world * model._engine.grad_full.numel() * 4 /
                                                   (ar_ms * 1e-3) / 1e9, 1) if ar_ms > 0 else None}
         dt = max(per_rank)
+    frames_per_step = frames_timed / float(args.steps)                               # all ranks
     final_loss = float(loss_acc[0] / loss_acc[1])
     if not (final_loss == final_loss) or final_loss <= 0:
         sys.exit("bench: loss is not finite/positive (%r)" % final_loss)
@@ -339,9 +391,14 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("RSH %dx%d BLSTM over [mix|attention], %d-spk (%d passes per step), " % (L, H, S, S)
                                 if args.arch == "rsh" else "uPIT %dx%d BLSTM, %d-spk, " % (L, H, S)) +
-                               "512-pt STFT (257 bins), batch %d x %d frames per GPU, fwd + %s + bwd + clip 0.25 + Adam, "
-                               "random-init weights" % (B, T, "greedy-assignment MSE" if args.arch == "rsh" else "PIT-MSE"),
-                   "global_batch": B * world, "frames_per_step": frames_per_step,
+                               "512-pt STFT (257 bins), batch %s per GPU, fwd + %s + bwd + clip 0.25 + Adam, random-init weights" %
+                               (("%d utterances of U(24000, 64000) samples = 188..501 frames (mean %.0f valid frames per step, "
+                                 "longest %.0f on average), a different batch every step, %s" %
+                                 (B, frames_per_step / world, T_mean, "zero-PADDED rows (diagnostic)" if args.padded_rows else "packed rows"))
+                                if args.ragged else "%d x %d frames" % (B, T),
+                                "greedy-assignment MSE" if args.arch == "rsh" else "PIT-MSE"),
+                   "numerics": numerics_note(model, args),
+                   "global_batch": B * world, "frames_per_step": round(frames_per_step, 1),
                    "parallelism": "dp%d" % world if world > 1 else "single",
                    "mean_loss": round(final_loss, 6)},
     }
@@ -351,7 +408,7 @@ def main():
         res["lstm_fallback"] = lstm_fallback
     if prof:
         kname = "gemm_f32_kernel"
-        if args.dtype == "bf16":     # bf16 operand copies + the NT kernel unless SEPKERN_BF16_NT=0 selects the r01 kernel
+        if args.dtype == "bf16":     # bf16 operand copies + the NT kernel (hidden sizes that are no multiple of 8: the r01 kernel)
             kname = "gemm_bf16_nt_kernel" if any(k.startswith("gemm_bf16_nt_kernel") for k in prof) else "gemm_bf16_kernel"
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         # launches recorded on the side stream are the weight-gradient GEMMs that the engine co-schedules with the
@@ -392,7 +449,7 @@ def main():
             row = {"launches_per_step": v[0] // args.steps, "avg_launch_ms": round(v[1] / v[0], 4),
                    "ms_per_step": round(v[1] / args.steps, 3), "achieved": round(a_, 2), "frac": round(a_ / peak, 4)}
             if k.startswith("lstm_"):
-                us = 1e3 * v[1] / v[0] / T
+                us = 1e3 * v[1] / v[0] / T_mean
                 # per workgroup and time step: 16 batch rows x 64 gate columns x H, on 4 SIMDs
                 floor = (2.0 * 16 * 64 * H / 4) / (64.0 if args.dtype != "bf16" else 1024.0) / 2.4e3
                 row.update({"us_per_time_step": round(us, 3), "mfma_floor_us": round(floor, 3),
@@ -408,7 +465,7 @@ def main():
         res["step_tflops"] = round(6.0 * P * frames_per_step / world / (dt / args.steps) / 1e12, 2)
         res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / peak, 4)   # the compute dtype's dense MFMA peak
     if args.aux and rank == 0:
-        res["aux"] = aux_kernels(torch, ops, pcms, mix, T, B, S)
+        res["aux"] = aux_kernels(torch, ops, pcms, T_mean, B, S)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (bounded sample)")
         res["cpu_baseline"] = cpu_baseline(H, L, S, B, T)
@@ -447,11 +504,22 @@ def pmc_traffic(kernel):
         return None
 
 
-def aux_kernels(torch, ops, pcms, mix, T, B, S):
+def numerics_note(model, args):
+    """What the `dtype` field does not say (a reader of "f32" is owed this)."""
+    eng = model._engine
+    if args.dtype == "bf16":
+        return "bf16 matrix-core inputs for every product incl. the recurrences, fp32 accumulate / state / optimizer"
+    if eng is not None and eng.tagged_fwd and eng.lstm_mode != 2:
+        return ("fp32 throughout; forward-recurrence hand-off 'tagged': the operand h entering h W_hh^T carries a 2-bit epoch "
+                "in its low mantissa bits (<= 3 ulp), all stored values exact; SEPKERN_LSTM_FWD=0,1,1,0,0,0,0 = exact hand-off")
+    return "fp32 throughout, exact hand-off (flags)"
+
+
+def aux_kernels(torch, ops, pcms, T, B, S):
     """HBM-bound front/back ends: STFT (train layout) and mask-apply + iSTFT, GB/s of algorithmic bytes."""
     wavs = [torch.from_numpy(p[k]).cuda() for p in pcms for k in range(S + 1)]
     specs = ops.stft_batch([torch.from_numpy(p[0]).cuda() for p in pcms], want_complex=True, layout="FT")
-    masks = [[torch.rand(257, T, device="cuda") for _ in range(S)] for _ in pcms]
+    masks = [[torch.rand(257, sp.shape[1], device="cuda") for _ in range(S)] for sp in specs]
     out = {}
 
     def timeit(fn, n=20):
@@ -465,12 +533,13 @@ def aux_kernels(torch, ops, pcms, mix, T, B, S):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
     ms = timeit(lambda: ops.stft_batch(wavs, want_complex=False, layout="TF"))
-    nfr = T * B * (S + 1)
+    utt_frames = sum(1 + len(p[0]) // 128 for p in pcms)
+    nfr = utt_frames * (S + 1)
     by = nfr * (128 * 2 + 257 * 4)
     out["stft_mag"] = {"ms_incl_host": round(ms, 4), "frames_per_s": round(nfr / ms * 1e3), "GBs_algorithmic": round(by / ms / 1e6, 1)}
     ms = timeit(lambda: ops.mask_istft(specs, masks, want_float=False))
-    by = T * B * S * (257 * 8 + 257 * 4 + 128 * 2)
-    out["mask_istft"] = {"ms_incl_host": round(ms, 4), "frames_per_s": round(T * B * S / ms * 1e3), "GBs_algorithmic": round(by / ms / 1e6, 1)}
+    by = utt_frames * S * (257 * 8 + 257 * 4 + 128 * 2)
+    out["mask_istft"] = {"ms_incl_host": round(ms, 4), "frames_per_s": round(utt_frames * S / ms * 1e3), "GBs_algorithmic": round(by / ms / 1e6, 1)}
     return out
 
 

@@ -11,7 +11,9 @@
  *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
  *     buffer (the library allocates nothing); workspace sizes are queried
  *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*)
- *   - tensors are row-major contiguous fp32; sequence tensors are time-major (T, B, C)
+ *   - tensors are row-major contiguous fp32; sequence tensors are time-major, either zero-padded (T, B, C) or
+ *     PACKED as torch's PackedSequence.data holds them (see "packed rows" below): every sequence entry point takes an
+ *     offset table `offs` (NULL = padded)
  *   - LSTM weight layout is torch's per-parameter layout (gate rows i,f,g,o), so a
  *     reference state_dict round-trips unchanged
  */
@@ -25,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 113
+#define SK_VERSION 120
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -88,12 +90,12 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * the recurrence more of the matrix pipe); 2 = exact three-way bf16 split of both operands on the bf16 matrix pipe
  * (nine exact piece products per element pair, fp32 accumulators: an fp32 product in another summation order; power-
  * bound on MI355X, opt-in); 3 = the 128 x 128-tile LDS-DMA kernel wherever it applies, 4 = its 256 x 128-tile, 8-wave form
- * wherever that applies (diagnostics; 0 picks among 1, 3 and 4 by shape); 5 = 256 x 256 tiles, one workgroup per CU
- * (unsplit products; opt-in for variant 0 by SEPKERN_GEMM_SQUARE=1); 6 = the same kernel PERSISTENT with a stream-K cut
- * of the last partial round of tiles (unsplit, unbatched products; splitk = 1 and ws >= sk_gemm_streamk_workspace_bytes(),
- * zero-filled before its first use and left with zeroed counters by every launch; without ws it is variant 5; variant 0
- * chooses it for the large N/T and N/N products when splitk = 1 and a ws is given, SEPKERN_GEMM_STREAMK=0: never).  Tiles of the cut are summed piece by piece in a fixed order:
- * deterministic, fp32 summation order differs from the other variants. */
+ * wherever that applies (diagnostics; 0 picks among 1, 3 and 4 by shape); 6 = 256 x 256 tiles, one PERSISTENT workgroup
+ * per CU with a stream-K cut of the last partial round of tiles (unsplit, unbatched products; splitk = 1 and
+ * ws >= sk_gemm_streamk_workspace_bytes(), zero-filled before its first use and left with zeroed counters by every
+ * launch; without ws it is variant 4; variant 0 chooses it for the large N/T and N/N products when splitk = 1 and a ws
+ * is given, SEPKERN_GEMM_STREAMK=0: never).  Tiles of the cut are summed piece by piece in a fixed order: deterministic,
+ * fp32 summation order differs from the other variants.  (5 was the same tile without the stream-K cut: retired in r04.) */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 size_t sk_gemm_streamk_workspace_bytes(void);
 /* Zero the ticket counters at the head of a split-K workspace (once, before its first use; a buffer that was allocated
@@ -114,8 +116,8 @@ int sk_gemm_bf16_splitk(const float* A, const float* B, float* C, const float* b
 
 /* bf16 operands IN MEMORY, both K-contiguous ("NT"): C[M,N] = act(A[M,K] B[N,K]^T + bias (+ C)), A and B bf16
  * (row-major, leading dimensions lda, ldb in elements), C / bias / slabs fp32.  The form every product of the bf16
- * configuration is brought to by writing bf16 copies of the operands (sk_cast_bf16, or sk_cast_bf16_t where the
- * product needs the transpose).  Requirements: K % 64 == 0 (pad the copies with zero columns), lda, ldb, sA, sB
+ * configuration is brought to by writing row-major bf16 copies of the operands (sk_cast_bf16_rows; a factor whose rows
+ * are the contraction index enters sk_gemm_bf16_mm K-major, so no transposed copy exists).  Requirements: K % 64 == 0 (pad the copies with zero columns), lda, ldb, sA, sB
  * multiples of 8, A and B 16-byte aligned; rows are read up to K.  M and N are arbitrary.  splitk / ws / batch /
  * accumulate / act as sk_gemm_f32_splitk. */
 int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
@@ -137,20 +139,39 @@ int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const float* bias, i
 int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                     int ldc, int a_kmajor, int b_kmajor, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                     int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream);
-/* dst[r][c] = bf16(src[r][c]) (round to nearest even) for c < C, 0 for C <= c < ld_dst; ld_dst % 8 == 0. */
-int sk_cast_bf16(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream);
-/* The same with R_pad >= R rows written, rows R .. R_pad-1 zero: a copy that also serves as a K-MAJOR factor of
- * sk_gemm_bf16_mm (its rows are then the contraction index, read in whole K steps of 64 and, in the time-shifted
- * recurrent weight gradient, a few rows past the end). */
+/* dst[r][c] = bf16(src[r][c]) (round to nearest even) for r < R, c < C; 0 for C <= c < ld_dst and for the rows
+ * R .. R_pad-1 (R_pad >= R): a copy that also serves as a K-MAJOR factor of sk_gemm_bf16_mm (its rows are then the
+ * contraction index, read in whole K steps of 64).  ld_dst % 8 == 0. */
 int sk_cast_bf16_rows(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, int R_pad, sk_stream_t stream);
-/* dst[c][r] = bf16(src[r][c]) for r < R, 0 for R <= r < ld_dst: the transposed copy, (C, ld_dst) row-major. */
-int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream);
+
+/* ---------------------------------------------------------------- packed rows
+ * The reference feeds the network a torch PackedSequence (archs/uPIT.py:46,132,135): of a length-sorted batch only the
+ * R = sum(lens) valid frames exist, time-major: row of (t, j) is offs[t] + j for j < n_t, where n_t = offs[t+1] - offs[t]
+ * is the number of utterances longer than t (offs has T+1 int32 entries, offs[0] = 0, offs[T] = R; lens[j] sorted
+ * descending, lens[0] = T).  Entry points that take `offs` work on that layout; offs = NULL means zero-padded (T, B, C).
+ * sk_pack_rows / sk_unpack_rows convert (perm, may be NULL: sorted position j is the caller's utterance perm[j]);
+ * unpack writes zeros at the padded positions, or the row `fill` (C floats; may be NULL) -- the value the reference's
+ * network shows at a zero-padded frame, sigmoid(lin(bn(0))), archs/uPIT.py:135-144.  ld_packed >= C is the packed
+ * matrix's leading dimension. */
+int sk_pack_rows(const float* padded, const int32_t* offs, const int32_t* perm, int T, int B, int C, float* packed,
+                 int ld_packed, sk_stream_t stream);
+int sk_unpack_rows(const float* packed, int ld_packed, const int32_t* offs, const int32_t* perm, int T, int B, int C,
+                   const float* fill, float* padded, sk_stream_t stream);
+/* The recurrent INPUT of every packed row of one BLSTM layer: out[r][0:H] = forward-direction output of the same
+ * utterance one frame earlier (h0[0][j] at t = 0), out[r][H:2H] = reverse-direction output one frame later (h0[1][j] at the
+ * utterance's last frame); y (R, ldy >= 2H) is the layer output, h0 (2, B, H).  With it the recurrent weight gradient is a
+ * plain product over the packed rows, dW_hh[d] = dG[:, d]^T out[:, d-half] (in the padded layout the shift was a constant
+ * B rows; packed it varies with t).  out_bf16 != 0: out is bf16 (the operand copy of the bf16 configuration). */
+int sk_hprev_rows(const float* y, int ldy, const float* h0, const int32_t* offs, int T, int B, int H, void* out,
+                  int ld_out, int out_bf16, sk_stream_t stream);
 
 /* ---------------------------------------------------------------- BLSTM recurrence
  * One bidirectional LSTM layer's time recurrence (the part of nn.LSTM, reference
- * archs/uPIT.py:115,132, that cannot be batched over time), with packed-sequence semantics
- * on padded input: for row b the state is frozen and y is 0 at t >= lens[b]; the reverse
- * direction starts from (h0,c0) at t = lens[b]-1.
+ * archs/uPIT.py:115,132, that cannot be batched over time), with packed-sequence semantics:
+ * for row b the state is frozen at t >= lens[b]; the reverse direction starts from (h0,c0) at t = lens[b]-1.
+ * Sequence tensors below are written (T,B,..) for the padded layout (offs = NULL; y is then 0 at t >= lens[b]); with
+ * `offs` they are the R packed rows ("packed rows" above; lens sorted descending) and positions past a row's end do
+ * not exist -- nothing is read or written there.
  *   gx    (T,B,2,4H)  input projections x*W_ih^T + b_ih + b_hh for both directions, GATE-INTERLEAVED: within a
  *                     direction's 4H values, element 4u + g is gate g (i,f,g,o) of hidden unit u -- the four gates
  *                     of a cell are one 16-byte access (torch keeps the rows of W_ih gate-major, g H + u:
@@ -168,72 +189,37 @@ int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld
  * inputs (this one IS arithmetic: BASELINE configs[3]); bit 17 8-unit / 256-thread workgroups, two per CU; bits 18..19
  * block id -> stream map; bit 20 one polling wave per workgroup; bit 21 flags replicated per XCD; bit 22 one flag per
  * 128-byte line; bits 23..27 hold-back of a step's first poll in units of 0.1 us (0 = the library's choice, 31 = none);
- * bit 28 (forward, fp32): two streams per workgroup -- a workgroup owns 8 hidden units x 16 batch rows of BOTH
- * directions and works on one direction's step while the other direction's h_t travels (lstm_fwd2_kernel) -- taken
- * where the shape allows it (H padded to 320 / 896 / 1024, 2 * ceil(H/8)-ish workgroups per 16 rows co-resident),
- * otherwise the call silently uses the one-stream kernel; results differ from it by the rounding of summing four K
- * quarters instead of two K halves;
- * bit 29 (fp32; forward and backward): "the data is the flag" -- every exchanged word (h_t forward, dG_t backward) carries
- * the step's epoch in its two low mantissa bits, producers publish without drain / barrier / flag, consumers hold back,
- * pull, check every word and pull again what was not complete; the next step's product runs on the tagged words (<= 3 ulp
- * = 3.6e-7 relative), everything stored (y, gates, cs, dgx, states) is exact.  The exchange buffers of the workspace are
- * zeroed by a call that starts a sequence (s_begin == 0).  The engine ships it for the fp32 forward recurrence. */
+ * bit 29 (fp32 forward): "the data is the flag" -- every exchanged h word carries the step's epoch in its two low mantissa
+ * bits, producers publish without drain / barrier / flag, consumers hold back, pull, check every word and pull again
+ * what was not complete; the next step's product runs on the tagged words (<= 3 ulp = 3.6e-7 relative), everything stored
+ * (y, gates, cs, states) is exact.  The engine ships it for the fp32 forward recurrence and says so in bench.py's line
+ * (config.numerics); SEPKERN_LSTM_FWD=0,1,1,0,0,8,0,0 selects the exact hand-off. */
 size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
-                float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
+                const int32_t* offs, float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
                 int T, int B, int H, int mode, sk_stream_t stream);
-/* The same for processing steps [s_begin, s_end) only (0 <= s_begin < s_end <= T; the forward direction works on
- * t = s, the reverse one on t = T-1-s): a sequence may be advanced by several calls on the SAME workspace, with no
- * other recurrence call in between -- the state travels through the workspace; hn / cn are written by the call that
- * ends at T.  After a call that ends at s_end < T, y[t] is final for t < s_end in the forward half and for
- * t >= T - s_end in the reverse half: the caller can start consuming those rows (the next layer's input projection)
- * while a second call finishes the sequence. */
-int sk_lstm_fwd_range(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
-                      float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
-                      int T, int B, int H, int mode, int s_begin, int s_end, sk_stream_t stream);
-/* Backward of the recurrence.  dy (T,B,2H) is the gradient of the layer output; produces
- * dgx (T,B,2,4H) = gradient of the gate pre-activations (gate-interleaved like gx; zero at padded positions), from which
- * the caller forms dW_ih, dW_hh, db and dx with sk_gemm_f32 / sk_colsum, and dh0/dc0 (2,B,H; may
- * be NULL).  gates / cs are what sk_lstm_fwd saved; dgx may alias gates (each cell is read, then overwritten, by
- * the same lane). */
-int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs,
-                const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0, void* ws,
-                int T, int B, int H, int mode, sk_stream_t stream);
-/* Same, with the gradient wrt the final state (dhn, dcn: (2,B,H), either may be NULL = 0) as an extra input:
- * needed when hn/cn feed a later computation (the RSH arch carries the hidden state from pass to pass,
- * reference archs/RSH.py:172), and two optional by-products that spare the caller a pass over dgx each:
+/* Backward of the recurrence.  dy (T,B,2H) is the gradient of the layer output, dhn / dcn (2,B,H; either may be NULL = 0)
+ * the gradient wrt the final state (the RSH arch carries the hidden state from pass to pass, reference archs/RSH.py:172);
+ * produces dgx (T,B,2,4H) = gradient of the gate pre-activations (gate-interleaved like gx; padded layout: zero at padded
+ * positions), from which the caller forms dW_ih, dW_hh (with sk_hprev_rows), db and dx with the GEMMs, and dh0/dc0
+ * (2,B,H; may be NULL).  gates / cs are what sk_lstm_fwd saved; dgx may alias gates (each cell is read, then
+ * overwritten, by the same lane).  Optional by-products that spare the caller a pass over dgx each:
  *   dbias    (ceil(B/16), 2, 4H)  partial sums of dG over (t, b), one row per 16-row batch group block of the
  *            grid (unused rows are 0): their column sum is the gradient of b_ih and of b_hh;
- *   dg_first (2, B, 4H)  dG of every row's FIRST recurrent step -- forward direction t = 0, reverse direction
- *            t = lens[b]-1 -- the only steps whose recurrent input is h0 instead of a stored output:
- *            dW_hh[d] = dgx[1:, :, d]^T y[:-1, :, d-half]  (time-shifted, d = 0; mirrored for d = 1)
- *                     + dg_first[d]^T h0[d]. */
-int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
-                      const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
-                      float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, sk_stream_t stream);
-/* The same over the processing steps [s_begin, s_end) only (step s is time T-1-s for the forward direction, s for the
- * reverse one): consecutive calls on one workspace advance one sequence (the carried gradients travel through ws), dbias
- * accumulates over the calls, dh0 / dc0 / dg_first are produced by the call whose range ends at T.  After s steps the
- * rows t >= T-s of the forward direction's dgx and the rows t < s of the reverse direction's are final -- the engine
- * starts their weight-gradient products beside the remaining steps. */
-int sk_lstm_bwd_range(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
-                      const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
-                      float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, int s_begin, int s_end,
-                      sk_stream_t stream);
-/* sk_lstm_bwd_range that ALSO writes dgx as bf16 (r03, the bf16 configuration): dgx_bf16[(t B + b) ld_bf16 + d 4H + 4u + g],
- * the row-major operand copy the layer's data- and weight-gradient products read, so that no cast pass over dgx runs between
- * the recurrence and those products.  ld_bf16 >= 8H, a multiple of 4; only the (T B) x 8H entries are written: padding
- * columns / rows a product expects to be zero are the caller's.  dgx_bf16 = NULL: exactly sk_lstm_bwd_range. */
-int sk_lstm_bwd_twin(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
-                     const float* cs, const float* c0, const int32_t* lens, float* dgx, float* dh0, float* dc0,
-                     float* dbias, float* dg_first, void* ws, int T, int B, int H, int mode, int s_begin, int s_end,
-                     void* dgx_bf16, int ld_bf16, sk_stream_t stream);
+ *   dgx_bf16 (the bf16 configuration) dgx a second time as bf16, dgx_bf16[row ld_bf16 + d 4H + 4u + g]: the row-major
+ *            operand copy the layer's data- and weight-gradient products read, so that no cast pass over dgx runs between
+ *            the recurrence and those products.  ld_bf16 >= 8H, a multiple of 4; only the rows x 8H entries are written:
+ *            padding columns / rows a product expects to be zero are the caller's. */
+int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
+                const float* cs, const float* c0, const int32_t* lens, const int32_t* offs, float* dgx, float* dh0,
+                float* dc0, float* dbias, void* dgx_bf16, int ld_bf16, void* ws, int T, int B, int H, int mode,
+                sk_stream_t stream);
 /* Reorder the rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g H + u inside each block of 4H
  * rows) and the gate-interleaved order of gx / gates / dgx (row 4u + g).  back = 0: dst[4u+g] = src[gH+u] (weights,
  * biases -> interleaved); back = 1: dst[gH+u] (+)= src[4u+g] (weight gradients back to the parameter order,
  * optionally accumulating).  Rows are ld_src / ld_dst floats apart (>= C); without `accumulate`, columns C..ld_dst-1
  * of the destination are zeroed, so a copy with a padded leading dimension (257 -> 260: 16-byte aligned rows for
- * the GEMMs) is made in the same pass.  dbias of sk_lstm_bwd_state is already gate-major. */
+ * the GEMMs) is made in the same pass.  dbias of sk_lstm_bwd is already gate-major. */
 int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int ld_src, int ld_dst, int back, int accumulate,
                  sk_stream_t stream);
 /* Word 0 of the workspace is a STICKY status word: a launch whose bounded spin gave up sets it (no launch clears
@@ -242,18 +228,23 @@ int sk_gate_rows(const float* src, float* dst, int nblk, int H, int C, int ld_sr
  * sk_lstm_status: 0, or SK_ETIMEOUT if a launch since the last call timed out (reads the word back to the host,
  * synchronises the stream, clears the word). */
 int sk_lstm_status(void* ws, sk_stream_t stream);
-/* dst (R, ld_dst) = src (R, C; rows ld_src floats apart) with columns C..ld_dst-1 zero: the copy of the F = 257 input
- * features with rows padded to 260 floats (16-byte aligned rows for both operands of the layer-0 products). */
-int sk_pad_rows(const float* src, int64_t R, int C, int ld_src, float* dst, int ld_dst, sk_stream_t stream);
+/* dst (R_pad, ld_dst) = src (R, C; rows ld_src floats apart) with columns C..ld_dst-1 and rows R..R_pad-1 zero: the copy of
+ * the F = 257 input features with rows padded to 260 floats (16-byte aligned rows for both operands of the layer-0 products)
+ * and the row count rounded up to whole K steps of the weight-gradient product. */
+int sk_pad_rows(const float* src, int64_t R, int C, int ld_src, float* dst, int ld_dst, int64_t R_pad, sk_stream_t stream);
 /* ---------------------------------------------------------------- BatchNorm1d over (rows, C)
- * Replaces nn.BatchNorm1d(2H) on (B, 2H, T) (reference archs/uPIT.py:119,138): statistics over
- * ALL rows = B*T_max positions, zero-padded frames included.
- * stats: mean[c], var[c] (biased) over R rows (two-pass); ws >= sk_bn_workspace_bytes(R,C). */
+ * Replaces nn.BatchNorm1d(2H) on (B, 2H, T) (reference archs/uPIT.py:119,135-138): statistics over
+ * ALL count = B*T_max positions, zero-padded frames included.
+ * stats: mean[c], var[c] (biased, two-pass) over `count` rows of which the first R are stored in x and the other
+ * count - R are zero rows that are not (packed rows: count = B*T_max, R = sum(lens); padded: count = R);
+ * ws >= sk_bn_workspace_bytes(R,C). */
 size_t sk_bn_workspace_bytes(int R, int C);
-int sk_bn_stats(const float* x, int R, int C, float* mean, float* var, void* ws, sk_stream_t stream);
-/* running = (1-momentum)*running + momentum*batch (var unbiased, n/(n-1)), as torch does */
+int sk_bn_stats(const float* x, int R, int C, int64_t count, float* mean, float* var, void* ws, sk_stream_t stream);
+/* running = (1-momentum)*running + momentum*batch (var unbiased, count/(count-1)), as torch does.  guard (may be NULL):
+ * a device word, non-zero = leave the running statistics alone (the recurrence's sticky status word, sk_lstm_status:
+ * after a timed-out launch the batch statistics are garbage and must not reach a checkpoint). */
 int sk_bn_update_running(const float* mean, const float* var, float* running_mean, float* running_var,
-                         int R, int C, float momentum, sk_stream_t stream);
+                         int64_t count, int C, float momentum, const void* guard, sk_stream_t stream);
 /* out = (x - mean) / sqrt(var + eps) * gamma + beta */
 int sk_bn_apply(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                 float* out, int R, int C, float eps, sk_stream_t stream);
@@ -285,7 +276,8 @@ int sk_sigmoid_bwd(const float* dmask, const float* m, float* dz, int64_t n, sk_
 
 /* ---------------------------------------------------------------- PIT-MSE loss
  * Replaces the loss body of compute_loss (reference archs/uPIT.py:181-197,206).
- *   mask (T,B,S*F), mix (T,B,F), src_host[s] -> (T,B,F) device pointers (host array of S), lens (B)
+ *   mask (T,B,S*F), mix (T,B,F), src_host[s] -> (T,B,F) device pointers (host array of S), lens (B);
+ *   with offs != NULL all of them are packed rows (R, .) -- PackedSequence.data as the collator built it
  *   pair_sse (B,S,S): pair[b][s][r] = sum_{t,f} (mask[t,b,s,f]*mix[t,b,f] - src_r[t,b,f])^2
  *   perm_loss (S!,B) in itertools.permutations order; best_perm (B) = argmin (first minimum)
  *   out[0] = loss/norm, out[1] = norm = sum(lens)*F, out[2] = sum_b min loss / S
@@ -293,11 +285,12 @@ int sk_sigmoid_bwd(const float* dmask, const float* m, float* dz, int64_t n, sk_
  * GLOBAL norm, all-reduced on the device without a host round trip. */
 size_t sk_pit_workspace_bytes(int T, int B, int S);
 int sk_pit_mse_fwd(const float* mask, const float* mix, const float* const* src_host, const int32_t* lens,
-                   int T, int B, int F, int S, const float* norm_dev, float* pair_sse, float* perm_loss,
-                   int32_t* best_perm, float* out, void* ws, sk_stream_t stream);
-/* dmask = gscale[0] * 2 * (mask*mix - src_{best_perm[b][s]}) * mix / (S * norm), norm = out[1] */
+                   const int32_t* offs, int T, int B, int F, int S, const float* norm_dev, float* pair_sse,
+                   float* perm_loss, int32_t* best_perm, float* out, void* ws, sk_stream_t stream);
+/* dmask = gscale[0] * 2 * (mask*mix - src_{best_perm[b][s]}) * mix / (S * norm), norm = out[1]; nrows = packed rows R
+ * (ignored when offs == NULL) */
 int sk_pit_mse_bwd(const float* mask, const float* mix, const float* const* src_host,
-                   const int32_t* best_perm, const float* out, const float* gscale,
+                   const int32_t* best_perm, const float* out, const float* gscale, const int32_t* offs, int64_t nrows,
                    int T, int B, int F, int S, float* dmask, sk_stream_t stream);
 
 /* ---------------------------------------------------------------- RSH arch (reference archs/RSH.py)

@@ -47,7 +47,8 @@ except ImportError:  # the frozen copy exp/<...>/arch.py is imported from anothe
     import sepkern  # noqa: F401
 from sepkern import dist as skdist
 from sepkern import ops
-from sepkern.model import SepDNNBase, to_padded as _to_padded
+from sepkern.model import SepDNNBase, to_packed as _to_packed
+from sepkern.packing import Packing
 from sepkern._lib import SepkernError
 
 
@@ -179,29 +180,32 @@ class WavCollator():
 
 
 def _features_from_pcm(pcm, dev):
-  """{'mix': [int16 (N_b,)], 'source1': ...} -> mix (T,B,F), sources [(T,B,F)], lens: STFT magnitudes on the GPU."""
+  """{'mix': [int16 (N_b,)], 'source1': ...} (length-sorted, as WavCollator leaves them) -> mix (R,F), sources [(R,F)]
+  packed rows and their Packing: STFT magnitudes on the GPU (sk_stft into the (T,B,F) grid, then the valid rows)."""
   B = len(pcm['mix'])
   F = 257
   Ts = [1 + int(w.numel()) // 128 for w in pcm['mix']]
   T = max(Ts)
+  pk = Packing.from_lens(Ts, dev)
   keys = ['mix'] + sorted(k for k in pcm if k != 'mix')
   feats = {}
   for k in keys:
     out = torch.zeros(T, B, F, device=dev)
     ops.stft_batch([w.to(dev, non_blocking=True) for w in pcm[k]], out=out, out_offs=[b * F for b in range(B)],
                    stride_t=[B * F] * B, stride_f=[1] * B)
-    feats[k] = out
-  lens = torch.tensor(Ts, dtype=torch.int32, device=dev)
-  return feats['mix'], [feats[k] for k in keys[1:]], lens
+    feats[k] = pk.pack(out)
+  return feats['mix'], [feats[k] for k in keys[1:]], pk
 
 
 class _PitFn(torch.autograd.Function):
   """out = [loss/norm, norm, sum_b min_p L/S] (reference archs/uPIT.py:181-197,206)."""
 
   @staticmethod
-  def forward(ctx, mask, mix, lens, norm_dev, *srcs):
-    res = ops.pit_mse_fwd(mask, mix, list(srcs), lens, norm_dev)
+  def forward(ctx, mask, mix, pk, norm_dev, *srcs):
+    # mask (R, S*F), mix / srcs (R, F): packed rows of the batch pk (PackedSequence.data, archs/uPIT.py:160-167)
+    res = ops.pit_mse_fwd(mask, mix, list(srcs), None, norm_dev, packing=pk)
     ctx.save_for_backward(mask, mix, res["best_perm"], res["out"], *srcs)
+    ctx.pk = pk
     ctx.mark_non_differentiable(res["best_perm"])
     return res["out"], res["best_perm"]
 
@@ -209,7 +213,7 @@ class _PitFn(torch.autograd.Function):
   def backward(ctx, gout, _gperm):
     mask, mix, best, out = ctx.saved_tensors[:4]
     srcs = list(ctx.saved_tensors[4:])
-    dmask = ops.pit_mse_bwd(mask, mix, srcs, best, out, gout[0:1].contiguous())
+    dmask = ops.pit_mse_bwd(mask, mix, srcs, best, out, gout[0:1].contiguous(), packing=ctx.pk)
     return (dmask, None, None, None) + (None,) * len(srcs)
 
 
@@ -225,6 +229,13 @@ class SepDNN(SepDNNBase):
     self._build(gpuid, self.feat_dim, self.feat_dim * self.num_spk, int(kwargs.get('hidden_dim', 600)),
                 int(kwargs.get('num_layers', 2)), str(kwargs.get('dtype', 'fp32')), kwargs.get('sync_bn', '0'))
 
+  def forward_packed(self, x2d, pk):
+    """x2d (R,F) packed rows of the batch pk (PackedSequence.data on the GPU) -> mask (R,F*S) packed."""
+    if self.hidden is None:
+      self.hidden = self.init_hidden(pk.B)
+    h0, c0 = self.hidden
+    return self.run_net_packed(x2d, pk, h0, c0)
+
   def forward_padded(self, x, lens):
     """x (T,B,F) time-major zero-padded CUDA tensor, lens int32 CUDA (B) -> mask (T,B,F*S)."""
     if self.hidden is None:
@@ -234,8 +245,10 @@ class SepDNN(SepDNNBase):
 
   def forward(self, x):
     # x: packed sequence of dim feat_dim  ->  tensor of shape (batch, seq_length, feat_dim*num_spk)
-    xp, lens = _to_padded(x, self.lin.weight.device)
-    return self.forward_padded(xp, lens).permute(1, 0, 2)
+    x2d, pk = _to_packed(x, self.lin.weight.device)
+    mask = self.forward_packed(x2d, pk)
+    # (padded frames: the constant the reference's BatchNorm / Linear / sigmoid produce there, archs/uPIT.py:135-144)
+    return pk.unpack(mask, fill=None if pk.uniform else self._engine.pad_row()).permute(1, 0, 2)
 
 
 def compute_cv_loss(model, epoch, batch_sample, plotdir=""):
@@ -246,10 +259,10 @@ def compute_cv_loss(model, epoch, batch_sample, plotdir=""):
   return loss, norm
 
 
-def compute_loss_padded(model, mix, sources, lens, plotdir=""):
-  """compute_loss on inputs that are already resident on the GPU: mix (T,B,F) and sources
-  [(T,B,F)]*S zero-padded time-major float32, lens int32 (B).  Same return as compute_loss."""
-  batch = mix.shape[1]
+def compute_loss_packed(model, mix, sources, pk, plotdir=""):
+  """compute_loss on inputs that are already resident on the GPU as PACKED rows: mix (R,F) and sources [(R,F)]*S
+  float32 -- PackedSequence.data of the collator's batch -- and their Packing pk.  Same return as compute_loss."""
+  batch = pk.B
   model.zero_grad()
   model.hidden = model.init_hidden(batch)
 
@@ -257,11 +270,11 @@ def compute_loss_padded(model, mix, sources, lens, plotdir=""):
   # single-device gradient of the global batch (None = single process, kernel uses sum(lens)*F)
   # -- only while training: the CV pass runs the whole (unsharded) set on every rank, local norm.
   training_step = model.training and torch.is_grad_enabled()
-  norm_override = skdist.global_norm(lens, model.feat_dim) if training_step else None
+  norm_override = skdist.global_norm(pk.lens, model.feat_dim) if training_step else None
 
-  mask_out = model.forward_padded(mix, lens)
-  # mask_out: tensor of shape (seq_length, batch, feat_dim*num_spk)
-  out, best = _PitFn.apply(mask_out, mix, lens, norm_override, *sources)
+  mask_out = model.forward_packed(mix, pk)
+  # mask_out: tensor of shape (sum of lengths, feat_dim*num_spk)
+  out, best = _PitFn.apply(mask_out, mix, pk, norm_override, *sources)
   loss, norm = out[0], out[1].detach()
   model.last_best_perm = best.detach()      # arg-min permutation per utterance (index into itertools.permutations)
 
@@ -270,26 +283,47 @@ def compute_loss_padded(model, mix, sources, lens, plotdir=""):
     import plot
     os.system("mkdir -p " + plotdir)
     F = model.feat_dim
-    m0 = mask_out[:, 0].detach()
-    masked = (m0.view(-1, model.num_spk, F) * mix[:, 0].unsqueeze(1)).reshape(-1, model.num_spk * F)
-    plot.plot_spec(mix[:, 0].cpu().numpy(), plotdir + '/Mixture.png')
+    rows0 = pk.offs[:int(pk.lens_host[0])].long()              # the rows of the batch's first (longest) utterance
+    m0, x0 = mask_out.detach()[rows0], mix[rows0]
+    masked = (m0.view(-1, model.num_spk, F) * x0.unsqueeze(1)).reshape(-1, model.num_spk * F)
+    plot.plot_spec(x0.cpu().numpy(), plotdir + '/Mixture.png')
     plot.plot_spec(masked.cpu().numpy(), plotdir + '/Masked_Mixture.png')
     permutation = list(itertools.permutations(range(model.num_spk)))[int(best[0])]
-    plot.plot_spec(torch.cat([sources[i][:, 0] for i in permutation], dim=1).cpu().numpy(),
+    plot.plot_spec(torch.cat([sources[i][rows0] for i in permutation], dim=1).cpu().numpy(),
                    plotdir + '/Chosen_Permutation.png')
 
   return loss, norm
+
+
+def compute_loss_padded(model, mix, sources, lens, plotdir=""):
+  """compute_loss on zero-padded time-major inputs resident on the GPU: mix (T,B,F), sources [(T,B,F)]*S float32,
+  lens int32 (B) in any order.  They are packed (sk_pack_rows; a view when all lengths are equal) and go the packed way."""
+  pk = model.packing_of(lens)
+  if pk.perm is not None:
+    # not length-sorted (the collator's batches are): the rows are packed in sorted order, so the initial state drawn for
+    # this batch follows, and the chosen permutations are handed back in the caller's order
+    h, c = model.init_hidden(pk.B)
+    pair = (pk.sort_batch(h, 1), pk.sort_batch(c, 1))
+    rest = model.next_hidden
+    model.next_hidden = pair if rest is None else [pair] + (rest if isinstance(rest, list) else [rest])
+  out = compute_loss_packed(model, pk.pack(mix), [pk.pack(s) for s in sources], pk, plotdir)
+  if pk.perm is not None:
+    model.last_best_perm = pk.unsort_batch(model.last_best_perm, 0)
+  return out
 
 
 # define training pass
 def compute_loss(model, epoch, batch_sample, plotdir=""):
   dev = model.lin.weight.device
   if 'pcm' in batch_sample:        # WavTrainSet batches: features are computed on the GPU
-    mix, sources, lens = _features_from_pcm(batch_sample['pcm'], dev)
-    return compute_loss_padded(model, mix, sources[:model.num_spk], lens, plotdir)
-  mix, lens = _to_padded(batch_sample['mix'], dev)
-  sources = [_to_padded(batch_sample['source' + str(i + 1)], dev)[0] for i in range(model.num_spk)]
-  return compute_loss_padded(model, mix, sources, lens, plotdir)
+    mix, sources, pk = _features_from_pcm(batch_sample['pcm'], dev)
+    return compute_loss_packed(model, mix, sources[:model.num_spk], pk, plotdir)
+  if 'packed' in batch_sample:     # batches staged on the GPU ahead of the step (sepkern.data.Prefetcher)
+    mix, sources, pk = batch_sample['packed']
+    return compute_loss_packed(model, mix, sources[:model.num_spk], pk, plotdir)
+  mix, pk = _to_packed(batch_sample['mix'], dev)
+  sources = [_to_packed(batch_sample['source' + str(i + 1)], dev)[0] for i in range(model.num_spk)]
+  return compute_loss_packed(model, mix, sources, pk, plotdir)
 
 
 # define test pass
@@ -297,20 +331,19 @@ def estimate_masks(model, batch_sample):
   """The arithmetic half of compute_masks: [(file name, {'s1': (257,T_i) float32, ...}), ...] for one batch, without
   touching the disk (steps/eval_qsub.py overlaps the zlib compression of one batch with the next batch's GPU work)."""
   dev = model.lin.weight.device
-  mix, lens = _to_padded(batch_sample['mix'], dev)
+  mix, pk = _to_packed(batch_sample['mix'], dev)
   name = batch_sample['name']
-  batch = mix.shape[1]
+  batch = pk.B
 
   model.zero_grad()
   model.hidden = model.init_hidden(batch)
 
   with torch.no_grad():
-    mask_out = model.forward_padded(mix, lens).permute(1, 0, 2)
-  mask_np = mask_out.cpu().numpy()
-  lens = lens.cpu().numpy()
+    mask_np = model.forward_packed(mix, pk).cpu().numpy()            # (sum of lengths, feat_dim*num_spk)
+  lens, offs = pk.lens_host, pk.offs_host
   out = []
   for i in range(len(name)):
-    mask = mask_np[i].transpose()[:, 0:lens[i]]
+    mask = mask_np[offs[:lens[i]] + i].transpose()                  # rows (t, i), t < lens[i]  ->  (feat_dim*num_spk, T_i)
     file_dict = dict()
     for src in range(model.num_spk):
       file_dict['s' + str(src + 1)] = mask[src * model.feat_dim:(src + 1) * model.feat_dim]

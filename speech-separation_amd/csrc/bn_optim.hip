@@ -63,11 +63,28 @@ __global__ __launch_bounds__(256) void colfin_kernel(const float* __restrict__ p
   out[c] = accumulate ? out[c] + a : a;
 }
 
-__global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var,
-                                                         float* __restrict__ rmean, float* __restrict__ rvar, int R,
-                                                         int C, float momentum) {
+// var[c] = (sum over the R stored rows of (x - mean)^2  +  (count - R) * mean^2) / count: the biased variance over `count`
+// rows of which count - R are zero rows that are not stored (packed sequences: the reference normalises over the
+// zero-padded (B, T_max) grid, archs/uPIT.py:135-138)
+__global__ __launch_bounds__(256) void colfin_var_kernel(const float* __restrict__ part, int nch, int C, float missing,
+                                                         float inv_count, const float* __restrict__ mean,
+                                                         float* __restrict__ var) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
+  float a = 0.f;
+  for (int k = 0; k < nch; ++k) a += part[(int64_t)k * C + c];
+  const float mu = mean[c];
+  var[c] = (a + missing * mu * mu) * inv_count;
+}
+
+// guard (may be NULL): the recurrence's sticky status word -- non-zero after a launch whose bounded wait gave up, whose
+// outputs (and therefore these batch statistics) are garbage: the running statistics are then left alone
+__global__ __launch_bounds__(256) void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar, int64_t R,
+                                                         int C, float momentum, const unsigned* __restrict__ guard) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  if (guard && guard[0] != 0u) return;
   const float unbiased = var[c] * ((float)R / (float)(R - 1));
   rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean[c];
   rvar[c] = (1.0f - momentum) * rvar[c] + momentum * unbiased;
@@ -159,12 +176,12 @@ __global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restric
 // dst (R, ld_dst) <- src (R, C) with row stride ld_src; columns C..ld_dst-1 zero.  One pass (the engine pads the
 // F = 257 input features to 260 columns so that rows of both GEMM operands are 16-byte aligned).
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t R,
-                                                       int C, int ld_src, int ld_dst) {
-  const int64_t total = R * ld_dst;
+                                                       int64_t R_pad, int C, int ld_src, int ld_dst) {
+  const int64_t total = R_pad * ld_dst;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / ld_dst;
     const int c = (int)(i - r * ld_dst);
-    dst[i] = c < C ? src[r * ld_src + c] : 0.f;
+    dst[i] = (c < C && r < R) ? src[r * ld_src + c] : 0.f;
   }
 }
 
@@ -249,26 +266,29 @@ static int colreduce(int mode, const float* x, const float* aux, const float* me
   return SK_OK;
 }
 
-extern "C" int sk_bn_stats(const float* x, int R, int C, float* mean, float* var, void* ws, sk_stream_t stream) {
-  SK_CHECK_ARG(x && mean && var && ws && R > 1 && C > 0, "sk_bn_stats: bad arguments");
+extern "C" int sk_bn_stats(const float* x, int R, int C, int64_t count, float* mean, float* var, void* ws,
+                           sk_stream_t stream) {
+  SK_CHECK_ARG(x && mean && var && ws && R > 0 && C > 0 && count >= R && count > 1, "sk_bn_stats: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const int nch = (int)sk_cdiv(R, RCH);
   float* part = (float*)ws;
+  const float inv = (float)(1.0 / (double)count);
   int rc = colreduce(0, x, nullptr, nullptr, nullptr, 0.f, R, C, C, part, nullptr, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(colfin_kernel, dim3((unsigned)sk_cdiv(C, 256)), dim3(256), 0, st, part, nch, C, 1.0f / (float)R, 0, mean);
+  hipLaunchKernelGGL(colfin_kernel, dim3((unsigned)sk_cdiv(C, 256)), dim3(256), 0, st, part, nch, C, inv, 0, mean);
   rc = colreduce(1, x, nullptr, mean, nullptr, 0.f, R, C, C, part, nullptr, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(colfin_kernel, dim3((unsigned)sk_cdiv(C, 256)), dim3(256), 0, st, part, nch, C, 1.0f / (float)R, 0, var);
+  hipLaunchKernelGGL(colfin_var_kernel, dim3((unsigned)sk_cdiv(C, 256)), dim3(256), 0, st, part, nch, C, (float)(count - R), inv,
+                     mean, var);
   SK_CHECK_LAUNCH("sk_bn_stats");
   return SK_OK;
 }
 
 extern "C" int sk_bn_update_running(const float* mean, const float* var, float* running_mean, float* running_var,
-                                    int R, int C, float momentum, sk_stream_t stream) {
-  SK_CHECK_ARG(mean && var && running_mean && running_var && R > 1 && C > 0, "sk_bn_update_running: bad arguments");
+                                    int64_t count, int C, float momentum, const void* guard, sk_stream_t stream) {
+  SK_CHECK_ARG(mean && var && running_mean && running_var && count > 1 && C > 0, "sk_bn_update_running: bad arguments");
   hipLaunchKernelGGL(bn_running_kernel, dim3((unsigned)sk_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, var,
-                     running_mean, running_var, R, C, momentum);
+                     running_mean, running_var, count, C, momentum, (const unsigned*)guard);
   SK_CHECK_LAUNCH("sk_bn_update_running");
   return SK_OK;
 }
@@ -359,10 +379,11 @@ extern "C" int sk_sigmoid_bwd(const float* dmask, const float* m, float* dz, int
   return SK_OK;
 }
 
-extern "C" int sk_pad_rows(const float* src, int64_t R, int C, int ld_src, float* dst, int ld_dst, sk_stream_t stream) {
-  SK_CHECK_ARG(src && dst && src != dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C, "sk_pad_rows: bad arguments");
-  hipLaunchKernelGGL(pad_rows_kernel, dim3(stream_blocks(R * ld_dst)), dim3(256), 0, (hipStream_t)stream, src, dst, R, C,
-                     ld_src, ld_dst);
+extern "C" int sk_pad_rows(const float* src, int64_t R, int C, int ld_src, float* dst, int ld_dst, int64_t R_pad,
+                           sk_stream_t stream) {
+  SK_CHECK_ARG(src && dst && src != dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C && R_pad >= R, "sk_pad_rows: bad arguments");
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(stream_blocks(R_pad * ld_dst)), dim3(256), 0, (hipStream_t)stream, src, dst, R, R_pad,
+                     C, ld_src, ld_dst);
   SK_CHECK_LAUNCH("sk_pad_rows");
   return SK_OK;
 }

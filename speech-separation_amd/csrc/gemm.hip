@@ -568,113 +568,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_dma256(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// 256 x 256 block tile, eight waves of 64 x 128 (2 x 4 MFMA tiles, 128 accumulator registers), one workgroup per CU
-// (r03, variant 5; unsplit products only).  Per flop it moves HALF the bytes global -> LDS of the 128 x 128 kernels
-// (2/3 of gemm_f32_kernel_dma256's) and reads 3/4 of the fragment bytes from LDS: the two terms the ablation of DESIGN.md
-// 4b shows the fp32 kernels' loss against the matrix pipe to go with.  Same images and DMA sources as the 256-row kernel
-// (both operands now 256 wide: 16 pieces each, four per wave), NST stages of 32 KB, one barrier per K step.
-template <bool TA, bool TB>
-__global__ __launch_bounds__(512, 2) void gemm_f32_kernel_dma256x256(GemmArgs g) {
-  constexpr int BMW = 256, BNW = 256;
-  constexpr int TILE = BMW * BK * 4, STAGE = 2 * TILE;  // 16 + 16 KB
-  constexpr int NST = 3;
-  __shared__ __attribute__((aligned(1024))) char lds[NST][STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int tile = blockIdx.x;
-  {
-    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
-    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
-  }
-  int m0, n0;
-  {
-    constexpr int GM = GROUP_M / 2;  // the same 1024 rows per group
-    const int tilesM = gridDim.x / g.tilesN, per = GM * g.tilesN;
-    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GM;
-    const int gsz = min(GM, tilesM - first);
-    m0 = (first + rem2 % gsz) * BMW;
-    n0 = (rem2 / gsz) * BNW;
-  }
-  const int z = blockIdx.z;
-  const float* A = g.A + z * g.sA;
-  const float* B = g.B + z * g.sB;
-  float* C = g.C + z * g.sC;
-  const float* bias = g.bias ? g.bias + z * g.sbias : nullptr;
-  const int nk = g.K / BK;  // unsplit: the whole K range (a multiple of BK)
-
-  // wave w DMAs A pieces 2w, 2w+1 and B pieces 2w, 2w+1 (16 pieces of 1 KB per operand and stage)
-  const float* srcA[2];
-  const float* srcB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    srcA[i] = dma_src_w256<TA>(A, g.lda, m0, g.M, 0, 2 * wave + i, lane);
-    srcB[i] = dma_src_w256<!TB>(B, g.ldb, n0, g.N, 0, 2 * wave + i, lane);
-  }
-  const int64_t stepA = TA ? (int64_t)BK * g.lda : BK, stepB = !TB ? (int64_t)BK * g.ldb : BK;
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
-  const unsigned pa = __builtin_amdgcn_readfirstlane(lds_base + 2 * wave * 1024);
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      dma_1k(srcA[i], pa + buf * STAGE + i * 1024);
-      dma_1k(srcB[i], pa + buf * STAGE + TILE + i * 1024);
-      srcA[i] += stepA;
-      srcB[i] += stepB;
-    }
-  };
-
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  int fa[2], fb[4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) fa[i] = frag_base_w<TA, BMW>(wm * 64 + 32 * i, lane);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) fb[j] = frag_base_w<!TB, BNW>(wn * 128 + 32 * j, lane);
-
-  if (nk > 0) stage(0);
-  if (nk > 1) stage(1);
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // step kt has landed; the 4 instructions of step kt + 1 may still fly
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // everybody's pieces of step kt are in LDS; all reads of the stage refilled next are done
-    if (kt + 2 < nk) stage((cur + 2) % NST);
-    const char* ai = lds[cur];
-    const char* bi = lds[cur] + TILE;
-#pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
-      float a[2][4], b[4][4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) frag_load_w<TA, BMW>(ai, fa[i], cp, a[i]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) frag_load_w<!TB, BNW>(bi, fb[j], cp, b[j]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], b[j][k], acc[i][j], 0, 0, 0);
-    }
-    cur = (cur + 1) % NST;
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {  // the wave's two 64-column halves through the 64 x 64 epilogue
-    const f32x16 part[2][2] = {{acc[0][2 * h], acc[0][2 * h + 1]}, {acc[1][2 * h], acc[1][2 * h + 1]}};
-    store_tile(g, part, C, g.ldc, bias, false, m0 + wm * 64, n0 + wn * 128 + 64 * h, lane);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
-// The 256 x 256 kernel as a PERSISTENT stream-K kernel (r03, variant 6; unsplit, unbatched products): one workgroup per
+// 256 x 256 block tiles (eight waves of 64 x 128: per flop HALF the bytes global -> LDS of the 128 x 128 kernels and 3/4 of
+// their fragment bytes) as a PERSISTENT stream-K kernel (r03, variant 6; unsplit, unbatched products): one workgroup per
 // CU, P = gridDim.x of them.  With one workgroup per CU a partial last round of tiles costs a whole round (1400 tiles on
 // 256 CUs: 6 rounds for 5.47 of work), which is what kept the 256 x 256 kernel off the training step.  Here workgroup b
 // first takes the tiles b, P + b, ... of `sk_full` whole rounds in the usual XCD-aware order, then its share of the
@@ -1734,23 +1629,6 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
   }
 }
 
-// fp32 (R, C) -> TRANSPOSED bf16 copy dst[c][r], leading dimension ldd >= R, columns R..ldd-1 zero.  64 x 64 tiles
-// through LDS: coalesced reads along C, coalesced writes along R.
-__global__ __launch_bounds__(256) void cast_t_kernel(const float* __restrict__ src, int R, int C, int lds_, __bf16* __restrict__ dst,
-                                                     int ldd) {
-  __shared__ float tile[64][65];
-  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    tile[r][c] = (r0 + r < R && c0 + c < C) ? src[(int64_t)(r0 + r) * lds_ + c0 + c] : 0.f;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-    const int c = i >> 6, r = i & 63;
-    if (c0 + c < C && r0 + r < ldd) dst[(int64_t)(c0 + c) * ldd + r0 + r] = (__bf16)tile[r][c];
-  }
-}
-
 }  // namespace bf2
 
 // C = act(sum_ks slabs[z][ks] + bias (+ C)), slices added in fixed order (deterministic)
@@ -1855,7 +1733,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                 int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
-  SK_CHECK_ARG(variant >= 0 && variant <= 6, "sk_gemm: unknown variant %d", variant);
+  SK_CHECK_ARG(variant >= 0 && variant <= 6 && variant != 5, "sk_gemm: unknown variant %d", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
@@ -1878,13 +1756,8 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   // with split-K launches included the step does not move.  SEPKERN_GEMM_WIDE=0 (diagnostics): never chosen.
   static const bool wide_ok = [] { const char* e = getenv("SEPKERN_GEMM_WIDE"); return !(e && e[0] == '0'); }();
   const bool wide = !bf16 && M >= 256 && dma_ok(g, transA, transB) &&
-                    (variant == 4 || (variant == 0 && wide_ok && !transA && M >= 4096 && N >= 1024 && splitk == 1));
-  // 256 x 256 block tiles (variant 5; SEPKERN_GEMM_SQUARE=1 lets variant 0 choose it for the large unsplit N/T and N/N
-  // products): the same operand forms as `wide`, unsplit only
-  static const bool square_ok = [] { const char* e = getenv("SEPKERN_GEMM_SQUARE"); return e && e[0] == '1'; }();
-  const bool square = !bf16 && M >= 256 && N >= 256 && splitk == 1 && dma_ok(g, transA, transB) &&
-                      (variant == 5 || variant == 6 || (variant == 0 && square_ok && !transA && M >= 4096 && N >= 1024));
-  // the same kernel persistent with a stream-K cut of the last partial round: variant 6, or chosen (variant 0) for the large
+                    (variant == 4 || variant == 6 || (variant == 0 && wide_ok && !transA && M >= 4096 && N >= 1024 && splitk == 1));
+  // 256 x 256 tiles, persistent, with a stream-K cut of the last partial round: variant 6, or chosen (variant 0) for the large
   // unsplit N/T and N/N products when the caller passes the workspace of sk_gemm_streamk_workspace_bytes() -- measured
   // 124.4 vs 121.5 TFLOP/s on the input projections, 134.6 vs 125.5 on the data gradients, 36.05 vs 36.63 ms on the training
   // step (three alternations).  SEPKERN_GEMM_STREAMK=0 (diagnostics): never chosen.
@@ -1900,8 +1773,8 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
     // a remainder too short to give every workgroup a K step goes to whole tiles (the plain kernel's last round)
     if (P < 8 || nt >= (1 << 24) || nk < 8 || (R > 0 && R < P) || nt - (int64_t)g.sk_full * P > 16384) streamk = false;
   }
-  if (square || streamk) g.tilesN = (int)sk_cdiv(N, 256);
-  const int64_t tiles = sk_cdiv(M, (wide || square || streamk) ? 256 : BM) * g.tilesN;
+  if (streamk) g.tilesN = (int)sk_cdiv(N, 256);
+  const int64_t tiles = sk_cdiv(M, (wide || streamk) ? 256 : BM) * g.tilesN;
   SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm: too many tiles");
   // workspace = [ticket counters | slabs]; the fp32 kernels reduce in-kernel when the counters cover every (batch, tile)
   g.slabs = ws ? (float*)((char*)ws + COUNTER_BYTES) : nullptr;
@@ -1927,13 +1800,6 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, true>), pgrid, dim3(512), 0, st, g);
     else
       hipLaunchKernelGGL((gemm_f32_kernel_streamk<true, false>), pgrid, dim3(512), 0, st, g);
-  } else if (square) {
-    if (!transA && !transB)
-      hipLaunchKernelGGL((gemm_f32_kernel_dma256x256<false, false>), grid, dim3(512), 0, st, g);
-    else if (!transA && transB)
-      hipLaunchKernelGGL((gemm_f32_kernel_dma256x256<false, true>), grid, dim3(512), 0, st, g);
-    else
-      hipLaunchKernelGGL((gemm_f32_kernel_dma256x256<true, false>), grid, dim3(512), 0, st, g);
   } else if (wide) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_dma256<false, false>), grid, dim3(512), 0, st, g);
@@ -2088,10 +1954,6 @@ extern "C" int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const flo
   return SK_OK;
 }
 
-extern "C" int sk_cast_bf16(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream) {
-  return sk_cast_bf16_rows(src, R, C, ld_src, dst, ld_dst, R, stream);
-}
-
 extern "C" int sk_cast_bf16_rows(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, int R_pad,
                                  sk_stream_t stream) {
   SK_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C && ld_dst % 8 == 0 && ((uintptr_t)dst % 16) == 0 &&
@@ -2101,13 +1963,5 @@ extern "C" int sk_cast_bf16_rows(const float* src, int R, int C, int ld_src, voi
   const unsigned nb = (unsigned)(sk_cdiv(n8, 256) > 4096 ? 4096 : sk_cdiv(n8, 256));
   hipLaunchKernelGGL(bf2::cast_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, R, C, ld_src, (__bf16*)dst, ld_dst, R_pad);
   SK_CHECK_LAUNCH("sk_cast_bf16");
-  return SK_OK;
-}
-
-extern "C" int sk_cast_bf16_t(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, sk_stream_t stream) {
-  SK_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= R, "sk_cast_bf16_t: bad arguments");
-  dim3 grid((unsigned)sk_cdiv(ld_dst, 64), (unsigned)sk_cdiv(C, 64));
-  hipLaunchKernelGGL(bf2::cast_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, R, C, ld_src, (__bf16*)dst, ld_dst);
-  SK_CHECK_LAUNCH("sk_cast_bf16_t");
   return SK_OK;
 }

@@ -117,6 +117,7 @@ struct FwdArgs {
   const float* h0;
   const float* c0;
   const int* lens;
+  const int* offs;  // packed rows: row of (t, b) is offs[t] + b for t < lens[b] (lens sorted descending); NULL: padded, t * B + b
   float* y;
   float* gates;
   float* cs;
@@ -140,6 +141,7 @@ struct BwdArgs {
   const float* cs;
   const float* c0;
   const int* lens;
+  const int* offs;  // as FwdArgs::offs
   float* dgx;
   float* dh0;
   float* dc0;
@@ -153,7 +155,6 @@ struct BwdArgs {
   unsigned* sticky;
   int T, B, H, NBG, G, s_begin, s_end, final_mm;
   int map, nby, poll_delay;
-  int tagged;  // fp32: the data is the flag (epoch in the two low mantissa bits of every exchanged dG word)
   __bf16* dgx_bf;  // optional bf16 twin of dgx (rows (t, b), ld_bf elements apart), written with the fp32 values; may be NULL
   int ld_bf;
 };
@@ -417,6 +418,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       const int b = bg * 16 + bl;
       const bool cellok = owner && unit < H && b < B;
       const int len_b = (b < B) ? a.lens[b] : 0;
+      const bool live = cellok && t < len_b;                       // this lane's cell takes part in step t
+      const size_t row = (size_t)(a.offs ? a.offs[t] : t * B) + b;  // its row in gx / y / gates / cs
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
       const size_t rep_stride = (size_t)2 * NBG * NUG;
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       SK_STAMP(7);
       // 1. this step's input-projection terms (independent of the recurrence: issue early)
       float4 gxv = make_float4(0.f, 0.f, 0.f, 0.f);  // gate-interleaved layout: i,f,g,o of a cell are one 16-byte access
-      if (cellok) gxv = *reinterpret_cast<const float4*>(a.gx + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit);
+      if (live) gxv = *reinterpret_cast<const float4*>(a.gx + (row * 2 + dir) * 4 * H + 4 * (size_t)unit);
       // 2./3. h_{s-1} image (16 rows x HP) -> LDS.  Each consumer wave waits for the flags of exactly the unit
       // groups whose 1 KB pieces it pulls and starts its LDS-DMAs as soon as those are up -- no workgroup
       // barrier in between.  fp32: all 8 waves pull (56 pieces); bf16 (28 pieces, latency-bound): only the four
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         const float go = fast_sigmoid(acc[3] + gxv.w);
         const float c_new = gf * c_reg + gi_ * gg;
         const float h_new = go * fast_tanh(c_new);
-        valid = cellok && t < len_b;
+        valid = live;
         if (valid) {
           c_reg = c_new;
           h_reg = h_new;
@@ -622,11 +625,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         if (tid == 0) st_tpub[gi] = wall_clock64();  // read back by this same wave when it polls for the next step
       }
       // 7. ... then the bulk stores of the step, off the critical path
-      if (cellok) {
-        a.y[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit] = y_out;
+      if (valid || (cellok && !a.offs)) {  // padded layout: y = 0 past a row's end; packed: those rows do not exist
+        a.y[row * 2 * H + (size_t)dir * H + unit] = y_out;
         if (a.gates && valid) {
-          *reinterpret_cast<f32x4*>(a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit) = acc;
-          a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit] = c_out;
+          *reinterpret_cast<f32x4*>(a.gates + (row * 2 + dir) * 4 * H + 4 * (size_t)unit) = acc;
+          a.cs[(row * 2 + dir) * H + unit] = c_out;
         }
       }
       SK_STAMP(6);
@@ -645,358 +648,6 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_c[gi][oi];
         if (BF || (a.opt & 8)) a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_h[gi][oi];
       }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------ forward, two streams per workgroup
-// The kernel above leaves the matrix pipe idle for half of every step: all workgroups of a stream compute, then all
-// publish, then all wait for each other (3.05 us of MFMA in a 6.0 us step at H = 896).  Here a workgroup owns 8 hidden
-// units x 16 batch rows of BOTH directions.  The two directions are independent recurrences, so while one direction's
-// h_s travels to the other workgroups (store -> drain -> flag -> poll) the matrix pipe works on the other direction's
-// step.  Same W_hh bytes in registers (2 directions x 32 gate rows x H), same number of MFMAs per workgroup and step,
-// same bytes exchanged; a stream has 2x the participants (H/8 workgroups) at half the payload each.
-//
-// Roles (768 threads, no workgroup barrier inside the time loop):
-//   waves 0..7   MFMA waves: wave (mt = w&1, kq = w>>1) multiplies gate-row tile mt (4 units x 4 gates) of BOTH
-//                directions by K quarter kq of that direction's h image.  Per direction-step: wait for "flags up" (an
-//                LDS word), pull its half of the K quarter's pieces by LDS-DMA (7 x 1 KB at H = 896), meet the other
-//                tile's wave of the same K quarter at a counter in LDS, NQ x 4 MFMAs, partial tile -> LDS, count up.
-//   waves 8..11  cell waves: wave (d = c>>1, mt = c&1) owns the 64 cells (4 units x 16 rows) of tile mt, direction d,
-//                for the whole sequence (c, h in registers).  Per step: wait for the 4 partial tiles, cell update,
-//                publish h (write-through, 16 B per row: 4 units gathered through LDS) + drain; the LAST of the pair
-//                raises the stream's flag; bulk stores; the pair's first wave then polls the stream's flags and tells
-//                the MFMA waves.
-// Hand-off protocol, flags, exchange image and workspace are those of lstm_fwd_kernel (placement-independent).
-// Wait for a word in LDS to reach `target`.  Ends on the workgroup's abort word, and -- every wait in these kernels is
-// bounded -- after 1.5 x the flag-poll limit on its own (it then raises the abort word and the launch's status words).
-__device__ __forceinline__ bool lds_wait_ge(int* word, int target, int* abort_word, unsigned* ctrl) {
-  long long t0 = 0;
-  for (unsigned it = 0;; ++it) {
-    if (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= target) return true;
-    if ((it & 15u) == 15u) {
-      if (__hip_atomic_load(abort_word, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return false;
-      if ((it & 1023u) == 1023u) {
-        const long long now = wall_clock64();
-        if (t0 == 0) t0 = now;
-        if (now - t0 > SPIN_TICKS + SPIN_TICKS / 2) {
-          __hip_atomic_store(abort_word, 1, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
-          __hip_atomic_store(ctrl - 64, 1u, SK_RLX, SK_AGENT);  // the sticky word (workspace word 0), see ws_layout
-          return false;
-        }
-      }
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
-// One wave's arrival at a counter in LDS (everything this wave stored or had landed in LDS before is visible to whoever
-// reads the count afterwards): returns, in every lane, the count BEFORE this arrival.
-__device__ __forceinline__ int pair_arrive(int* counter, int lane) {
-  int before = 0;
-  if (lane == 0) before = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-  return __builtin_amdgcn_readfirstlane(before);
-}
-
-// Diagnostic build only (-DSK_LSTM_STAMPS): workgroup 0's MFMA wave 0 (slots 0..7) and cell wave 8 (slots 8..14) add up
-// the 100 MHz ticks they spend in each phase; tools/lstm_stamps.py --dual prints them.
-#ifdef SK_LSTM_STAMPS
-#define SK2_DECL long long st2_t = wall_clock64(), st2_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SK2_STAMP(i)                      \
-  do {                                    \
-    const long long n__ = wall_clock64(); \
-    st2_acc[i] += n__ - st2_t;            \
-    st2_t = n__;                          \
-  } while (0)
-#define SK2_FLUSH(ctrl, base, n)                                                      \
-  do {                                                                                \
-    if (blockIdx.x == 0 && lane == 0)                                                 \
-      for (int i__ = 0; i__ < (n); ++i__) ((long long*)(ctrl))[4 + (base) + i__] = st2_acc[i__]; \
-  } while (0)
-#else
-#define SK2_DECL
-#define SK2_STAMP(i)
-#define SK2_FLUSH(ctrl, base, n)
-#endif
-
-template <int KS>
-__global__ __launch_bounds__(768) void lstm_fwd2_kernel(FwdArgs a) {
-  constexpr int HP = 16 * KS;
-  constexpr int NCH = KS;        // 1 KB chunks (16 k) of one direction's h image
-  constexpr int NQ = NCH / 4;    // chunks per MFMA wave (one K quarter)
-  constexpr int NUG = HP / 8;    // workgroups (8 units each) per batch group = producers per stream
-  constexpr int NP0 = (NQ + 1) / 2;  // pieces of a K quarter pulled by the tile-0 wave (the tile-1 wave: the rest)
-  static_assert(NCH % 4 == 0, "four K quarters");
-  __shared__ __attribute__((aligned(16))) float hs[2][16 * HP];    // per direction: B-operand image of h_{s-1}
-  __shared__ __attribute__((aligned(16))) float red[2][8][64][4];  // per direction: the 8 MFMA waves' partial tiles
-  __shared__ __attribute__((aligned(16))) float pubs[4][16][4];    // per cell wave: h of its 4 units, row-major (publish)
-  __shared__ int up[2];             // [direction]: images whose pieces may be pulled (poller -> MFMA waves)
-  __shared__ int kq_full[2][4];     // [direction][K quarter]: arrivals of the two tile waves with their pieces landed
-  __shared__ int part_done[2][2];   // [direction][tile]: partial tiles written so far (MFMA waves -> cell waves)
-  __shared__ int pub_done[2];       // [direction]: arrivals of the two cell waves with their h published
-  __shared__ int choice[4][8];      // [K quarter][decision % 8]: which direction the pair of tile waves takes next
-  __shared__ int s_abort;
-
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;
-  int ug, bg;
-  {  // streams (batch groups) dealt to XCD groups where the counts allow (speed only; any bijection is correct)
-    const int L = (int)blockIdx.x, x = L & 7, j = L >> 3;
-    if ((a.map & 3) == 1 && NBG <= 8 && (8 % NBG) == 0 && (NUG % (8 / NBG)) == 0) {
-      const int g = 8 / NBG;
-      bg = x / g;
-      ug = j * g + (x % g);
-    } else {
-      bg = L / NUG;
-      ug = L - bg * NUG;
-    }
-  }
-  if (tid == 0) {
-    s_abort = 0;
-    up[0] = up[1] = 0;
-    for (int i = 0; i < 4; ++i) kq_full[0][i] = kq_full[1][i] = 0;
-    part_done[0][0] = part_done[0][1] = part_done[1][0] = part_done[1][1] = 0;
-    pub_done[0] = pub_done[1] = 0;
-    for (int i = 0; i < 32; ++i) (&choice[0][0])[i] = 0;
-  }
-  const int nsteps = a.s_end - a.s_begin;
-  const bool from_h0 = a.s_begin == 0;  // the first image is built from h0 by the cell waves, not pulled
-  const size_t xblk = (size_t)16 * HP;  // floats per (parity, direction, batch group) exchange block
-
-  if (w < 8) {
-    // ================================================================== MFMA waves
-    const int mt = w & 1, kq = w >> 1;
-    float wreg[2][4 * NQ];
-    {
-      const int i = lane & 15, k4 = lane >> 4;
-      const int unit_i = ug * 8 + 4 * mt + (i >> 2), g_i = i & 3;
-      const bool rowok = unit_i < H;
-#pragma unroll
-      for (int d = 0; d < 2; ++d) {
-        const float* wrow = a.whh + ((size_t)d * 4 * H + (size_t)g_i * H + unit_i) * H;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int k = 16 * (kq * NQ + q) + 4 * k4;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (rowok && k < H) v = *reinterpret_cast<const float4*>(wrow + k);
-          wreg[d][4 * q + 0] = v.x;
-          wreg[d][4 * q + 1] = v.y;
-          wreg[d][4 * q + 2] = v.z;
-          wreg[d][4 * q + 3] = v.w;
-        }
-      }
-    }
-    const int p_lo = kq * NQ + (mt ? NP0 : 0), p_n = mt ? NQ - NP0 : NP0;  // the pieces this wave pulls
-    __syncthreads();  // the only workgroup barrier: the LDS words above are initialised
-    SK2_DECL
-    // One direction-step (d compile-time: the W slice is indexed statically).  Returns false on abort.
-    auto dstep = [&](auto dtag, int r) -> bool {
-      constexpr int d = decltype(dtag)::value;
-      const int s = a.s_begin + r;
-      if (r > 0 || !from_h0) {
-        // "flags up" also says that every wave of this workgroup is done with the previous image and partial tiles
-        // of direction d (this workgroup's own flag is among those the poller saw)
-        if (!lds_wait_ge(&up[d], r + 1, &s_abort, a.ctrl)) return false;
-        SK2_STAMP(4 * d + 0);
-        const float* src = a.xbuf + ((size_t)(((s - 1) & 1) * 2 + d) * NBG + bg) * xblk;
-        for (int p = p_lo; p < p_lo + p_n; ++p) dma_piece(src + p * 256, &hs[d][p * 256], lane);
-        wait_vmcnt<0>();
-        pair_arrive(&kq_full[d][kq], lane);
-        SK2_STAMP(4 * d + 1);
-      }
-      if (!lds_wait_ge(&kq_full[d][kq], 2 * (r + 1), &s_abort, a.ctrl)) return false;
-      SK2_STAMP(4 * d + 2);
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const float* hp = &hs[d][(kq * NQ) * 256 + lane * 4];
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const float4 hb = *reinterpret_cast<const float4*>(hp + q * 256);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[d][4 * q + 0], hb.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[d][4 * q + 1], hb.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[d][4 * q + 2], hb.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[d][4 * q + 3], hb.w, acc1, 0, 0, 0);
-      }
-      *reinterpret_cast<f32x4*>(&red[d][w][lane][0]) = acc0 + acc1;
-      // release: the tile is in LDS (and this wave's reads of the image have returned) before the count goes up
-      if (lane == 0) __hip_atomic_fetch_add(&part_done[d][mt], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      SK2_STAMP(4 * d + 3);
-      return true;
-    };
-    // Whichever direction's flags are up goes next (the one further behind first; never more than one step apart, so
-    // that the two streams keep interleaving).  Every wave decides for itself; a direction's steps stay in order.
-    int r0 = 0, r1 = 0;
-    while (r0 < nsteps || r1 < nsteps) {
-#ifdef SK2_STRICT
-      const bool go0 = r0 <= r1;
-#else
-      const bool can0 = r0 < nsteps && r0 <= r1 + 1, can1 = r1 < nsteps && r1 <= r0 + 1;
-      const bool rdy0 = can0 && ((r0 == 0 && from_h0) || __hip_atomic_load(&up[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= r0 + 1);
-      const bool rdy1 = can1 && ((r1 == 0 && from_h0) || __hip_atomic_load(&up[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= r1 + 1);
-      bool go0;
-      if (rdy0 && rdy1) go0 = r0 <= r1;
-      else if (rdy0 || rdy1) go0 = rdy0;
-      else go0 = can0 && (!can1 || r0 <= r1);  // nothing is up: wait (inside dstep) for the one further behind
-      // The two tile waves of a K quarter meet at a counter inside every direction-step: they MUST take the steps in the
-      // same order (one waiting in direction 0 for a partner that waits in direction 1 would never end).  They read the
-      // readiness words at different moments, so the first of the pair to reach decision n publishes it and the other
-      // adopts it (n = steps done so far, equal for both at matching decisions; a slot is reused every 8 decisions).
-      {
-        const int n = r0 + r1;
-        int dec = 0;
-        if (lane == 0) {
-          int* slot = &choice[kq][n & 7];
-          const int want = ((n + 1) << 1) | (go0 ? 0 : 1);
-          int cur = __hip_atomic_load(slot, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP);
-          for (;;) {
-            if ((cur >> 1) == n + 1) { dec = cur & 1; break; }
-            if (__hip_atomic_compare_exchange_strong(slot, &cur, want, __ATOMIC_ACQ_REL, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-              dec = want & 1;
-              break;
-            }
-          }
-        }
-        go0 = __builtin_amdgcn_readfirstlane(dec) == 0;
-      }
-#endif
-      if (go0) {
-        if (!dstep(std::integral_constant<int, 0>{}, r0)) return;
-        ++r0;
-      } else {
-        if (!dstep(std::integral_constant<int, 1>{}, r1)) return;
-        ++r1;
-      }
-    }
-    if (w == 0) SK2_FLUSH(a.ctrl, 0, 8);
-    return;
-  }
-
-  // ==================================================================== cell waves
-  const int c = w - 8, d = c >> 1, mt = c & 1;
-  const int u_l = lane >> 4, bl = lane & 15;
-  const int unit = ug * 8 + 4 * mt + u_l, b = bg * 16 + bl;
-  const bool cellok = unit < H && b < B;
-  const int len_b = (b < B) ? a.lens[b] : 0;
-  const int xoff = ((unit >> 2) * 16 + bl) * 4 + (unit & 3);  // image position of (k = unit, row = bl)
-  float* const xb0 = a.xbuf + ((size_t)(0 * 2 + d) * NBG + bg) * xblk;
-  float* const xb1 = a.xbuf + ((size_t)(1 * 2 + d) * NBG + bg) * xblk;
-  const int fs = (a.opt & 4) ? FSPREAD : 1;
-  unsigned* const flags0 = a.flags + (size_t)(d * NBG + bg) * NUG * fs;
-  const int pt = mt * 64 + lane;  // thread index inside the direction's pair of cell waves
-#ifndef SK2_NOPRIO
-  __builtin_amdgcn_s_setprio(2);  // the cell waves carry the hand-off chain: first pick of the issue slots
-#endif
-  float c_reg = 0.f, h_reg = 0.f;
-  if (cellok) {
-    if (from_h0) {
-      c_reg = a.c0[((size_t)d * B + b) * H + unit];
-      h_reg = a.h0[((size_t)d * B + b) * H + unit];
-    } else {
-      c_reg = a.state[((size_t)d * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
-      h_reg = __hip_atomic_load(((a.s_begin - 1) & 1 ? xb1 : xb0) + xoff, SK_RLX, SK_AGENT);
-    }
-  }
-  __syncthreads();  // the only workgroup barrier (pairs with the MFMA waves')
-  // ---- image of the first step: from h0, or (a later range of a sequence) the block the previous launch published,
-  //      which the MFMA waves pull like any other
-  if (from_h0) {
-    for (int i = pt; i < 16 * (HP / 4); i += 128) {
-      const int bb = i & 15, cq = i >> 4;  // row, k/4
-      const int brow = bg * 16 + bb;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (brow < B && 4 * cq < H) v = *reinterpret_cast<const float4*>(a.h0 + ((size_t)d * B + brow) * H + 4 * cq);
-      *reinterpret_cast<float4*>(&hs[d][(cq * 16 + bb) * 4]) = v;
-    }
-    // both cell waves stand in for the two tile waves of every K quarter
-    if (lane < 4) __hip_atomic_fetch_add(&kq_full[d][lane], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  } else if (mt == 0 && lane == 0) {
-    __hip_atomic_store(&up[d], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-
-  float4 gxv = make_float4(0.f, 0.f, 0.f, 0.f);
-  {
-    const int t0 = d ? T - 1 - a.s_begin : a.s_begin;
-    if (cellok) gxv = *reinterpret_cast<const float4*>(a.gx + (((size_t)t0 * B + b) * 2 + d) * 4 * H + 4 * (size_t)unit);
-  }
-  SK2_DECL
-  for (int r = 0; r < nsteps; ++r) {
-    const int s = a.s_begin + r;
-    const int t = d ? T - 1 - s : s;
-    // 1. the four K-quarter partial tiles of this (direction, tile)
-    if (!lds_wait_ge(&part_done[d][mt], 4 * (r + 1), &s_abort, a.ctrl)) return;
-    SK2_STAMP(0);
-    f32x4 acc = *reinterpret_cast<const f32x4*>(&red[d][mt][lane][0]);
-    acc += *reinterpret_cast<const f32x4*>(&red[d][mt + 2][lane][0]);
-    acc += *reinterpret_cast<const f32x4*>(&red[d][mt + 4][lane][0]);
-    acc += *reinterpret_cast<const f32x4*>(&red[d][mt + 6][lane][0]);
-    // 2. cell update (lane-local: D row = 4 (lane>>4) + reg -> i,f,g,o of (unit, b))
-    const float gi_ = fast_sigmoid(acc[0] + gxv.x);
-    const float gf = fast_sigmoid(acc[1] + gxv.y);
-    const float gg = fast_tanh(acc[2] + gxv.z);
-    const float go = fast_sigmoid(acc[3] + gxv.w);
-    const float c_new = gf * c_reg + gi_ * gg;
-    const float h_new = go * fast_tanh(c_new);
-    const bool valid = cellok && t < len_b;
-    if (valid) {
-      c_reg = c_new;
-      h_reg = h_new;
-    }
-    // 3. publish h_s: the 4 units of a row are adjacent in the image -> gathered through LDS, one 16-byte write-through
-    //    store per row (16 lanes, 256 contiguous bytes per wave); drain; the last wave of the pair raises the flag
-    pubs[c][bl][u_l] = cellok ? h_reg : 0.f;
-    if (lane < 16) {
-      const u32x4 hv = *reinterpret_cast<const u32x4*>(&pubs[c][lane][0]);  // same wave: LDS operations are in order
-      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((s & 1) ? xb1 : xb0, 0, (int)(xblk * 4), 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b128(hv, rs, (unsigned)((((ug * 2 + mt) * 16 + lane) * 4) * 4), 0, 16 /* sc1 */);
-    }
-    SK2_STAMP(1);
-    wait_vmcnt<0>();
-    SK2_STAMP(2);
-    if (pair_arrive(&pub_done[d], lane) == 2 * r + 1 && lane == 0)
-      __hip_atomic_store(flags0 + (size_t)ug * fs, (unsigned)(s + 1), SK_RLX, SK_AGENT);
-    const long long t_pub = a.poll_delay ? wall_clock64() : 0LL;
-    SK2_STAMP(3);
-    // 4. bulk stores of the step, off the chain
-    if (cellok) {
-      a.y[((size_t)t * B + b) * 2 * H + (size_t)d * H + unit] = valid ? h_new : 0.f;
-      if (a.gates && valid) {
-        f32x4 gv = {gi_, gf, gg, go};
-        *reinterpret_cast<f32x4*>(a.gates + (((size_t)t * B + b) * 2 + d) * 4 * H + 4 * (size_t)unit) = gv;
-        a.cs[(((size_t)t * B + b) * 2 + d) * H + unit] = c_new;
-      }
-    }
-    if (r + 1 == nsteps) break;
-    // 5. next step: input-projection terms; the pair's first wave waits for the stream's flags and tells the MFMA waves
-    {
-      const int tn = d ? t - 1 : t + 1;
-      if (cellok) gxv = *reinterpret_cast<const float4*>(a.gx + (((size_t)tn * B + b) * 2 + d) * 4 * H + 4 * (size_t)unit);
-    }
-    SK2_STAMP(4);
-    if (mt == 0) {
-      if (!wait_flags(flags0, NUG, (unsigned)(s + 1), a.ctrl, lane, a.poll_delay ? t_pub + 10LL * a.poll_delay : 0LL, fs)) {
-        if (lane == 0) __hip_atomic_store(&s_abort, 1, SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return;
-      }
-      if (lane == 0) __hip_atomic_store(&up[d], r + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    SK2_STAMP(5);
-  }
-  if (w == 8) SK2_FLUSH(a.ctrl, 8, 6);
-#ifdef SK_LSTM_STAMPS
-  if (mt == 0 && lane == 0) {  // every workgroup, both directions: the unused tail of the exchange buffer (diagnostic build only)
-    long long* dbg = reinterpret_cast<long long*>(a.xbuf + (size_t)4 * NBG * xblk) + ((size_t)blockIdx.x * 2 + d) * 16;
-    for (int i = 0; i < 6; ++i) dbg[i] = st2_acc[i];
-    dbg[9] = (long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
-    dbg[10] = ug;
-    dbg[11] = bg;
-  }
-#endif
-  if (cellok) {
-    if (a.s_end == T) {
-      if (a.hn) a.hn[((size_t)d * B + b) * H + unit] = h_reg;
-      if (a.cn) a.cn[((size_t)d * B + b) * H + unit] = c_reg;
-    } else {
-      a.state[((size_t)d * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = c_reg;
     }
   }
 }
@@ -1032,15 +683,11 @@ struct BwdW {
   bf16x8 b[BF ? BwdCfg<KS, BF>::NQ : 1];
 };
 
-// Returns (tagged hand-off only) a per-lane word whose two low bits are non-zero if a word of this sub-block did not carry
-// the epoch `want`.
 template <int KS, bool BF, int SBI>
-__device__ __forceinline__ unsigned bwd_consume(const BwdW<KS, BF>& W, const float* ring, int lane, f32x4& acc0,
-                                                f32x4& acc1, unsigned want = 0u) {
+__device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* ring, int lane, f32x4& acc0, f32x4& acc1) {
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
   const float* src = ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4;
-  unsigned bad = 0u;
 #pragma unroll
   for (int j = 0; j < n; ++j) {
     const int q = SBI * C::SB + j;
@@ -1056,27 +703,8 @@ __device__ __forceinline__ unsigned bwd_consume(const BwdW<KS, BF>& W, const flo
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 1], db.y, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 2], db.z, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 3], db.w, acc1, 0, 0, 0);
-      bad |= (__builtin_bit_cast(unsigned, db.x) ^ want) | (__builtin_bit_cast(unsigned, db.y) ^ want) |
-             (__builtin_bit_cast(unsigned, db.z) ^ want) | (__builtin_bit_cast(unsigned, db.w) ^ want);
     }
   }
-  return bad & 3u;
-}
-
-// Tagged hand-off: OR of (word ^ epoch) over this lane's words of sub-block SBI; the two low bits are zero iff all of them
-// carry the epoch `want`.
-template <int KS, bool BF, int SBI>
-__device__ __forceinline__ unsigned bwd_check(const float* ring, int lane, unsigned want) {
-  using C = BwdCfg<KS, BF>;
-  constexpr int n = C::cnt(SBI);
-  const u32x4* src = reinterpret_cast<const u32x4*>(ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4);
-  unsigned bad = 0u;
-#pragma unroll
-  for (int j = 0; j < n; ++j) {
-    const u32x4 v = src[j * 64];
-    bad |= (v[0] ^ want) | (v[1] ^ want) | (v[2] ^ want) | (v[3] ^ want);
-  }
-  return bad & 3u;
 }
 
 template <int KS, bool BF>
@@ -1095,48 +723,14 @@ __device__ __forceinline__ void bwd_prologue(const float* xbase, unsigned xoff, 
 
 // Sub-block I of the DEPTH-deep ring: wait until it has landed (only the DMAs of the next DEPTH-1 sub-blocks may
 // still be in flight), multiply, and refill its slot with sub-block I+DEPTH.
-// TG (tagged hand-off, fp32): the products of a sub-block are formed speculatively while its words' epochs are checked
-// beside them; if a word was not there yet, the accumulators go back to their values before the sub-block, everything in
-// flight is drained, the sub-block is pulled again and re-checked (bounded; `*ok` false on a time-out or a peer's abort).
-template <int KS, bool BF, bool TG, int I>
+template <int KS, bool BF, int I>
 __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
-                                         unsigned ring_lds, int w, int lane, f32x4& acc0, f32x4& acc1, unsigned want,
-                                         unsigned* ctrl, bool* ok) {
+                                         unsigned ring_lds, int w, int lane, f32x4& acc0, f32x4& acc1) {
   using C = BwdCfg<KS, BF>;
   if constexpr (I < C::NSB) {
     constexpr int younger = bwd_younger<KS, BF>(I);
     wait_vmcnt<younger>();
-    if constexpr (TG) {
-      // check the sub-block's words first (a second pass of LDS reads: no snapshot of the accumulators, the kernel must stay
-      // within 192 VGPRs), pull it again until they are this step's, then multiply
-      unsigned bad = bwd_check<KS, BF, I>(ring, lane, want);
-      if (__any(bad != 0u) && *ok) {
-        const long long t0 = wall_clock64();
-        for (unsigned it = 0;; ++it) {
-          wait_vmcnt<0>();
-          __builtin_amdgcn_s_sleep(2);
-          bwd_issue<KS, BF, I>(xbase, xoff, ring_lds, w, lane);
-          wait_vmcnt<0>();
-          bad = bwd_check<KS, BF, I>(ring, lane, want);
-          if (!__any(bad != 0u)) break;
-          if ((it & 15u) == 15u) {
-            if (__hip_atomic_load(ctrl, SK_RLX, SK_AGENT) != 0u) *ok = false;
-            if (wall_clock64() - t0 > SPIN_TICKS) {
-              if (lane == 0) {
-                __hip_atomic_store(ctrl, 1u, SK_RLX, SK_AGENT);
-                __hip_atomic_store(ctrl - 64, 1u, SK_RLX, SK_AGENT);  // the sticky word
-              }
-              *ok = false;
-            }
-            if (!*ok) break;
-          }
-        }
-      }
-      asm volatile("" ::: "memory");  // the products read the sub-block again (values are not kept in registers)
-      bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
-    } else {
-      bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
-    }
+    bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
     if constexpr (I + C::DEPTH < C::NSB) {
       if constexpr (C::cnt(I + C::DEPTH) > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this ring slot returned before it is refilled
@@ -1144,15 +738,14 @@ __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* 
         bwd_issue<KS, BF, I + C::DEPTH>(xbase, xoff, ring_lds, w, lane);
       }
     }
-    bwd_ring<KS, BF, TG, I + 1>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, want, ctrl, ok);
+    bwd_ring<KS, BF, I + 1>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1);
   }
 }
 
 // Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
-template <int KS, bool BF, bool TG = false>
+template <int KS, bool BF>
 __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
-                                            float (*red)[16][17], int w, int lane, unsigned want = 0u, unsigned* ctrl = nullptr,
-                                            int* abort_word = nullptr) {
+                                            float (*red)[16][17], int w, int lane) {
   // xbase: the exchange buffer (kernel argument: scalar), xoff: byte offset of this stream's block of the step (uniform)
   const unsigned ring_lds = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1160,9 +753,7 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
   // nothing may be scheduled into this region (the cell loads of the step were issued before it).
   __builtin_amdgcn_sched_barrier(0);
   bwd_prologue<KS, BF, 0>(xbase, xoff, ring_lds, w, lane);
-  bool ok = true;
-  bwd_ring<KS, BF, TG, 0>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, want, ctrl, &ok);
-  if (TG && !ok && lane == 0) *abort_word = 1;  // seen by every wave behind the reduce barriers below
+  bwd_ring<KS, BF, 0>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1);
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll
@@ -1179,9 +770,8 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
 // Keep this kernel at 192 VGPRs or fewer (bias-gradient sums live in LDS for that reason): two waves per SIMD then leave 128 registers per lane for ONE co-resident GEMM wave (the
 // weight-gradient GEMMs of the layer above run next to this recurrence on the same CUs, sepkern/engine.py); at 200+
 // no GEMM block fits beside it and the co-scheduling is lost (measured: 39.3 -> 40.9 ms per step).
-template <int KS, bool BF, bool TG = false>
+template <int KS, bool BF>
 __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) void lstm_bwd_kernel(BwdArgs a) {
-  static_assert(!(BF && TG), "the tagged hand-off steals mantissa bits of fp32 words");
   using C = BwdCfg<KS, BF>;
   constexpr int HP = 16 * KS, NQ = C::NQ;
   __shared__ __attribute__((aligned(16))) float ring_all[8][C::DEPTH * C::SB * 256];
@@ -1257,7 +847,6 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
 
   if (owner) *reinterpret_cast<f32x4*>(&st_db[oi][0]) = f32x4{0.f, 0.f, 0.f, 0.f};  // read and written by the same lane only
   bool aborted = false;
-  long long t_self = 0;  // tagged hand-off: when this wave was done with the previous step
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
     for (int gi = 0; gi < G; ++gi) {
@@ -1272,52 +861,39 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
       unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS * fs;
       SK_STAMP(7);
       const bool valid = cellok && t < len_b;
+      const size_t row = (size_t)(a.offs ? a.offs[t] : t * B) + b;  // row of (t, b) in gates / cs / dy / dgx
       // 1. saved activations of this cell (independent of the recurrence: issue early)
       float gi_ = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cprev = 0.f, dyv = 0.f;
       if (valid) {
-        const float4 gv = *reinterpret_cast<const float4*>(a.gates + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit);
+        const float4 gv = *reinterpret_cast<const float4*>(a.gates + (row * 2 + dir) * 4 * H + 4 * (size_t)unit);
         gi_ = gv.x;
         gf = gv.y;
         gg = gv.z;
         go = gv.w;
-        ct = a.cs[(((size_t)t * B + b) * 2 + dir) * H + unit];
+        ct = a.cs[(row * 2 + dir) * H + unit];
         const int tp = dir ? t + 1 : t - 1;
         const bool has_prev = dir ? (t + 1 < len_b) : (t > 0);
-        cprev = has_prev ? a.cs[(((size_t)tp * B + b) * 2 + dir) * H + unit] : a.c0[((size_t)dir * B + b) * H + unit];
-        dyv = a.dy[((size_t)t * B + b) * 2 * H + (size_t)dir * H + unit];
+        const size_t rowp = has_prev ? (size_t)(a.offs ? a.offs[tp] : tp * B) + b : 0;
+        cprev = has_prev ? a.cs[(rowp * 2 + dir) * H + unit] : a.c0[((size_t)dir * B + b) * H + unit];
+        dyv = a.dy[row * 2 * H + (size_t)dir * H + unit];
       }
       // 2. recurrent gradient from the step processed before this one
       float dh_rec = 0.f;
       if (s > 0) {
         const unsigned xo = (unsigned)(((size_t)((((s - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4);
-        if constexpr (TG) {
-          // THE DATA IS THE FLAG (mode bit 29, fp32; see lstm_fwd_kernel): no flags, no barrier -- every wave holds its pull
-          // back by itself and checks the epoch ((s) & 3 for dG_{s-1}) of every word it multiplies
-          if (s > a.s_begin && a.poll_delay) {
-            const long long nb = t_self + 10LL * a.poll_delay;
-            while (wall_clock64() - nb < 0) __builtin_amdgcn_s_sleep(1);
-          }
-          SK_STAMP(0);
-          dh_rec = bwd_matmul<KS, BF, true>(wreg, a.xbuf, xo, ring, red, w, lane, (unsigned)s & 3u, a.ctrl, &s_abort);
-          if (s_abort) {  // (set before the reduce barriers inside the product: every wave sees it)
-            aborted = true;
-            break;
-          }
-        } else {
-          // one wave polls for the whole workgroup: letting every wave wait for just the unit groups of its own
-          // eighth of k' (no barrier before the product) measured SLOWER here (fp32 9.4 -> 10.0 ms, bf16 5.6 -> 5.9)
-          if (s > a.s_begin && w == 0) {
-            if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL, fs) && lane == 0)
-              s_abort = 1;
-          }
-          __syncthreads();
-          if (s_abort) {
-            aborted = true;
-            break;
-          }
-          SK_STAMP(0);
-          dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
+        // one wave polls for the whole workgroup: letting every wave wait for just the unit groups of its own
+        // eighth of k' (no barrier before the product) measured SLOWER here (fp32 9.4 -> 10.0 ms, bf16 5.6 -> 5.9)
+        if (s > a.s_begin && w == 0) {
+          if (!wait_flags(myflags, KS, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub[gi] + 10LL * a.poll_delay : 0LL, fs) && lane == 0)
+            s_abort = 1;
         }
+        __syncthreads();
+        if (s_abort) {
+          aborted = true;
+          break;
+        }
+        SK_STAMP(0);
+        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
         SK_STAMP(2);
       }
       // 3. cell backward (owner waves)
@@ -1350,33 +926,24 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
           bf16x4 pk;
           pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pk), rs, (unsigned)(xoff * 2), 0, 16 /* sc1 */);
-        } else if (TG) {
-          u32x4 tg = __builtin_bit_cast(u32x4, dpre);
-          const unsigned ep = (unsigned)(s + 1) & 3u;
-          tg[0] = (tg[0] & ~3u) | ep; tg[1] = (tg[1] & ~3u) | ep; tg[2] = (tg[2] & ~3u) | ep; tg[3] = (tg[3] & ~3u) | ep;
-          __builtin_amdgcn_raw_buffer_store_b128(tg, rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
         } else {
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, dpre), rs, (unsigned)(xoff * 4), 0, 16 /* sc1 */);
         }
-        if (!TG) wait_vmcnt<0>();  // tagged words need no ordering: nobody is told anything
+        wait_vmcnt<0>();
         SK_STAMP(5);
       }
-      if constexpr (TG) {
-        t_self = wall_clock64();
-      } else {
-        __syncthreads();
-        if (tid == 0) {
-          __hip_atomic_store(myflags + (size_t)ug * fs, (unsigned)(s + 1), SK_RLX, SK_AGENT);
-          st_tpub[gi] = wall_clock64();
-        }
+      __syncthreads();
+      if (tid == 0) {
+        __hip_atomic_store(myflags + (size_t)ug * fs, (unsigned)(s + 1), SK_RLX, SK_AGENT);
+        st_tpub[gi] = wall_clock64();
       }
       // 5. ... then the bulk store of the step (dgx, zero at padded positions)
-      if (cellok) {
-        *reinterpret_cast<f32x4*>(a.dgx + (((size_t)t * B + b) * 2 + dir) * 4 * H + 4 * (size_t)unit) = dpre;
+      if (valid || (cellok && !a.offs)) {  // (packed rows: positions past a row's end do not exist)
+        *reinterpret_cast<f32x4*>(a.dgx + (row * 2 + dir) * 4 * H + 4 * (size_t)unit) = dpre;
         if (a.dgx_bf) {  // the operand copy the data- and weight-gradient products of the bf16 configuration read (no cast pass)
           bf16x4 pk;
           pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
-          *reinterpret_cast<bf16x4*>(a.dgx_bf + ((size_t)t * B + b) * a.ld_bf + (size_t)dir * 4 * H + 4 * (size_t)unit) = pk;
+          *reinterpret_cast<bf16x4*>(a.dgx_bf + row * a.ld_bf + (size_t)dir * 4 * H + 4 * (size_t)unit) = pk;
         }
       }
       SK_STAMP(6);
@@ -1414,18 +981,12 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
       const int fs = (a.map & 4) ? FSPREAD : 1;
       const unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS * fs;
       const unsigned xo = (unsigned)(((size_t)((((T - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4);
-      float dh_rec;
-      if constexpr (TG) {
-        dh_rec = bwd_matmul<KS, BF, true>(wreg, a.xbuf, xo, ring, red, w, lane, (unsigned)T & 3u, a.ctrl, &s_abort);
-        if (s_abort) return;
-      } else {
-        if (T > a.s_begin && w == 0) {
-          if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane, 0LL, fs) && lane == 0) s_abort = 1;
-        }
-        __syncthreads();
-        if (s_abort) return;
-        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
+      if (T > a.s_begin && w == 0) {
+        if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane, 0LL, fs) && lane == 0) s_abort = 1;
       }
+      __syncthreads();
+      if (s_abort) return;
+      float dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
       if (cellok) {
         dh_rec += st_carry[gi][oi];
         if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
@@ -1439,19 +1000,6 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
   }
 }
 
-
-// dg_first[dir][b][:] = dgx[t0][b][dir][:] with t0 = 0 (forward) / lens[b]-1 (reverse): the dG of the one step of every
-// row whose recurrent input is h0 rather than a stored output (its term of dW_hh pairs with h0).  2B rows of 4H floats.
-__global__ __launch_bounds__(256) void first_dg_kernel(const float* __restrict__ dgx, const int* __restrict__ lens,
-                                                       float* __restrict__ out, int T, int B, int H) {
-  const int b = blockIdx.x % B, dir = blockIdx.x / B;
-  const int len = lens[b];
-  const int t0 = dir ? (len < 1 ? 0 : (len > T ? T : len) - 1) : 0;
-  const float4* src = reinterpret_cast<const float4*>(dgx + (((size_t)t0 * B + b) * 2 + dir) * 4 * H);
-  float4* dst = reinterpret_cast<float4*>(out + ((size_t)dir * B + b) * 4 * H);
-  const bool live = len >= 1;
-  for (int i = threadIdx.x; i < H; i += 256) dst[i] = live ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-}
 
 // Rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g*H + u inside each block of 4H rows: the
 // order of weight_ih / weight_hh / bias rows, gates i,f,g,o) and the recurrence's gate-interleaved order (row 4u + g).
@@ -1495,24 +1043,7 @@ int launch_fwd(const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
 }
 template <int KS, bool BF>
 int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
-  if constexpr (!BF) {
-    if (a.tagged) {
-      hipLaunchKernelGGL((lstm_bwd_kernel<KS, false, true>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
-      return 0;
-    }
-  }
   hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
-  return 0;
-}
-
-// two-stream kernel: KS whose 16-k chunks split into four K quarters
-bool fwd2_supported(int KS) { return KS == 20 || KS == 56 || KS == 64; }
-int dispatch_fwd2(int KS, const FwdArgs& a, int nblocks, hipStream_t st) {
-  switch (KS) {
-    case 20: hipLaunchKernelGGL((lstm_fwd2_kernel<20>), dim3((unsigned)nblocks), dim3(768), 0, st, a); break;
-    case 56: hipLaunchKernelGGL((lstm_fwd2_kernel<56>), dim3((unsigned)nblocks), dim3(768), 0, st, a); break;
-    default: hipLaunchKernelGGL((lstm_fwd2_kernel<64>), dim3((unsigned)nblocks), dim3(768), 0, st, a); break;
-  }
   return 0;
 }
 
@@ -1583,22 +1114,14 @@ extern "C" size_t sk_lstm_workspace_bytes(int T, int B, int H) {
 }
 
 extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
-                           float* y, float* gates, float* cs, float* hn, float* cn, void* ws, int T, int B, int H,
-                           int mode, sk_stream_t stream) {
-  return sk_lstm_fwd_range(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, ws, T, B, H, mode, 0, T, stream);
-}
-
-extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float* h0, const float* c0,
-                                 const int32_t* lens, float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
-                                 int T, int B, int H, int mode, int s_begin, int s_end, sk_stream_t stream) {
+                           const int32_t* offs, float* y, float* gates, float* cs, float* hn, float* cn, void* ws, int T,
+                           int B, int H, int mode, sk_stream_t stream) {
   SK_CHECK_ARG(gx && whh && h0 && c0 && lens && y && ws, "sk_lstm_fwd: null pointer");
-  SK_CHECK_ARG(s_begin >= 0 && s_begin < s_end && s_end <= T, "sk_lstm_fwd: bad step range [%d, %d) of %d", s_begin, s_end, T);
   SK_CHECK_ARG((gates == nullptr) == (cs == nullptr), "sk_lstm_fwd: gates and cs must be given together");
   SK_CHECK_ARG(((uintptr_t)h0 % 16) == 0, "sk_lstm_fwd: h0 must be 16-byte aligned");
   SK_CHECK_ARG(((uintptr_t)gx % 16) == 0 && ((uintptr_t)gates % 16) == 0, "sk_lstm_fwd: gx / gates must be 16-byte aligned");
   int rc = check_common("sk_lstm_fwd", T, B, H, whh, mode);
   if (rc) return rc;
-  const int mode_in = mode;
   const int gmin = (mode >> 8) & 0xff;  // bits 8..15: minimum batch groups per workgroup (frees CUs for concurrent kernels)
   const bool bf = (mode >> 16) & 1;     // bit 16: bf16 matrix-core inputs
   const bool half = (mode >> 17) & 1;   // bit 17: 8-unit, 256-thread workgroups, two per CU
@@ -1609,13 +1132,12 @@ extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float*
   const bool tagged = ((mode >> 29) & 1) && !((mode >> 16) & 1) && !((mode >> 17) & 1);  // bit 29 (fp32, 8-wave workgroups)
   if (tagged) opt |= 8;                // the data is the flag (lstm_fwd_kernel)
   int poll_delay = (mode >> 23) & 31;  // bits 23..27: FwdArgs::poll_delay, units of 0.1 us; 0 = choose, 31 = none
-  const bool dual = (mode >> 28) & 1;  // bit 28: two-stream workgroups (8 units x both directions), where the shape allows
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
   FwdArgs a;
-  a.gx = gx; a.whh = whh; a.h0 = h0; a.c0 = c0; a.lens = lens;
+  a.gx = gx; a.whh = whh; a.h0 = h0; a.c0 = c0; a.lens = lens; a.offs = offs;
   a.y = y; a.gates = gates; a.cs = cs; a.hn = hn; a.cn = cn;
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
@@ -1633,21 +1155,13 @@ extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float*
   a.map = map; a.nby = nby; a.opt = opt; a.poll_delay = poll_delay;
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_fwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));  // per-launch status word + flags (not the sticky word)
-  if ((opt & 8) && s_begin == 0 && (mode & 0xff) != 2)  // tagged words: a new sequence must not find an old one's epochs in the buffers
+  if ((opt & 8) && mode != 2)  // tagged words: a new sequence must not find an old one's epochs in the buffers
     SK_CHECK_HIP(hipMemsetAsync(base + L.xbuf, 0, L.state - L.xbuf, st));
-  if (dual && !bf && !half && mode != 2 && gmin <= 1 && fwd2_supported(L.KS) && 2 * L.KS * L.NBG <= num_cus()) {
-    // one 768-thread workgroup per CU (131-147 KB of LDS): 2 KS unit groups x NBG batch groups, both directions each
-    a.G = 1; a.nby = L.NBG; a.s_begin = s_begin; a.s_end = s_end;
-    a.poll_delay = ((mode_in >> 23) & 31) == 31 ? 0 : (((mode_in >> 23) & 31) ? ((mode_in >> 23) & 31) : 8);
-    dispatch_fwd2(L.KS, a, 2 * L.KS * L.NBG, st);
-    SK_CHECK_LAUNCH("sk_lstm_fwd");
-    return SK_OK;
-  }
   if (mode == 1 || (mode == 0 && fits)) {
-    a.s_begin = s_begin; a.s_end = s_end;
+    a.s_begin = 0; a.s_end = T;
     dispatch_fwd(L.KS, bf, a, half, nblocks, st);
-  } else {
-    for (int s = s_begin; s < s_end; ++s) {
+  } else {  // one launch per step: the state travels through the workspace
+    for (int s = 0; s < T; ++s) {
       a.s_begin = s; a.s_end = s + 1;
       dispatch_fwd(L.KS, bf, a, half, nblocks, st);
     }
@@ -1656,37 +1170,13 @@ extern "C" int sk_lstm_fwd_range(const float* gx, const float* whh, const float*
   return SK_OK;
 }
 
-extern "C" int sk_lstm_bwd(const float* dy, const float* whh, const float* gates, const float* cs, const float* c0,
-                           const int32_t* lens, float* dgx, float* dh0, float* dc0, void* ws, int T, int B, int H,
+extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
+                           const float* cs, const float* c0, const int32_t* lens, const int32_t* offs, float* dgx,
+                           float* dh0, float* dc0, float* dbias, void* dgx_bf16, int ld_bf16, void* ws, int T, int B, int H,
                            int mode, sk_stream_t stream) {
-  return sk_lstm_bwd_state(dy, nullptr, nullptr, whh, gates, cs, c0, lens, dgx, dh0, dc0, nullptr, nullptr, ws, T, B, H,
-                           mode, stream);
-}
-
-extern "C" int sk_lstm_bwd_state(const float* dy, const float* dhn, const float* dcn, const float* whh,
-                                 const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
-                                 float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
-                                 int mode, sk_stream_t stream) {
-  return sk_lstm_bwd_range(dy, dhn, dcn, whh, gates, cs, c0, lens, dgx, dh0, dc0, dbias, dg_first, ws, T, B, H, mode, 0, T,
-                           stream);
-}
-
-extern "C" int sk_lstm_bwd_range(const float* dy, const float* dhn, const float* dcn, const float* whh,
-                                 const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
-                                 float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
-                                 int mode, int s_begin, int s_end, sk_stream_t stream) {
-  return sk_lstm_bwd_twin(dy, dhn, dcn, whh, gates, cs, c0, lens, dgx, dh0, dc0, dbias, dg_first, ws, T, B, H, mode, s_begin,
-                          s_end, nullptr, 0, stream);
-}
-
-extern "C" int sk_lstm_bwd_twin(const float* dy, const float* dhn, const float* dcn, const float* whh,
-                                const float* gates, const float* cs, const float* c0, const int32_t* lens, float* dgx,
-                                float* dh0, float* dc0, float* dbias, float* dg_first, void* ws, int T, int B, int H,
-                                int mode, int s_begin, int s_end, void* dgx_bf16, int ld_bf16, sk_stream_t stream) {
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
   SK_CHECK_ARG(!dgx_bf16 || (ld_bf16 >= 8 * H && ld_bf16 % 4 == 0 && ((uintptr_t)dgx_bf16 % 8) == 0),
                "sk_lstm_bwd: bf16 twin needs ld >= 8H, ld %% 4 == 0, 8-byte alignment");
-  SK_CHECK_ARG(s_begin >= 0 && s_begin < s_end && s_end <= T, "sk_lstm_bwd: bad step range [%d, %d) of %d", s_begin, s_end, T);
   SK_CHECK_ARG(((uintptr_t)gates % 16) == 0 && ((uintptr_t)dgx % 16) == 0, "sk_lstm_bwd: gates / dgx must be 16-byte aligned");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
   if (rc) return rc;
@@ -1696,13 +1186,12 @@ extern "C" int sk_lstm_bwd_twin(const float* dy, const float* dhn, const float* 
   // (7.59 -> 7.50 us/step) and not kept
   const int map = ((mode >> 18) & 3) | (((mode >> 22) & 1) << 2);
   int poll_delay = (mode >> 23) & 31;  // as sk_lstm_fwd; 0 = none here until measured otherwise
-  const bool tagged = ((mode >> 29) & 1) && !bf;  // bit 29 (fp32): the data is the flag
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
   BwdArgs a;
-  a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens;
+  a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens; a.offs = offs;
   a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0; a.dhn = dhn; a.dcn = dcn;
   a.dbias = dbias;
   a.dgx_bf = (__bf16*)dgx_bf16; a.ld_bf = ld_bf16;
@@ -1715,31 +1204,26 @@ extern "C" int sk_lstm_bwd_twin(const float* dy, const float* dhn, const float* 
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
   if (poll_delay == 31) poll_delay = 0;
-  a.map = map; a.nby = nby; a.poll_delay = poll_delay; a.tagged = tagged ? 1 : 0;
+  a.map = map; a.nby = nby; a.poll_delay = poll_delay;
   dim3 grid((unsigned)L.KS, (unsigned)nby, 2);
   SK_CHECK_ARG(mode != 1 || fits, "sk_lstm_bwd: persistent mode cannot keep B=%d H=%d co-resident on %d CUs", B, H, num_cus());
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));
-  if (tagged && s_begin == 0)  // tagged words: a new sequence must not find an old one's epochs in the exchange buffers
-    SK_CHECK_HIP(hipMemsetAsync(base + L.xbuf, 0, L.state - L.xbuf, st));
-  if (dbias && s_begin == 0)  // (the kernels ADD their sums: a sequence advanced in several launches accumulates)
+  if (dbias)  // (the kernels ADD their sums: a sequence advanced in step launches accumulates)
     SK_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)L.NBG * 8 * H * sizeof(float), st));  // rows >= grid y stay 0
-  const bool last = s_end == T;
   if (mode == 1 || (mode == 0 && fits)) {
-    a.s_begin = s_begin; a.s_end = s_end; a.final_mm = last ? want_d0 : 0;  // not the last range: the state goes to the workspace
+    a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;
     dispatch_bwd(L.KS, bf, a, grid, st);
   } else {
     a.final_mm = 0;  // a step launch never waits on other workgroups
-    for (int s = s_begin; s < s_end; ++s) {
+    for (int s = 0; s < T; ++s) {
       a.s_begin = s; a.s_end = s + 1;
       dispatch_bwd(L.KS, bf, a, grid, st);
     }
-    if (want_d0 && last) {
+    if (want_d0) {
       a.s_begin = T; a.s_end = T; a.final_mm = 1;
       dispatch_bwd(L.KS, bf, a, grid, st);
     }
   }
-  if (dg_first && last)
-    hipLaunchKernelGGL(first_dg_kernel, dim3((unsigned)(2 * B)), dim3(256), 0, st, dgx, lens, dg_first, T, B, H);
   SK_CHECK_LAUNCH("sk_lstm_bwd");
   return SK_OK;
 }

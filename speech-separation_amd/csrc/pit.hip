@@ -6,6 +6,10 @@
 // by wavefront reduction (HBM-bound: (2S+1)*F*4 bytes per frame), and the S! permutation sums,
 // the per-utterance arg-min and the scalar loss are formed from it by a tiny finalize kernel.
 // Reductions use fixed-order partial sums (no atomics), so results are run-to-run reproducible.
+//
+// Row layouts: padded time-major (row of (t, b) = t*B + b, zeros past an utterance's end) or, with an offset table
+// `offs` (T+1 entries), PACKED rows exactly as torch's PackedSequence.data holds them (archs/uPIT.py:46,167: row of
+// (t, b) = offs[t] + b for t < lens[b], lens sorted descending) -- the layout the reference's collator produces.
 #include "sk_common.h"
 
 namespace {
@@ -20,7 +24,8 @@ struct SrcPtrs {
 
 template <int S>
 __global__ __launch_bounds__(256) void pit_pair_kernel(const float* __restrict__ mask, const float* __restrict__ mix,
-                                                       SrcPtrs src, int T, int B, int F,
+                                                       SrcPtrs src, const int32_t* __restrict__ lens,
+                                                       const int32_t* __restrict__ offs, int T, int B, int F,
                                                        float* __restrict__ partial /* (B, nch, S*S) */) {
   __shared__ float red[4];
   const int b = blockIdx.y, ch = blockIdx.x, nch = gridDim.x;
@@ -30,10 +35,11 @@ __global__ __launch_bounds__(256) void pit_pair_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < S; ++r) acc[s][r] = 0.f;
   // the chunk's frames x bins as one flat range, so that F = 257 does not leave a nearly empty second sweep
-  const int t0 = ch * TCH, nel = (min(T, t0 + TCH) - t0) * F;
+  const int Tb = offs ? min(T, lens[b]) : T;  // packed rows end with the utterance
+  const int t0 = ch * TCH, nel = max(0, min(Tb, t0 + TCH) - t0) * F;
   for (int i = threadIdx.x; i < nel; i += 256) {
     const int dt = i / F, f = i - dt * F;
-    const int64_t row = (int64_t)(t0 + dt) * B + b;
+    const int64_t row = (offs ? (int64_t)offs[t0 + dt] : (int64_t)(t0 + dt) * B) + b;
     const float mx = mix[row * F + f];
     float sv[S];
 #pragma unroll
@@ -121,11 +127,25 @@ template <int S>
 __global__ __launch_bounds__(256) void pit_bwd_kernel(const float* __restrict__ mask, const float* __restrict__ mix,
                                                       SrcPtrs src, const int32_t* __restrict__ best_perm,
                                                       const float* __restrict__ out, const float* __restrict__ gscale,
-                                                      int T, int B, int F, float* __restrict__ dmask) {
+                                                      const int32_t* __restrict__ offs, int64_t nrows, int T, int B, int F,
+                                                      float* __restrict__ dmask) {
   __shared__ int perm[RB][MAXS];
-  const int64_t row0 = (int64_t)blockIdx.x * RB, nrows = (int64_t)T * B;  // row = t*B + b
-  if (threadIdx.x < RB && row0 + threadIdx.x < nrows)
-    nth_perm(best_perm[(int)((row0 + threadIdx.x) % B)], S, perm[threadIdx.x]);
+  const int64_t row0 = (int64_t)blockIdx.x * RB;  // padded: row = t*B + b; packed: row = offs[t] + b
+  if (threadIdx.x < RB && row0 + threadIdx.x < nrows) {
+    const int64_t row = row0 + threadIdx.x;
+    int b;
+    if (offs) {
+      int lo = 0, hi = T;  // the t with offs[t] <= row < offs[t+1]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)offs[mid] <= row) lo = mid; else hi = mid;
+      }
+      b = (int)(row - offs[lo]);
+    } else {
+      b = (int)(row % B);
+    }
+    nth_perm(best_perm[b], S, perm[threadIdx.x]);
+  }
   __syncthreads();
   const float k = gscale[0] * 2.0f / ((float)S * out[1]);
   const int nel = (int)min((int64_t)RB, nrows - row0) * F;
@@ -149,8 +169,8 @@ extern "C" size_t sk_pit_workspace_bytes(int T, int B, int S) {
 }
 
 extern "C" int sk_pit_mse_fwd(const float* mask, const float* mix, const float* const* src_host, const int32_t* lens,
-                              int T, int B, int F, int S, const float* norm_dev, float* pair_sse, float* perm_loss,
-                              int32_t* best_perm, float* out, void* ws, sk_stream_t stream) {
+                              const int32_t* offs, int T, int B, int F, int S, const float* norm_dev, float* pair_sse,
+                              float* perm_loss, int32_t* best_perm, float* out, void* ws, sk_stream_t stream) {
   SK_CHECK_ARG(mask && mix && src_host && lens && pair_sse && perm_loss && best_perm && out && ws,
                "sk_pit_mse_fwd: null pointer");
   SK_CHECK_ARG(S >= 1 && S <= MAXS, "sk_pit_mse_fwd: num_spk %d outside 1..%d", S, MAXS);
@@ -162,10 +182,10 @@ extern "C" int sk_pit_mse_fwd(const float* mask, const float* mix, const float* 
   float* partial = (float*)ws;
   hipStream_t st = (hipStream_t)stream;
   switch (S) {
-    case 1: hipLaunchKernelGGL(pit_pair_kernel<1>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
-    case 2: hipLaunchKernelGGL(pit_pair_kernel<2>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
-    case 3: hipLaunchKernelGGL(pit_pair_kernel<3>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
-    default: hipLaunchKernelGGL(pit_pair_kernel<4>, grid, dim3(256), 0, st, mask, mix, sp, T, B, F, partial); break;
+    case 1: hipLaunchKernelGGL(pit_pair_kernel<1>, grid, dim3(256), 0, st, mask, mix, sp, lens, offs, T, B, F, partial); break;
+    case 2: hipLaunchKernelGGL(pit_pair_kernel<2>, grid, dim3(256), 0, st, mask, mix, sp, lens, offs, T, B, F, partial); break;
+    case 3: hipLaunchKernelGGL(pit_pair_kernel<3>, grid, dim3(256), 0, st, mask, mix, sp, lens, offs, T, B, F, partial); break;
+    default: hipLaunchKernelGGL(pit_pair_kernel<4>, grid, dim3(256), 0, st, mask, mix, sp, lens, offs, T, B, F, partial); break;
   }
   SK_CHECK_LAUNCH("pit_pair_kernel");
   hipLaunchKernelGGL(pit_finalize_kernel, dim3(1), dim3(256), 0, st, partial, nch, lens, B, F, S, norm_dev,
@@ -175,20 +195,22 @@ extern "C" int sk_pit_mse_fwd(const float* mask, const float* mix, const float* 
 }
 
 extern "C" int sk_pit_mse_bwd(const float* mask, const float* mix, const float* const* src_host,
-                              const int32_t* best_perm, const float* out, const float* gscale, int T, int B, int F,
-                              int S, float* dmask, sk_stream_t stream) {
+                              const int32_t* best_perm, const float* out, const float* gscale, const int32_t* offs,
+                              int64_t nrows, int T, int B, int F, int S, float* dmask, sk_stream_t stream) {
   SK_CHECK_ARG(mask && mix && src_host && best_perm && out && gscale && dmask, "sk_pit_mse_bwd: null pointer");
   SK_CHECK_ARG(S >= 1 && S <= MAXS, "sk_pit_mse_bwd: num_spk %d outside 1..%d", S, MAXS);
   SK_CHECK_ARG(T > 0 && B > 0 && F > 0, "sk_pit_mse_bwd: bad sizes");
+  if (!offs) nrows = (int64_t)T * B;
+  SK_CHECK_ARG(nrows > 0 && nrows <= (int64_t)T * B, "sk_pit_mse_bwd: %lld packed rows for T=%d B=%d", (long long)nrows, T, B);
   SrcPtrs sp;
   for (int s = 0; s < MAXS; ++s) sp.p[s] = s < S ? src_host[s] : nullptr;
-  dim3 grid((unsigned)sk_cdiv((int64_t)T * B, RB));
+  dim3 grid((unsigned)sk_cdiv(nrows, RB));
   hipStream_t st = (hipStream_t)stream;
   switch (S) {
-    case 1: hipLaunchKernelGGL(pit_bwd_kernel<1>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;
-    case 2: hipLaunchKernelGGL(pit_bwd_kernel<2>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;
-    case 3: hipLaunchKernelGGL(pit_bwd_kernel<3>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;
-    default: hipLaunchKernelGGL(pit_bwd_kernel<4>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, T, B, F, dmask); break;
+    case 1: hipLaunchKernelGGL(pit_bwd_kernel<1>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, offs, nrows, T, B, F, dmask); break;
+    case 2: hipLaunchKernelGGL(pit_bwd_kernel<2>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, offs, nrows, T, B, F, dmask); break;
+    case 3: hipLaunchKernelGGL(pit_bwd_kernel<3>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, offs, nrows, T, B, F, dmask); break;
+    default: hipLaunchKernelGGL(pit_bwd_kernel<4>, grid, dim3(256), 0, st, mask, mix, sp, best_perm, out, gscale, offs, nrows, T, B, F, dmask); break;
   }
   SK_CHECK_LAUNCH("pit_bwd_kernel");
   return SK_OK;

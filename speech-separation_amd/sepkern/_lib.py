@@ -13,7 +13,7 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEPKERN_LIB") or os.path.join(_HERE, "libsepkern.so")   # SEPKERN_LIB: diagnostic builds
 
-SK_VERSION = 113
+SK_VERSION = 120
 
 _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -32,21 +32,18 @@ PROTOTYPES = {
     "sk_gemm_bf16_splitk": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "sk_gemm_bf16_nt": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "sk_gemm_bf16_mm": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
-    "sk_cast_bf16": (_i, [_p, _i, _i, _i, _p, _i, _p]),
     "sk_cast_bf16_rows": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
-    "sk_cast_bf16_t": (_i, [_p, _i, _i, _i, _p, _i, _p]),
+    "sk_pack_rows": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),
+    "sk_unpack_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "sk_hprev_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "sk_lstm_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sk_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "sk_lstm_fwd_range": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "sk_lstm_bwd_state": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "sk_lstm_bwd_range": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "sk_lstm_bwd_twin": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "sk_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_status": (_i, [_p, _p]),
     "sk_gate_rows": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "sk_bn_workspace_bytes": (_sz, [_i, _i]),
-    "sk_bn_stats": (_i, [_p, _i, _i, _p, _p, _p, _p]),
-    "sk_bn_update_running": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
+    "sk_bn_stats": (_i, [_p, _i, _i, _i64, _p, _p, _p, _p]),
+    "sk_bn_update_running": (_i, [_p, _p, _p, _p, _i64, _i, _f, _p, _p]),
     "sk_bn_apply": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "sk_bn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "sk_bn_fold": (_i, [_p, _p, _p, _p, _p, _p, _f, _i, _i, _p, _i, _p, _p, _p, _p]),
@@ -55,10 +52,10 @@ PROTOTYPES = {
     "sk_bn_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, C.c_double, _f, _p]),
     "sk_colsum": (_i, [_p, _i, _i, _i, _p, _i, _p, _p]),
     "sk_sigmoid_bwd": (_i, [_p, _p, _p, _i64, _p]),
-    "sk_pad_rows": (_i, [_p, _i64, _i, _i, _p, _i, _p]),
+    "sk_pad_rows": (_i, [_p, _i64, _i, _i, _p, _i, _i64, _p]),
     "sk_pit_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sk_pit_mse_fwd": (_i, [_p, _p, C.POINTER(_p), _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
-    "sk_pit_mse_bwd": (_i, [_p, _p, C.POINTER(_p), _p, _p, _p, _i, _i, _i, _i, _p, _p]),
+    "sk_pit_mse_fwd": (_i, [_p, _p, C.POINTER(_p), _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p]),
+    "sk_pit_mse_bwd": (_i, [_p, _p, C.POINTER(_p), _p, _p, _p, _p, _i64, _i, _i, _i, _i, _p, _p]),
     "sk_rsh_workspace_bytes": (_sz, [_i, _i, _i]),
     "sk_rsh_loss_fwd": (_i, [_p, _p, _i, C.POINTER(_p), _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p]),
     "sk_rsh_loss_bwd": (_i, [_p, _p, _i, C.POINTER(_p), _p, _p, _i, _i, _i, _i, _p, _p]),

@@ -150,21 +150,25 @@ def overlap_enabled():
     return os.environ.get("SEPKERN_DP_OVERLAP", "0") == "1"
 
 
-def combine_bn_stats(mean, var, count):
-    """Per-rank batch statistics (mean, biased variance over `count` rows) -> statistics of the union of all ranks'
-    rows, by the pairwise-combination formula M2 = sum_r n_r (var_r + (mean_r - mean)^2).  One all-gather.
-    Returns (mean, var, total_count); the inputs unchanged when not parallel."""
+def combine_bn_stats(mean, var, B, T):
+    """Per-rank batch statistics (mean, biased variance over this rank's zero-padded (B, T) grid of frames) -> statistics
+    of the GLOBAL batch's grid, (sum of the ranks' B) x (longest utterance of any rank), by the pairwise-combination
+    formula M2 = sum_r n_r (var_r + (mean_r - mean)^2): a rank whose longest utterance is shorter than the global one
+    contributes B_r (T_max - T_r) further all-zero frames, as the reference's pad_packed_sequence of the global batch would
+    hold them (archs/uPIT.py:135-138).  One all-gather.  Returns (mean, var, total_count); unchanged when not parallel."""
     if not is_parallel():
-        return mean, var, float(count)
+        return mean, var, float(B * T)
     C = mean.numel()
-    mine = torch.cat([mean.reshape(-1), var.reshape(-1), mean.new_full((1,), float(count))])
+    mine = torch.cat([mean.reshape(-1), var.reshape(-1), mean.new_tensor([float(B), float(T)])])
     allr = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(allr, mine)
-    st = torch.stack(allr)                                   # (world, 2C+1)
-    n = st[:, 2 * C:2 * C + 1]                               # (world, 1)
-    total = n.sum()
+    st = torch.stack(allr)                                   # (world, 2C+2)
+    Br, Tr = st[:, 2 * C:2 * C + 1], st[:, 2 * C + 1:2 * C + 2]
+    n = Br * Tr                                              # (world, 1) frames of every rank's own grid
+    total = (Br * Tr.max()).sum()
+    n_zero = total - n.sum()                                 # frames of the global grid that no rank's grid holds: zeros
     gmean = (st[:, :C] * n).sum(0) / total
-    gvar = (n * (st[:, C:2 * C] + (st[:, :C] - gmean) ** 2)).sum(0) / total
+    gvar = ((n * (st[:, C:2 * C] + (st[:, :C] - gmean) ** 2)).sum(0) + n_zero * gmean ** 2) / total
     return gmean.contiguous(), gvar.contiguous(), float(total.item())
 
 

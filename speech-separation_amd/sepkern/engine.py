@@ -1,8 +1,10 @@
 """The uPIT network (BLSTM -> BatchNorm1d -> Linear -> sigmoid) as a sequence of libsepkern calls.
 
 Mirrors SepDNN.forward of the reference (archs/uPIT.py:129-147) and the backward torch's autograd
-would run for it, on padded time-major (T, B, C) tensors with per-row lengths instead of
-PackedSequences.  All parameters live in ONE flat fp32 buffer (and all gradients in another):
+would run for it, on PACKED rows -- the layout of the PackedSequence the reference's collator builds
+(archs/uPIT.py:46) and nn.LSTM consumes (:132): only the R = sum(lens) valid frames of a length-sorted
+batch exist (sepkern.packing.Packing), so no product, statistic or store touches a padded frame.
+All parameters live in ONE flat fp32 buffer (and all gradients in another):
   * the LSTM kernels want (2, 4H, *) blocks (both directions of a layer) contiguous,
   * data-parallel training all-reduces one buffer (RCCL, one collective per step),
   * clip_grad_norm_ + Adam run as one fused pass over it (sepkern.optim).
@@ -87,17 +89,12 @@ class Engine:
         # gradients) rounds both operands to bf16 on the way into the matrix cores and accumulates in fp32;
         # parameters, activations, cell state, gradients, BatchNorm, the loss and Adam stay fp32.
         self.precision, self.bf16 = precision, precision == "bf16"
-        # bf16 products read bf16 COPIES of their operands (sk_cast_bf16 / sk_cast_bf16_t, transposed where the product
-        # needs it so that every product is the one NT form of sk_gemm_bf16_nt); SEPKERN_BF16_NT=0 keeps the r01 kernel
-        # that reads fp32 operands and rounds them on the way into LDS (same arithmetic, half the speed)
-        self.nt = self.bf16 and os.environ.get("SEPKERN_BF16_NT", "1") == "1"
-        # ... and (r03) only ROW-MAJOR copies: a factor whose rows are the contraction index (both factors of a weight
-        # gradient, the weight matrix of a data gradient) enters the product K-major (sk_gemm_bf16_mm: the tile is DMA'd as
-        # it lies and transposed by ds_read_b64_tr_b16 on the way into the matrix cores), so the 12 transposed copies per
-        # step (sk_cast_bf16_t, 0.94 ms) are never made.  SEPKERN_BF16_KMAJOR=0 keeps the r02 path with transposed copies.
-        self.kmajor = self.nt and hidden % 8 == 0 and os.environ.get("SEPKERN_BF16_KMAJOR", "1") == "1"
-        # ... and the backward recurrence writes the bf16 copy of dgx itself (sk_lstm_bwd_twin); SEPKERN_BF16_TWIN=0: cast pass
-        self.bf16_twin = os.environ.get("SEPKERN_BF16_TWIN", "1") == "1"
+        # bf16 products read ROW-MAJOR bf16 copies of their operands (sk_cast_bf16_rows; the backward recurrence writes the
+        # copy of dgx itself, sk_hprev_rows the recurrent inputs): a factor whose rows are the contraction index (both factors
+        # of a weight gradient, the weight matrix of a data gradient) enters the product K-major (sk_gemm_bf16_mm).  Hidden
+        # sizes that are no multiple of 8 (none of BASELINE's) take the kernel that reads fp32 operands and rounds them on
+        # the way into LDS -- same arithmetic, half the speed.
+        self.nt = self.bf16 and hidden % 8 == 0
         # data-parallel runs only: BatchNorm over the GLOBAL batch instead of per rank (sepkern/dist.py)
         self.sync_bn = bool(sync_bn) or os.environ.get("SEPKERN_SYNC_BN", "0") == "1"
         if hidden % 4 != 0 or hidden > 1024:
@@ -119,48 +116,42 @@ class Engine:
         self.running_var = torch.ones(2 * hidden, device=device)
         self.eps, self.momentum = 1e-5, 0.1
         self.lstm_mode = int(os.environ.get("SEPKERN_LSTM_MODE", "0"))
-        # forward recurrence geometry (speed only): "half,map" -- half=1: 8-unit / 256-thread workgroups, two per CU;
-        # map 0..2: block id -> stream assignment (csrc/lstm.hip::decode_block)
+
+        # hand-off geometry / protocol of the persistent recurrences (speed only): "half,map,poll1,repflags,
+        # spread,delay,tagged".  Forward: streams dealt to XCD groups, one polling wave, first poll held back (delay 0 = the
+        # library's choice); bf16: one flag per 128-byte line on top.  fp32 forward: THE DATA IS THE FLAG (tagged = 1, hold-back
+        # 0.8 us): the exchanged h carries the step's epoch in its two low mantissa bits -- h entering the next step's product
+        # is perturbed by at most 3 ulp, everything stored is exact; SEPKERN_LSTM_FWD=0,1,1,0,0,0,0 is the exact hand-off
+        # (0.5 ms per training step slower; bench.py's config.numerics says which one ran).  Backward: the XCD map only.
         def variant(env, default):
             v = [int(x) for x in os.environ.get(env, default).split(",")]
-            v += [0] * (8 - len(v))
-            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5], dual=bool(v[6]), tagged=bool(v[7]))
-        # "half,map,poll1,repflags,spread,delay[,dual[,tagged]]" (dual: the two-stream forward kernel, tagged:
-        # the data-is-the-flag hand-off, both 5c).  Forward: streams dealt to XCD groups, one polling wave,
-        # first poll held back (delay 0 = the library's choice); r02: 7.33 -> 6.0 us/step in fp32, 4.0 -> 3.0 in bf16, where
-        # one flag per 128-byte line is worth another 5 %.  Backward: the XCD map only (8.00 -> 7.25; it polls later anyway).
-        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0" if self.bf16 else "0,1,1,0,0,8,0,1")
-        # fp32 forward (r03): the data is the flag (tagged = 1, mode bit 29; hold-back 0.8 us): the exchanged h carries the
-        # step's epoch in its two low mantissa bits, no drain / barrier / flag / poll: 7.44 -> 7.02 ms of forward recurrences
-        # per training step (37.1 -> 36.6 ms), h entering the next step's product perturbed by at most 3 ulp
-        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31")
-        # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one.
-        # SEPKERN_OVERLAP=2 (default): the recurrence keeps its one-workgroup-per-CU grid and the GEMM blocks
-        # become CO-RESIDENT on its CUs -- a persistent workgroup leaves >=124 VGPRs per SIMD lane and >=69 KB of
-        # LDS free, and the matrix pipe idle during its hand-offs -- : 42.9 -> 40.5 ms/step at 3x896, 32x400 (the
-        # co-scheduled GEMMs run at ~1/3 of their stand-alone rate, the recurrence 25 % slower, net +6 %).
-        # =1: recurrence on half the CUs (2 batch groups per workgroup), GEMMs on the rest: +1.3 % only, the
-        # hand-off chain slows from 9.5 to 15.6 ms/step under the GEMMs' L2/fabric load.  =0: no overlap.
-        self.overlap_mode = int(os.environ.get("SEPKERN_OVERLAP", "2"))
-        self.overlap = self.overlap_mode in (1, 2)
-        # forward: recurrences in two launches with half of the next input projection beside the second (see forward())
-        self.fwd_split = os.environ.get("SEPKERN_FWD_SPLIT", "0") == "1"
-        # fp32 GEMM kernel per stream (sk_gemm_f32_splitk's variant): "main,side".  Default: choose (LDS-DMA where it
-        # applies) on the main stream, the register-staged kernel for products that run beside a recurrence (_wgrad).
-        # "2,2": every product by the exact three-way bf16 split on the bf16 matrix pipe (opt-in).
-        self.dgrad_unsplit = os.environ.get("SEPKERN_DGRAD_UNSPLIT", "1") == "1"
-        # backward recurrences in two launches, half of a layer's own weight-gradient products beside the second
-        # (backward(); built, parity-tested, measured 38.7 vs 37.7 ms per step: off)
-        self.bwd_split = os.environ.get("SEPKERN_BWD_SPLIT", "0") == "1"
+            v += [0] * (7 - len(v))
+            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5], tagged=bool(v[6]))
+        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0,0" if self.bf16 else "0,1,1,0,0,8,1")
+        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31,0")
+        self.tagged_fwd = bool(self.fwd_bits & 0x20000000) and not self.bf16
+        # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one: the
+        # recurrence keeps its one-workgroup-per-CU grid and the GEMM blocks become CO-RESIDENT on its CUs -- a persistent
+        # workgroup leaves >= 124 VGPRs per SIMD lane and >= 69 KB of LDS free, and the matrix pipe idle during its
+        # hand-offs (42.9 -> 40.5 ms per step in r01).  SEPKERN_OVERLAP=0: everything on one stream (tests: bitwise equal).
+        self.overlap = os.environ.get("SEPKERN_OVERLAP", "1") != "0"
         # BatchNorm folded into the Linear layer (fp32 path; the bf16 arithmetic is DEFINED with bn(y) and W rounded
         # separately, oracle/upit_bf16.py, so that path keeps the explicit normalisation)
         self.bn_fold = os.environ.get("SEPKERN_BN_FOLD", "1") == "1" and not self.bf16
+        # fp32 GEMM kernel per stream (sk_gemm_f32_splitk's variant): "main,side".  Default: choose (LDS-DMA / stream-K where
+        # they apply) on the main stream, the register-staged kernel for products that run beside a recurrence.
         self.var_main, self.var_side = (int(v) for v in os.environ.get("SEPKERN_GEMM_VARIANTS", "0,1").split(","))
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
+        self.version = 0               # bumped by whoever writes the parameters (ClipAdam, load_state_dict): see backward()
 
     def p(self, name):
         return self.layout.view(self.flat, name)
+
+    def param_version(self):
+        """Changes whenever the parameters were written: `version` is bumped by sepkern.optim.ClipAdam (its kernel writes
+        through raw pointers), torch's own counter covers in-place torch ops on the flat buffer or its views."""
+        return (self.version, self.flat._version)
 
     def g(self, name):
         return self.layout.view(self.grad, name)
@@ -178,152 +169,125 @@ class Engine:
         """The workspace's sticky status word as a device tensor (1 element, int32): non-zero after a timed-out launch."""
         return ops.lstm_sticky(ops.workspace(0, "lstm"))
 
+    def pad_row(self):
+        """(out_dim,) the mask the reference's network shows at a zero-padded frame with the statistics of the last forward:
+        sigmoid(lin(bn(0))) (archs/uPIT.py:135-144 run BatchNorm / Linear / sigmoid over the padded (B, T_max) grid).  The
+        engine never computes padded frames; callers that hand out padded masks (SepDNN.forward, run_net) fill them in."""
+        mean, var = self._last_bn
+        Wf, bf_, _, _ = ops.bn_fold(self.p("lin.weight"), self.p("lin.bias"), mean, var, self.p("bn.weight"), self.p("bn.bias"),
+                                    self.eps)
+        zero = torch.zeros(1, 2 * self.H, device=self.device)
+        row = torch.empty(1, self.O, device=self.device)
+        ops.gemm(zero, Wf, row, 1, self.O, 2 * self.H, 2 * self.H, 2 * self.H, self.O, transB=True, bias=bf_, act=1)
+        return row.view(-1)
+
+    def _side_stream(self, dev):
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        return self.side
+
     # ------------------------------------------------------------------ the three kinds of product
-    # fp32: the fp32 MFMA kernel on the fp32 tensors.  bf16: sk_gemm_bf16_nt on bf16 copies; `cache` (one dict per
-    # pass) holds the copies already made, keyed by (kind, id of the fp32 tensor), and keeps them alive.
+    # All of them over packed rows: operands are (Rp, C) row buffers with zero tail rows; row-parallel products write the
+    # R valid rows, contractions over rows run over all Rp (whole K steps).
+    # fp32: the fp32 MFMA kernels on the fp32 tensors.  bf16: sk_gemm_bf16_nt / _mm on bf16 copies; `cache` (one dict per
+    # step) holds the copies already made, keyed by (address, shape) of the fp32 tensor, and keeps them alive.
     @staticmethod
-    def _copy(cache, kind, t2d):
-        """bf16 operand copy of t2d ("row": as stored, "t": transposed), made once per pass.  A copy made on one stream and
-        used on the other is ordered by ITS OWN event: the user waits for that cast, not for everything the maker's
-        stream has queued behind it."""
-        key = (kind, t2d.data_ptr(), tuple(t2d.shape))
+    def _copy(cache, t2d):
+        """Row-major bf16 copy of t2d (whole K steps of zero rows behind it: it may serve as a K-major factor), made once per
+        step.  A copy made on one stream and used on the other is ordered by ITS OWN event: the user waits for that cast, not
+        for everything the maker's stream has queued behind it."""
+        key = (t2d.data_ptr(), tuple(t2d.shape))
         cur = torch.cuda.current_stream()
         ent = cache.get(key)
         if ent is None:
-            if kind == "rowk":     # row-major copy that also serves as a K-major factor: whole K steps of zero rows behind it
-                c = ops.cast_bf16(t2d, rows=ops.pad_to(t2d.shape[0], 64) + 64)
-            else:
-                c = ops.cast_bf16(t2d) if kind == "row" else ops.cast_bf16_t(t2d)
+            c = ops.cast_bf16(t2d, rows=ops.pad_to(t2d.shape[0], 64) + 64)
             ev = torch.cuda.Event()
             ev.record(cur)
             # the entry holds the fp32 SOURCE too: its address cannot be recycled for another tensor of the same shape
-            # while the copy is cached (sources are not written between their uses within a pass)
+            # while the copy is cached (sources are not written between their uses within a step)
             cache[key] = ent = (c, ev, cur, t2d)
         elif ent[2] != cur:
             cur.wait_event(ent[1])
             ent[0].record_stream(cur)
         return ent[0]
 
-    def _proj(self, cache, inp2d, w, out2d, bias, act=0):
-        """out (R, N) = act(inp (R, K) w (N, K)^T + bias)."""
-        R, K = inp2d.shape
+    def _proj(self, cache, inp2d, w, out2d, bias, R, act=0):
+        """out[:R] (R, N) = act(inp[:R] (R, K) w (N, K)^T + bias)."""
+        K = inp2d.shape[1]
         N = w.shape[0]
         if not self.nt:
             ops.gemm(inp2d, w, out2d, R, N, K, inp2d.stride(0), K, N, transB=True, bias=bias, act=act, bf16=self.bf16,
                      variant=self.var_main)
             return
-        kind = "rowk" if self.kmajor else "row"            # the same copies serve the backward products K-major
-        a, b = self._copy(cache, kind, inp2d), self._copy(cache, kind, w)
+        a, b = self._copy(cache, inp2d), self._copy(cache, w)
         # (not the stream-K kernel: with 1400 tiles of 28 K steps its fix-up costs more than the sixth partial round it saves --
         # main-stream products 3.03 vs 3.11 ms per step; the data gradients' 350 tiles of 112 steps are where it pays)
-        ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act,
-                         streamk=os.environ.get("SEPKERN_BF16_PROJ_SK", "0") == "1")
+        ops.gemm_bf16_nt(a, b, out2d, R, N, a.shape[1], a.shape[1], b.shape[1], N, bias=bias, act=act)
 
-    def _dgrad(self, cache, dout2d, w, out2d, ws_tag):
-        """out (R, K) = dout (R, N) w (N, K)."""
-        R, N = dout2d.shape
+    def _dgrad(self, cache, dout2d, w, out2d, R, ws_tag):
+        """out[:R] (R, K) = dout[:R] (R, N) w (N, K)."""
+        N = dout2d.shape[1]
         K = w.shape[1]
         if not self.nt:
-            # large data gradients unsplit: the 256 x 128-tile kernel (sk_gemm_f32_splitk picks it for unsplit N/N products)
-            # measured 125.5 TFLOP/s against 119-120 for two K slices of 128 x 128 tiles
-            sk = 1 if (self.dgrad_unsplit and not self.bf16 and R >= 4096 and K >= 1024 and N % 16 == 0) else 0
+            # large data gradients unsplit (stream-K / 256 x 128 tiles: 125.5-134.6 TFLOP/s against 119-120 for two K slices)
+            sk = 1 if (not self.bf16 and R >= 4096 and K >= 1024 and N % 16 == 0) else 0
             ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=sk, ws_tag=ws_tag, bf16=self.bf16, variant=self.var_main)
             return
-        if self.kmajor:
-            # out = dout w: w (N, K) is the K-major B of the product as it lies (contraction over its rows, padded with
-            # zero rows up to dout's zero-padded width)
-            a, b = self._copy(cache, "rowk", dout2d), self._copy(cache, "rowk", w)
-            ops.gemm_bf16_mm(a, b, out2d, R, K, a.shape[1], a.shape[1], b.shape[1], K, b_kmajor=True, splitk=0, ws_tag=ws_tag,
-                             streamk=True)
-            return
-        a, bt = self._copy(cache, "row", dout2d), self._copy(cache, "t", w)      # w^T: (K, N padded)
-        ops.gemm_bf16_nt(a, bt, out2d, R, K, a.shape[1], a.shape[1], bt.shape[1], K, splitk=0, ws_tag=ws_tag)
+        # w (N, K) is the K-major B of the product as it lies (contraction over its rows, padded with zero rows up to
+        # dout's zero-padded width)
+        a, b = self._copy(cache, dout2d), self._copy(cache, w)
+        ops.gemm_bf16_mm(a, b, out2d, R, K, a.shape[1], a.shape[1], b.shape[1], K, b_kmajor=True, splitk=0, ws_tag=ws_tag,
+                         streamk=True)
 
-    def _wgrad(self, cache, dout2d, inp2d, gw, acc, ws_tag, beside=False):
-        """gw (N, K) [+]= dout (R, N)^T inp (R, K).  beside=True: the product runs co-resident with a recurrence (side
-        stream): the register-staged GEMM kernel, which leaves the recurrence more of the matrix pipe than the LDS-DMA
-        one does (measured: same step time with either, 2 ms longer recurrences with the latter)."""
-        R, N = dout2d.shape
-        K = inp2d.shape[1]
+    def _wgrad(self, cache, dout2d, inp2d, gw, acc, ws_tag, beside=False, batch=1, sA=0, sB=0, sC=0, N=None, K=None):
+        """gw (N, K) [+]= dout (Rp, N)^T inp (Rp, K), contraction over all Rp rows (zero tails).  batch = 2 with operand
+        strides: the two directions of the recurrent weight gradient in one launch.  beside=True: the product runs
+        co-resident with a recurrence (side stream): the register-staged GEMM kernel, which leaves the recurrence more of
+        the matrix pipe than the LDS-DMA one does (measured: same step time with either, 2 ms longer recurrences with the
+        latter)."""
+        Rp = dout2d.shape[0]
+        N = dout2d.shape[1] if N is None else N
+        K = inp2d.shape[1] if K is None else K
         if not self.nt:
-            ops.gemm(dout2d, inp2d, gw, N, K, R, N, inp2d.stride(0), K, transA=True, accumulate=acc, splitk=0,
-                     ws_tag=ws_tag, bf16=self.bf16, variant=self.var_side if beside else self.var_main)
+            ops.gemm(dout2d, inp2d, gw, N, K, Rp, dout2d.stride(0), inp2d.stride(0), K, transA=True, accumulate=acc, splitk=0,
+                     batch=batch, sA=sA, sB=sB, sC=sC, ws_tag=ws_tag, bf16=self.bf16, variant=self.var_side if beside else self.var_main)
             return
-        if self.kmajor:
-            # gw = dout^T inp: both factors K-major as they lie (their rows are the contraction index)
-            a, b = self._copy(cache, "rowk", dout2d), self._copy(cache, "rowk", inp2d)
-            ops.gemm_bf16_mm(a, b, gw, N, K, ops.pad_to(R, 64), a.shape[1], b.shape[1], K, a_kmajor=True, b_kmajor=True,
-                             accumulate=acc, splitk=0, ws_tag=ws_tag, streamk=not beside)
-            return
-        at, bt = self._copy(cache, "t", dout2d), self._copy(cache, "t", inp2d)    # (N, R padded), (K, R padded)
-        ops.gemm_bf16_nt(at, bt, gw, N, K, ops.pad_to(R, 64), at.shape[1], bt.shape[1], K, accumulate=acc, splitk=0,
-                         ws_tag=ws_tag)
+        # both factors K-major as they lie (their rows are the contraction index)
+        a = dout2d if dout2d.dtype == torch.bfloat16 else self._copy(cache, dout2d)
+        b = inp2d if inp2d.dtype == torch.bfloat16 else self._copy(cache, inp2d)
+        ops.gemm_bf16_mm(a, b, gw, N, K, ops.pad_to(Rp, 64), a.shape[1], b.shape[1], K, a_kmajor=True, b_kmajor=True,
+                         accumulate=acc, batch=batch, sA=sA, sB=sB, sC=sC, splitk=0, ws_tag=ws_tag, streamk=not beside and batch == 1)
 
-    def _whh_grad(self, cache, dgx2d, y2d, h0, dg_first, gw, T, B, acc, ws_tag, beside=False):
-        """dW_hh (2,4H,H) [+]= sum_t dG_t^T h_prev(t) (ops.lstm_whh_grad); in bf16 from the transposed copies: the time
-        shift is an offset of B columns into one of them, and the copies end in >= 64 zero columns."""
+    def _hprev(self, y, h0l, pk):
+        """The recurrent inputs of a layer's packed rows (sk_hprev_rows), as the operand its recurrent weight gradient reads."""
         H = self.H
-        if not (self.nt and T > 1 and B % 8 == 0):
-            ops.lstm_whh_grad(dgx2d, y2d, h0, dg_first, gw, T, B, H, accumulate=acc, bf16=self.bf16, ws_tag=ws_tag,
-                              variant=self.var_side if beside else self.var_main)
-            return
-        if self.kmajor:
-            # the time shift is an offset of B ROWS into one of the K-major factors: direction 0 pairs dG rows from t = 1
-            # with y rows from t = 0, direction 1 dG rows from t = 0 with y rows from t = 1; the copies end in >= 64 zero
-            # rows, which absorb the rounding of K = (T-1) B up to 64
-            a, b = self._copy(cache, "rowk", dgx2d), self._copy(cache, "rowk", y2d)   # (R+, 8H), (R+, 2H)
-            lda, ldb = a.shape[1], b.shape[1]
-            ops.gemm_bf16_mm(a.view(-1)[B * lda:], b, gw, 4 * H, H, ops.pad_to((T - 1) * B, 64), lda, ldb, H, a_kmajor=True,
-                             b_kmajor=True, accumulate=acc, batch=2, sA=4 * H - B * lda, sB=B * ldb + H, sC=4 * H * H, splitk=0,
-                             ws_tag=ws_tag)
-            ops.gemm(dg_first, h0, gw, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=True, batch=2, sA=B * 4 * H, sB=B * H,
-                     sC=4 * H * H, ws_tag=ws_tag, bf16=True)
-            return
-        at, bt = self._copy(cache, "t", dgx2d), self._copy(cache, "t", y2d)       # (8H, ld), (2H, ld)
-        ld = at.shape[1]
-        ops.gemm_bf16_nt(at.view(-1)[B:], bt, gw, 4 * H, H, ops.pad_to((T - 1) * B, 64), ld, ld, H, accumulate=acc, batch=2,
-                         sA=4 * H * ld - B, sB=H * ld + B, sC=4 * H * H, splitk=0, ws_tag=ws_tag)
-        ops.gemm(dg_first, h0, gw, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=True, batch=2, sA=B * 4 * H, sB=B * H,
-                 sC=4 * H * H, ws_tag=ws_tag, bf16=True)
-
-    def _wgrad_half(self, c, dgx, y, inp, gw_hh, gw_ih, T, B, Ip, ws_tag, beside):
-        """Half c (1 or 2) of a layer's weight-gradient products in the split backward schedule (fp32).  With S = T/2:
-        half 1 = the rows that are final after S steps of the backward recurrence (forward direction t >= S, reverse
-        direction t < S), half 2 = the rest, accumulated onto half 1.  Per direction, as one batched launch each:
-          dW_hh[d] (+)= sum_t dG_t[d]^T h_prev(t)[d]   (ops.lstm_whh_grad's time-shifted pairs, cut at S)
-          dW_ih[d] (+)= sum_t dG_t[d]^T x_t            (rows of gw_ih: direction 0's 4H, then direction 1's)"""
-        H, S = self.H, T // 2
-        dg, yv, xv = dgx.view(-1), y.view(-1), inp.reshape(-1)
-        var = self.var_side if beside else self.var_main
-        kw = dict(transA=True, accumulate=(c == 2), batch=2, splitk=0, ws_tag=ws_tag, variant=var)
-        if c == 1:     # forward direction: pairs (dG_t, y_{t-1}), t = S..T-1; reverse: (dG_t, y_{t+1}), t = 0..S-1
-            ops.gemm(dg[S * B * 8 * H:], yv[(S - 1) * B * 2 * H:], gw_hh, 4 * H, H, S * B, 8 * H, 2 * H, H,
-                     sA=4 * H - S * B * 8 * H, sB=H - (S - 2) * B * 2 * H, sC=4 * H * H, **kw)
-            ops.gemm(dg[S * B * 8 * H:], xv[S * B * Ip:], gw_ih, 4 * H, Ip, S * B, 8 * H, Ip, Ip,
-                     sA=4 * H - S * B * 8 * H, sB=-S * B * Ip, sC=4 * H * Ip, **kw)
-        else:          # forward direction: t = 1..S-1 (t = 0 pairs with h0: the caller's rank-B term); reverse: t = S..T-2
-            ops.gemm(dg[B * 8 * H:], yv, gw_hh, 4 * H, H, (S - 1) * B, 8 * H, 2 * H, H,
-                     sA=S * B * 8 * H + 4 * H - B * 8 * H, sB=(S + 1) * B * 2 * H + H, sC=4 * H * H, **kw)
-            ops.gemm(dg, xv, gw_ih, 4 * H, Ip, S * B, 8 * H, Ip, Ip, sA=S * B * 8 * H + 4 * H, sB=S * B * Ip, sC=4 * H * Ip, **kw)
+        if self.nt:
+            ld = ops.pad_to(2 * H, 64)
+            rows = ops.pad_to(pk.Rp, 64) + 64
+            hp = (torch.empty if ld == 2 * H else torch.zeros)(rows, ld, dtype=torch.bfloat16, device=y.device)
+            if ld == 2 * H:
+                hp[pk.R:].zero_()
+        else:
+            hp = pk.rows(2 * H)
+        return ops.hprev_rows(y, h0l, pk, H, hp)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, lens, h0, c0, training, save, want_state=False):
-        """x (T,B,in_dim) fp32, lens int32 (B) on device, h0/c0 (2L,B,H) ->
-        (mask (T,B,out_dim), hn, cn (2L,B,H) or None, ctx or None).  ctx feeds backward(); several may be alive
+    def forward(self, x2d, pk, h0, c0, training, save, want_state=False):
+        """x2d (>= R, in_dim) packed rows of the batch `pk` (sepkern.packing.Packing), h0/c0 (2L,B,H) in sorted order ->
+        (mask (R, out_dim) packed, hn, cn (2L,B,H) or None, ctx or None).  ctx feeds backward(); several may be alive
         (the RSH arch runs the network num_spk times per batch)."""
-        T, B, I0 = x.shape
-        if I0 != self.I:
-            raise SepkernError("input feature dim %d != model input dim %d" % (I0, self.I))
-        H, L, O = self.H, self.L, self.O
-        R = T * B
-        x = x.contiguous()
-        dev = x.device
+        if x2d.dim() != 2 or x2d.shape[1] != self.I or x2d.shape[0] < pk.R:
+            raise SepkernError("forward: input is %s, expected (>= %d, %d) packed rows" % (tuple(x2d.shape), pk.R, self.I))
+        T, B, R, Rp = pk.T, pk.B, pk.R, pk.Rp
+        H, L, O, I0 = self.H, self.L, self.O, self.I
+        lens, offs = pk.lens, pk.offs
+        dev = x2d.device
         saved = []
         cache = {}
-        inp, I = x, I0
         ws = None
         hn = torch.empty(2 * L, B, H, device=dev) if want_state else None
         cn = torch.empty(2 * L, B, H, device=dev) if want_state else None
+
         def weights_of(l, I, ws_tag="bn"):
             """(W_ih rows gate-interleaved and padded to Ip columns, summed bias gate-interleaved, Ip) of layer l."""
             wih = self.p("weight_ih_l%d" % l)
@@ -339,129 +303,119 @@ class Engine:
             wih_gi = ops.gate_rows(wih.view(8 * H, I), H, out=torch.empty(8 * H, Ip, device=dev), cols=I)
             return wih_gi, ops.gate_rows(bsum, H), Ip
 
-        # Split recurrences (fp32): a layer that feeds another one runs as TWO launches of T/2 steps.  After the first,
-        # the forward half of y is final for t < T/2 and the reverse half for t >= T/2, so half of the next layer's input
-        # projection -- those rows times the matching half of W_ih -- is issued on the side stream and runs CO-RESIDENT
-        # with the second launch (a recurrence leaves its CU's matrix pipe idle half of the time); the other
-        # half of the product follows on the main stream.  Same sums in a different order: fp32 rounding-level changes.
-        split = (self.fwd_split and self.overlap and not self.bf16 and self.lstm_mode == 0 and T % 2 == 0 and T >= 16 and L > 1)
         main = torch.cuda.current_stream(dev)
-        if split and self.side is None:
-            self.side = torch.cuda.Stream(device=dev)
-        keep = []
+        use_side = self.overlap and self.lstm_mode == 0 and L > 1
+        side = self._side_stream(dev) if (use_side and save) else self.side
         # The gate-interleaved copies of W_ih and the summed biases of the layers above the first depend on the weights only:
-        # they are made on the side stream (when the backward pass has created one) beside layer 0's projection and
-        # recurrence instead of in front of each layer's projection on the main stream (r03: 0.13 ms of small kernels per step)
+        # they are made on the side stream beside layer 0's projection and recurrence instead of in front of each layer's
+        # projection on the main stream (r03: 0.13 ms of small kernels per step)
         ahead, ahead_ev = {}, None
-        if self.side is not None and self.overlap and L > 1 and not split and os.environ.get("SEPKERN_PREP_AHEAD", "1") == "1":
-            self.side.wait_stream(main)
-            with torch.cuda.stream(self.side):
+        if side is not None and use_side:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
                 for l in range(1, L):
                     ahead[l] = weights_of(l, 2 * H, ws_tag="bn_side")
                     for t_ in ahead[l][:2]:
                         t_.record_stream(main)
                 ahead_ev = torch.cuda.Event()
-                ahead_ev.record(self.side)
-        gx_ready = None                                  # (gx, wih_gi) of the NEXT layer when its projection was split in
+                ahead_ev.record(side)
+        inp, I = x2d, I0
         for l in range(L):
             whh = self.p("weight_hh_l%d" % l)
-            if gx_ready is None:
-                if l in ahead:
-                    if ahead_ev is not None:
-                        main.wait_event(ahead_ev)
-                        ahead_ev = None
-                    wih_gi, bsum, Ip = ahead[l]
+            if l in ahead:
+                if ahead_ev is not None:
+                    main.wait_event(ahead_ev)
+                    ahead_ev = None
+                wih_gi, bsum, Ip = ahead[l]
+            else:
+                wih_gi, bsum, Ip = weights_of(l, I)
+            if Ip != I or inp.shape[0] < Rp or not inp.is_contiguous():
+                inp = ops.pad_rows(inp[:R], Ip, rows=Rp)   # one pass, no memset (F = 257 -> 260; tail rows zero)
+            gx = pk.rows(8 * H)                              # (Rp, 2, 4H): projections -> saved gates -> dgx, in place
+            self._proj(cache, inp, wih_gi, gx, bsum, R)
+            y = pk.rows(2 * H)
+            cs = torch.empty(Rp, 2 * H, device=dev) if save else None
+            h0l = h0[2 * l:2 * l + 2]
+            ws = ops.lstm_fwd(gx, whh, h0l, c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
+                              hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
+                              T, B, H, self.lstm_mode | self.fwd_bits, bf16=self.bf16, offs=offs, rows=R)
+            hp = hp_ev = None
+            if save:
+                # the recurrent inputs of the layer's rows, for its recurrent weight gradient: gathered HERE, on the side
+                # stream beside the next layer's projection, not in the backward pass where the side stream is the bound
+                if use_side:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        hp = self._hprev(y, h0l, pk)
+                        hp_ev = torch.cuda.Event()
+                        hp_ev.record(side)
+                    hp.record_stream(main)
+                    y.record_stream(side)
                 else:
-                    wih_gi, bsum, Ip = weights_of(l, I)
-                inp2d = inp.view(R, I)
-                if Ip != I:
-                    inp2d = ops.pad_rows(inp2d, Ip)          # one pass, no memset (F = 257 -> 260)
-                gx = torch.empty(T, B, 2, 4 * H, device=dev)
-                self._proj(cache, inp2d, wih_gi, gx.view(R, 8 * H), bsum)
-            else:
-                gx, wih_gi = gx_ready
-                inp2d = inp.view(R, I)
-                gx_ready = None
-            y = torch.empty(T, B, 2 * H, device=dev)
-            cs = torch.empty(T, B, 2, H, device=dev) if save else None
-            args = (gx, whh, h0[2 * l:2 * l + 2], c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
-                    hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
-                    T, B, H, self.lstm_mode | self.fwd_bits)
-            if split and l + 1 < L:
-                S1, half = T // 2, (T // 2) * B              # steps per launch, rows of y per half
-                nw, nb, _ = weights_of(l + 1, 2 * H)         # (8H, 2H) interleaved rows, bias
-                ngx = torch.empty(T, B, 2, 4 * H, device=dev)
-                ws = ops.lstm_fwd(*args, bf16=False, steps=(0, S1))
-                self.side.wait_stream(main)
-                with torch.cuda.stream(self.side):
-                    # rows t < T/2: forward half of y (columns :H) x W[:, :H]^T;  rows t >= T/2: reverse half x W[:, H:]^T
-                    ops.gemm(y.view(R, 2 * H), nw, ngx.view(R, 8 * H), half, 8 * H, H, 2 * H, 2 * H, 8 * H, transB=True, bias=nb,
-                             batch=2, sA=half * 2 * H + H, sB=H, sC=half * 8 * H, sbias=0)
-                ws = ops.lstm_fwd(*args, bf16=False, steps=(S1, T))
-                main.wait_stream(self.side)
-                # the other halves, accumulated: rows t < T/2 x W[:, H:]^T of the reverse half, rows t >= T/2 x W[:, :H]^T
-                ops.gemm(y.view(-1)[H:], nw.view(-1)[H:], ngx.view(R, 8 * H), half, 8 * H, H, 2 * H, 2 * H, 8 * H, transB=True,
-                         accumulate=True, batch=2, sA=half * 2 * H - H, sB=-H, sC=half * 8 * H)
-                gx_ready = (ngx, nw)
-                keep += [nw, nb, ngx, y]
-            else:
-                ws = ops.lstm_fwd(*args, bf16=self.bf16)
-            saved.append((inp2d, gx, cs, y, wih_gi))
+                    hp = self._hprev(y, h0l, pk)
+            saved.append((inp, gx, cs, y, wih_gi, hp, hp_ev))
             inp, I = y, 2 * H
-        del keep
         if not save and not skdist.is_parallel():
             # inference: the caller copies the masks to the host next, a sync costs nothing.  Under data parallelism a
             # raise on ONE rank would leave the others waiting in their next collective: there the sticky word stays set
             # and the driver reports it on every rank together (steps/train_qsub.py::validation_pass)
             ops.lstm_status(ws)
-        y2d = inp.view(R, 2 * H)
+        y_top = inp
+        count = B * T                 # BatchNorm1d sees the zero-padded (B, 2H, T_max) grid (archs/uPIT.py:135-138)
         if training:
             mean = torch.empty(2 * H, device=dev)
             var = torch.empty(2 * H, device=dev)
-            ops.bn_stats(y2d, mean, var)
-            bn_count = float(R)
+            ops.bn_stats(y_top, mean, var, rows=R, count=count)
+            bn_count = float(count)
             if self.sync_bn:                             # statistics of the global batch (one all-gather)
-                mean, var, bn_count = skdist.combine_bn_stats(mean, var, R)
-            ops.bn_update_running(mean, var, self.running_mean, self.running_var, int(bn_count), self.momentum)
+                mean, var, bn_count = skdist.combine_bn_stats(mean, var, B, T)
+            # (guarded: after a timed-out launch y is garbage and must not reach running statistics a checkpoint will hold)
+            ops.bn_update_running(mean, var, self.running_mean, self.running_var, int(bn_count), self.momentum,
+                                  guard=ops.lstm_sticky(ws))
         else:
-            mean, var, bn_count = self.running_mean, self.running_var, float(R)
-        mask = torch.empty(T, B, O, device=dev)
+            mean, var, bn_count = self.running_mean, self.running_var, float(count)
+        self._last_bn = (mean, var)
+        mask = torch.empty(Rp, O, device=dev)
         xbn = fold = None
         if self.bn_fold:
             # BatchNorm folded into the Linear weights (sk_bn_fold): mask = sigmoid(y Wf^T + bf), the
             # normalised activations are never written (one 92 MB pass less, forward and backward)
             Wf, bf_, s_, t_ = ops.bn_fold(self.p("lin.weight"), self.p("lin.bias"), mean, var, self.p("bn.weight"),
                                           self.p("bn.bias"), self.eps)
-            self._proj(cache, y2d, Wf, mask.view(R, O), bf_, act=1)
+            self._proj(cache, y_top, Wf, mask, bf_, R, act=1)
             fold = (s_, t_)
         else:
-            xbn = torch.empty(R, 2 * H, device=dev)
-            ops.bn_apply(y2d, mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
-            self._proj(cache, xbn, self.p("lin.weight"), mask.view(R, O), self.p("lin.bias"), act=1)
+            xbn = pk.rows(2 * H)
+            ops.bn_apply(y_top[:R], mean, var, self.p("bn.weight"), self.p("bn.bias"), xbn, self.eps)
+            self._proj(cache, xbn, self.p("lin.weight"), mask, self.p("lin.bias"), R, act=1)
         ctx = None
         if save:
-            ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, fold=fold, mask=mask, lens=lens, h0=h0,
-                       c0=c0, T=T, B=B, training=training,
-                       # bf16, K-major products: the backward pass multiplies the SAME row-major copies of the weights and
-                       # of every layer input (none of them is written in between), so they are made once per step
-                       cache=cache if self.kmajor else None)
-        return mask, hn, cn, ctx
+            ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, fold=fold, mask=mask, pk=pk, h0=h0,
+                       c0=c0, training=training, version=self.param_version(),
+                       # bf16: the backward pass multiplies the SAME row-major copies of the weights and of every layer
+                       # input (none of them is written in between), so they are made once per step
+                       cache=cache if self.nt else None)
+        return mask[:R], hn, cn, ctx
 
     # ------------------------------------------------------------------ backward
     def backward(self, ctx, dmask, dhn=None, dcn=None, want_dx=False, want_dstate=False, reducer=None):
-        """Parameter gradients (into the flat gradient buffer) from dmask (T,B,out_dim) and, optionally, the
-        gradient wrt the final state (dhn, dcn (2L,B,H)).  Returns (dx (T,B,in_dim) or None, dh0, dc0 or None).
+        """Parameter gradients (into the flat gradient buffer) from dmask (R, out_dim) packed and, optionally, the
+        gradient wrt the final state (dhn, dcn (2L,B,H)).  Returns (dx (R, in_dim) packed or None, dh0, dc0 or None).
         reducer (sepkern.dist.GradReducer, data-parallel runs with SEPKERN_DP_OVERLAP=1, last backward of a step only):
         every chunk of ParamLayout.grad_chunks() is handed over as soon as the kernels that complete it are enqueued."""
         if ctx is None:
             raise SepkernError("backward called without a saved forward")
         if not ctx["training"]:
             raise SepkernError("backward through eval-mode BatchNorm is not built")
-        T, B, H, L, O, I0 = ctx["T"], ctx["B"], self.H, self.L, self.O, self.I
-        R = T * B
+        pk = ctx["pk"]
+        T, B, R, Rp = pk.T, pk.B, pk.R, pk.Rp
+        H, L, O, I0 = self.H, self.L, self.O, self.I
+        lens, offs = pk.lens, pk.offs
         dev = dmask.device
         acc = not self.grads_fresh
-        lens, h0, c0 = ctx["lens"], ctx["h0"], ctx["c0"]
+        h0, c0 = ctx["h0"], ctx["c0"]
         dmask = dmask.contiguous()
 
         def put(name, val):           # small vectors produced by non-accumulating kernels
@@ -471,32 +425,34 @@ class Engine:
                 self.g(name).copy_(val)
 
         overlap = self.overlap and L > 1 and self.lstm_mode == 0
-        if overlap and self.side is None:
-            self.side = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
+        side = self._side_stream(dev) if overlap else None
         keep = []                                        # tensors used on the side stream stay alive until the join
-        dz = torch.empty_like(dmask)
-        ops.sigmoid_bwd(dmask, ctx["mask"], dz)
-        cache = ctx.get("cache") or {}                   # bf16 operand copies (see _copy); with K-major products the forward's
-        dz2d = dz.view(R, O)
-        dxbn = torch.empty(R, 2 * H, device=dev)
-        self._dgrad(cache, dz2d, self.p("lin.weight"), dxbn, "gemm")
-        y_top = ctx["saved"][-1][3].view(R, 2 * H)
-        dy = torch.empty(R, 2 * H, device=dev)
+        dz = pk.rows(O)
+        ops.sigmoid_bwd(dmask[:R], ctx["mask"][:R], dz)
+        # bf16 operand copies (see _copy): the forward's, unless the parameters were written since (a backward of a ctx saved
+        # before an optimizer step would otherwise multiply stale bf16 weight copies against the new fp32 weights)
+        cache = ctx.get("cache") if ctx.get("version") == self.param_version() else None
+        cache = {} if cache is None else cache
+        dxbn = torch.empty(Rp, 2 * H, device=dev)
+        # (folded or not, the data gradient contracts with the UNFOLDED weight: dxbn is the gradient wrt bn(y))
+        self._dgrad(cache, dz, self.p("lin.weight"), dxbn, R, "gemm")
+        y_top = ctx["saved"][-1][3]
+        dy = torch.empty(Rp, 2 * H, device=dev)
         dgamma = torch.empty(2 * H, device=dev)
         dbeta = torch.empty(2 * H, device=dev)
-        ops.bn_bwd_sums(dxbn, y_top, ctx["mean"], ctx["var"], dgamma, dbeta, self.eps)
+        ops.bn_bwd_sums(dxbn[:R], y_top[:R], ctx["mean"], ctx["var"], dgamma, dbeta, self.eps)
         put("bn.weight", dgamma)                         # local sums: the flat all-reduce adds the ranks up later
         put("bn.bias", dbeta)
         if self.sync_bn:                                 # dx needs the sums over the global batch (one all-reduce)
             dgamma, dbeta = skdist.allreduce_bn_sums(dgamma, dbeta)
-        ops.bn_bwd_apply(dxbn, y_top, ctx["mean"], ctx["var"], self.p("bn.weight"), dgamma, dbeta, dy, ctx["bn_count"],
+        ops.bn_bwd_apply(dxbn[:R], y_top[:R], ctx["mean"], ctx["var"], self.p("bn.weight"), dgamma, dbeta, dy, ctx["bn_count"],
                          self.eps)
         del dxbn
         # the Linear layer's own gradients are needed by nobody before clip+Adam: side stream, next to the top
         # layer's recurrence (enqueued HERE, after the BatchNorm backward on the main stream: issued earlier they ran
         # beside those short critical-path kernels and slowed them by 0.1 ms)
-        stream = self.side if overlap else main
+        stream = side if overlap else main
         if stream is not main:
             stream.wait_stream(main)
         with torch.cuda.stream(stream):
@@ -505,7 +461,7 @@ class Engine:
                 # dW = dz^T bn(y) = (dz^T y) diag(s) + colsum(dz) t^T  (sk_bn_unfold_grad): the product runs against y itself
                 G = torch.empty(O, 2 * H, device=dev)
                 dzsum = torch.empty(O, device=dev)
-                self._wgrad(cache, dz2d, y_top, G, False, "gemm" + tag, beside=overlap)
+                self._wgrad(cache, dz, y_top, G, False, "gemm" + tag, beside=overlap)
                 ops.colsum(dz, R, O, O, dzsum, ws_tag="bn" + tag)
                 ops.bn_unfold_grad(G, dzsum, ctx["fold"][0], ctx["fold"][1], self.g("lin.weight"), accumulate=acc)
                 if acc:
@@ -514,7 +470,7 @@ class Engine:
                     self.g("lin.bias").copy_(dzsum)
                 keep += [G, dzsum]
             else:
-                self._wgrad(cache, dz2d, ctx["xbn"], self.g("lin.weight"), acc, "gemm" + tag, beside=overlap)
+                self._wgrad(cache, dz, ctx["xbn"], self.g("lin.weight"), acc, "gemm" + tag, beside=overlap)
                 ops.colsum(dz, R, O, O, self.g("lin.bias"), accumulate=acc, ws_tag="bn" + tag)
             keep.append(dz)
         del dz
@@ -526,98 +482,66 @@ class Engine:
         dc0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
         dx = None
         for l in range(L - 1, -1, -1):
-            inp, gates, cs, y, wih_gi = ctx["saved"][l]          # inp: (R, I padded to a multiple of 4)
+            inp, gates, cs, y, wih_gi, hp, hp_ev = ctx["saved"][l]      # inp: (Rp, I padded to a multiple of 4)
             I = I0 if l == 0 else 2 * H
             Ip = inp.shape[1]
             whh = self.p("weight_hh_l%d" % l)
             dgx = gates                                  # overwritten in place, cell by cell
-            # with weight-gradient GEMMs in flight on the side stream: SEPKERN_OVERLAP=1 carries 2 batch groups per
-            # workgroup (the recurrence on half the CUs, GEMMs on the rest); =2 leaves the recurrence as it is and
-            # lets GEMM blocks co-reside on its CUs (it leaves 124 VGPRs per SIMD lane and 69 KB of LDS free)
-            mode = self.lstm_mode | self.bwd_bits | ((2 << 8) if (overlap and self.overlap_mode == 1 and l < L - 1) else 0)
+            mode = self.lstm_mode | self.bwd_bits
             sl = slice(2 * l, 2 * l + 2)
             nbg = (B + 15) // 16
-            dbias = torch.empty(nbg, 8 * H, device=dev)      # by-products of the recurrence: bias-gradient partials ...
-            dg_first = torch.empty(2, B, 4 * H, device=dev)  # ... and the dG of the steps whose recurrent input is h0
-            bargs = (dy, whh, gates, cs, c0[sl], lens, dgx, dh0[sl] if want_dstate else None,
-                     dc0[sl] if want_dstate else None, T, B, H, mode)
-            bkw = dict(dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None, bf16=self.bf16,
-                       dbias=dbias, dg_first=dg_first)
+            dbias = torch.empty(nbg, 8 * H, device=dev)      # by-product of the recurrence: bias-gradient partials
             gw_hh = torch.empty(2, 4 * H, H, device=dev)     # rows gate-interleaved, like dgx (sk_gate_rows puts them back)
             gw_ih = torch.empty(8 * H, Ip, device=dev)
-            split = self.bwd_split and overlap and not self.bf16 and T % 2 == 0 and T >= 16
-            if split:
-                # Split schedule: the recurrence in two launches of T/2 steps.  After the first, the forward direction's dgx
-                # is final for t >= T/2 and the reverse direction's for t < T/2, so HALF of this layer's own weight-gradient
-                # products (those rows, per direction: _wgrad_half) starts on the side stream beside the second launch --
-                # the top layer's recurrence then hosts work too, and only half of layer 0's products is left for the end.
-                ws = ops.lstm_bwd(*bargs, steps=(0, T // 2), **bkw)
-                self.side.wait_stream(main)
-                with torch.cuda.stream(self.side):
-                    self._wgrad_half(1, dgx, y, inp, gw_hh, gw_ih, T, B, Ip, "gemm_side", True)
-                ws = ops.lstm_bwd(*bargs, steps=(T // 2, T), **bkw)
-            else:
-                # bf16 (r03): the recurrence writes dgx a second time as bf16 -- the operand copy its three products read
-                # (data gradient, dW_ih, dW_hh) -- instead of a cast pass over 4 x the bytes between recurrence and products
-                twin = None
-                if self.kmajor and self.bf16_twin:
-                    rows, ld = ops.pad_to(R, 64) + 64, ops.pad_to(8 * H, 64)
-                    twin = (torch.empty if ld == 8 * H else torch.zeros)(rows, ld, dtype=torch.bfloat16, device=dev)
-                    if ld == 8 * H:
-                        twin[R:].zero_()                 # whole K steps of zero rows behind the data (K-major factor)
-                ws = ops.lstm_bwd(*bargs, dgx_bf16=twin, **bkw)
-                if twin is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    d2 = dgx.view(R, 8 * H)
-                    cache[("rowk", d2.data_ptr(), tuple(d2.shape))] = (twin, ev, main, d2)
-            # The layer's weight-gradient products need the recurrence's dgx only: with SEPKERN_WGRAD_EARLY=1 the side stream is
-            # released BEFORE the data gradient is issued on the main stream, so its blocks fill what that launch leaves free
-            # (its tail, the launch gaps) instead of starting behind it.  r03, fp32: 35.85-35.97 vs 36.00-36.07 ms per step,
-            # but the side launches then spend 4.5 ms per step queued behind the persistent data-gradient kernel, which
-            # bench.py's per-launch events count as theirs (roofline.frac 0.505 instead of 0.57): opt-in.  bf16: slower
-            # (14.0 vs 13.55 ms; short products that share operand copies across the two streams).
-            early = overlap and l > 0 and not split and not self.bf16 and os.environ.get("SEPKERN_WGRAD_EARLY", "0") == "1"
-            if early:
-                self.side.wait_stream(main)
+            # bf16: the recurrence writes dgx a second time as bf16 -- the operand copy its three products read (data
+            # gradient, dW_ih, dW_hh) -- instead of a cast pass over 4 x the bytes between recurrence and products
+            twin = None
+            if self.nt:
+                rows, ld = ops.pad_to(Rp, 64) + 64, ops.pad_to(8 * H, 64)
+                twin = (torch.empty if ld == 8 * H else torch.zeros)(rows, ld, dtype=torch.bfloat16, device=dev)
+                if ld == 8 * H:
+                    twin[R:].zero_()                     # whole K steps of zero rows behind the data (K-major factor)
+            ws = ops.lstm_bwd(dy, whh, gates, cs, c0[sl], lens, dgx, dh0[sl] if want_dstate else None,
+                              dc0[sl] if want_dstate else None, T, B, H, mode,
+                              dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None, bf16=self.bf16,
+                              dbias=dbias, dgx_bf16=twin, offs=offs, rows=R)
+            if twin is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                cache[(dgx.data_ptr(), tuple(dgx.shape))] = (twin, ev, main, dgx)
             if l > 0 or want_dx:                         # the only product the next recurrence (or the caller) waits for
-                dy_next = torch.empty(R, Ip, device=dev)
-                self._dgrad(cache, dgx.view(R, 8 * H), wih_gi, dy_next, "gemm_dgrad")
+                dy_next = torch.empty(Rp, Ip, device=dev)
+                self._dgrad(cache, dgx, wih_gi, dy_next, R, "gemm_dgrad")
                 if l == 0:
-                    dx = (dy_next if Ip == I else dy_next[:, :I].contiguous()).view(T, B, I)
-            stream = self.side if (overlap and l > 0) else main
+                    dx = dy_next[:R] if Ip == I else dy_next[:R, :I].contiguous()
+            stream = side if (overlap and l > 0) else main
             if stream is not main:
-                if not early:
-                    stream.wait_stream(main)
-            elif overlap and split:
-                main.wait_stream(self.side)      # layer 0 adds its second half onto the half sums the side stream made
-            # (unsplit: layer 0's products share nothing with the side stream's but bf16 operand copies, which carry their
-            # own events -- _copy -- so they start as soon as layer 0's recurrence ends)
+                stream.wait_stream(main)
+            elif hp_ev is not None:
+                main.wait_event(hp_ev)                   # (layer 0's products run on the main stream; long since recorded)
+            # (layer 0's products share nothing with the side stream's but bf16 operand copies, which carry their own
+            # events -- _copy -- so they start as soon as layer 0's recurrence ends)
             with torch.cuda.stream(stream):
                 tag = "side" if stream is not main else "main"
                 beside = stream is not main
-                if split:
-                    self._wgrad_half(2, dgx, y, inp, gw_hh, gw_ih, T, B, Ip, "gemm_" + tag, beside)
-                    ops.gemm(dg_first, h0[sl], gw_hh, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=True, batch=2,
-                             sA=B * 4 * H, sB=B * H, sC=4 * H * H, ws_tag="gemm_" + tag)      # the steps that start from h0
-                else:
-                    # dW_hh[d] = sum_t dG_t^T h_prev(t): the layer output shifted by one step in time (+ the h0 steps)
-                    self._whh_grad(cache, dgx.view(R, 8 * H), y.view(R, 2 * H), h0[sl], dg_first, gw_hh, T, B, False, "gemm_" + tag, beside)
-                    # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
-                    self._wgrad(cache, dgx.view(R, 8 * H), inp, gw_ih, False, "gemm_" + tag, beside)
+                # dW_hh[d] = sum_rows dG[:, d]^T hprev[:, d-half]: both directions as one batched launch
+                self._wgrad(cache, dgx, hp, gw_hh, False, "gemm_" + tag, beside, batch=2, sA=4 * H, sB=H, sC=4 * H * H,
+                            N=4 * H, K=H)
+                # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
+                self._wgrad(cache, dgx, inp, gw_ih, False, "gemm_" + tag, beside)
                 ops.gate_rows(gw_hh, H, back=True, out=self.g("weight_hh_l%d" % l), accumulate=acc)
                 ops.gate_rows(gw_ih, H, back=True, out=self.g("weight_ih_l%d" % l).view(8 * H, I), accumulate=acc, cols=I)
                 db = torch.empty(8 * H, device=dev)
                 ops.colsum(dbias, nbg, 8 * H, 8 * H, db, ws_tag="bn_" + tag)       # a few rows: the kernel did the sums
                 put("bias_ih_l%d" % l, db.view(2, 4 * H))
                 put("bias_hh_l%d" % l, db.view(2, 4 * H))
-                keep += [db, dbias, dg_first, dgx, inp, y, gw_hh, gw_ih]
+                keep += [db, dbias, dgx, inp, y, hp, gw_hh, gw_ih]
             if reducer is not None and l > 0:
                 reducer.chunk(self.grad_full, *chunks["layer%d" % l], stream)
             if l > 0:
                 dy = dy_next
         if overlap:
-            main.wait_stream(self.side)
+            main.wait_stream(side)
         del keep, cache
         self.guard.copy_(ops.lstm_sticky(ws))      # int32 -> float: non-zero = this step's gradients are garbage
         if reducer is not None:

@@ -7,6 +7,7 @@ from torch.nn.utils.rnn import PackedSequence, pad_packed_sequence
 
 from . import dist as skdist
 from .engine import Engine
+from .packing import Packing
 from ._lib import SepkernError
 
 
@@ -17,27 +18,46 @@ class _Params(nn.Module):
 class NetFn(torch.autograd.Function):
   """(mask, hn, cn) = net(x, h0, c0).  backward runs the libsepkern backward kernels: parameter gradients
   go to the flat gradient buffer every param.grad is a view of; gradients wrt x, h0, c0 are returned
-  (the RSH arch chains passes through the attention input and the carried hidden state)."""
+  (the RSH arch chains passes through the attention input and the carried hidden state).
+  x is either the packed rows (R, in_dim) of the batch `pk` (the native layout: PackedSequence.data) or, with
+  padded=True, a zero-padded (T, B, in_dim) tensor in the caller's utterance order, which is packed on the way in and
+  unpacked on the way out (h0 / c0 / hn / cn then follow the caller's order too)."""
 
   @staticmethod
-  def forward(ctx, anchor, model, x, lens, h0, c0, want_state):
-    ctx.model = model
-    mask, hn, cn, ctx.fwd = model._engine.forward(x, lens, h0, c0, model.training, save=True, want_state=want_state)
+  def forward(ctx, anchor, model, x, pk, h0, c0, want_state, padded):
+    ctx.model, ctx.pk, ctx.padded = model, pk, padded
+    if padded:
+      ctx.T_pad = T_pad = x.shape[0]
+      x, h0, c0 = pk.pack(x), pk.sort_batch(h0, 1).contiguous(), pk.sort_batch(c0, 1).contiguous()
+    mask, hn, cn, ctx.fwd = model._engine.forward(x, pk, h0, c0, model.training, save=True, want_state=want_state)
+    if padded:
+      mask = pk.unpack(mask, fill=None if (pk.uniform and T_pad == pk.T) else model._engine.pad_row(), T=T_pad)
+      if want_state:
+        hn, cn = pk.unsort_batch(hn, 1), pk.unsort_batch(cn, 1)
     if not want_state:
       return mask
     return mask, hn, cn
 
   @staticmethod
   def backward(ctx, dmask, dhn=None, dcn=None):
-    model = ctx.model
+    model, pk = ctx.model, ctx.pk
     want_dx = ctx.needs_input_grad[2]
     want_ds = ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
     last = model._pending <= 1        # the last backward of the step: the gradients become final chunk by chunk
     reducer = model._reducer() if (last and skdist.is_parallel() and skdist.overlap_enabled()) else None
-    dx, dh0, dc0 = model._engine.backward(ctx.fwd, dmask.contiguous(),
+    dmask = dmask.contiguous()
+    if ctx.padded:
+      dmask = pk.pack(dmask)
+      dhn = pk.sort_batch(dhn, 1) if dhn is not None else None
+      dcn = pk.sort_batch(dcn, 1) if dcn is not None else None
+    dx, dh0, dc0 = model._engine.backward(ctx.fwd, dmask,
                                           dhn.contiguous() if dhn is not None else None,
                                           dcn.contiguous() if dcn is not None else None,
                                           want_dx=want_dx, want_dstate=want_ds, reducer=reducer)
+    if ctx.padded:
+      dx = pk.unpack(dx, T=ctx.T_pad) if dx is not None else None
+      dh0 = pk.unsort_batch(dh0, 1) if dh0 is not None else None
+      dc0 = pk.unsort_batch(dc0, 1) if dc0 is not None else None
     ctx.fwd = None
     model._pending -= 1
     if model._pending <= 0:
@@ -45,7 +65,7 @@ class NetFn(torch.autograd.Function):
         reducer.finish()              # the chunks went out during the pass (SEPKERN_DP_OVERLAP=1)
       else:
         model._allreduce_grads()      # once per step, after the last pass's backward
-    return None, None, dx, None, dh0, dc0, None
+    return None, None, dx, None, dh0, dc0, None, None
 
 
 class SepDNNBase(nn.Module):
@@ -161,9 +181,20 @@ class SepDNNBase(nn.Module):
     return (torch.randn(shape, device=dev, generator=self.hidden_generator),
             torch.randn(shape, device=dev, generator=self.hidden_generator))
 
-  def run_net(self, x, lens, h0, c0, want_state=False):
-    """x (T,B,in_dim) time-major zero-padded CUDA tensor, lens int32 CUDA (B) -> mask (T,B,out_dim)
-    [, hn, cn (2L,B,H)].  Differentiable when grad is enabled."""
+  def packing_of(self, lens):
+    """The Packing of a batch given per-utterance lengths (device int32 tensor, list or array; any order).  A device
+    tensor costs a host read-back, so the last one is remembered (the RSH arch runs several passes per batch)."""
+    if torch.is_tensor(lens):
+      key = (lens.data_ptr(), lens._version, int(lens.numel()))
+      hit = getattr(self, "_pk_last", None)
+      if hit is not None and hit[0] == key:
+        return hit[1]
+      pk = Packing.from_lens(lens, self.lin.weight.device)
+      self._pk_last = (key, pk, lens)         # (holds `lens`: its address cannot be reused while the entry is alive)
+      return pk
+    return Packing.from_lens(lens, self.lin.weight.device)
+
+  def _run(self, x, pk, h0, c0, want_state, padded):
     eng = self._bind()
     h0 = h0.to(x.device, torch.float32).contiguous()
     c0 = c0.to(x.device, torch.float32).contiguous()
@@ -171,9 +202,42 @@ class SepDNNBase(nn.Module):
       self.bn.num_batches_tracked += 1
     if torch.is_grad_enabled():
       self._pending += 1
-      return NetFn.apply(self._anchor, self, x, lens, h0, c0, want_state)
-    mask, hn, cn, _ = eng.forward(x, lens, h0, c0, self.training, save=False, want_state=want_state)
+      return NetFn.apply(self._anchor, self, x, pk, h0, c0, want_state, padded)
+    if padded:
+      T_pad = x.shape[0]
+      x, h0, c0 = pk.pack(x), pk.sort_batch(h0, 1).contiguous(), pk.sort_batch(c0, 1).contiguous()
+    mask, hn, cn, _ = eng.forward(x, pk, h0, c0, self.training, save=False, want_state=want_state)
+    if padded:
+      mask = pk.unpack(mask, fill=None if (pk.uniform and T_pad == pk.T) else eng.pad_row(), T=T_pad)
+      if want_state:
+        hn, cn = pk.unsort_batch(hn, 1), pk.unsort_batch(cn, 1)
     return (mask, hn, cn) if want_state else mask
+
+  def run_net_packed(self, x2d, pk, h0, c0, want_state=False):
+    """x2d (R, in_dim) packed rows of the batch `pk` (sepkern.packing.Packing; PackedSequence.data as the collator built
+    it), h0 / c0 (2L,B,H) in the batch's sorted order -> mask (R, out_dim) packed [, hn, cn].  Differentiable when grad
+    is enabled.  This is the engine's native layout: nothing is copied."""
+    return self._run(x2d, pk, h0, c0, want_state, False)
+
+  def run_net(self, x, lens, h0, c0, want_state=False):
+    """x (T,B,in_dim) time-major zero-padded CUDA tensor, lens int32 CUDA (B) or host lengths, any order -> mask
+    (T,B,out_dim), at padded positions the value the reference's network shows there [, hn, cn (2L,B,H)].  Differentiable when grad is enabled.  The batch is
+    packed on the way in and unpacked on the way out (sk_pack_rows / sk_unpack_rows)."""
+    return self._run(x, self.packing_of(lens), h0, c0, want_state, True)
+
+
+def to_packed(packed, device):
+  """PackedSequence (as the Collators build it) -> (its data on the device (R, C), Packing).  No padding is ever made:
+  PackedSequence.data IS the engine's row layout."""
+  if not isinstance(packed, PackedSequence):
+    raise TypeError("expected a PackedSequence from the arch's collator")
+  if packed.sorted_indices is not None:
+    raise TypeError("expected a PackedSequence of an already length-sorted batch (the arch's collator sorts)")
+  pk = Packing.from_batch_sizes(packed.batch_sizes, device)
+  data = packed.data
+  if data.device != torch.device(device):
+    data = data.to(device, non_blocking=True)
+  return data, pk
 
 
 def to_padded(packed, device):

@@ -129,7 +129,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     if splitk > 1:
         ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
     elif not bf16 and batch == 1 and (variant == 6 or (variant == 0 and _STREAMK and not transA and M >= 4096 and N >= 1024)):
-        ws = workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), ws_tag + "_sk")    # pieces of the stream-K cut
+        ws = _streamk_ws()                                                              # pieces of the stream-K cut
     with _timed("gemm_bf16_kernel" if bf16 else "gemm_f32_kernel", 2.0 * M * N * K * batch):
         args = (_ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA), int(transB), int(accumulate),
                 int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws))
@@ -137,6 +137,12 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
             _lib.call("sk_gemm_bf16_splitk", *args, _stream())
         else:
             _lib.call("sk_gemm_f32_splitk", *args, int(variant), _stream())
+
+
+def _streamk_ws():
+    """The stream-K kernels' workspace (ticket counters + piece slabs, 134 MB): ONE per stream -- launches on a stream run
+    in order, so they can share it; two streams never do (their tickets and slabs would mix)."""
+    return workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), "streamk_%x" % torch.cuda.current_stream().cuda_stream)
 
 
 def pad_to(n, m):
@@ -157,18 +163,6 @@ def cast_bf16(x2d, ld=None, out=None, rows=None):
     return out
 
 
-def cast_bf16_t(x2d, ld=None, out=None):
-    """TRANSPOSED bf16 copy (C, ld) of an fp32 (R, C) matrix, ld >= R (default: R rounded up to 64, plus 64 zero
-    columns so that a product may start a few rows in and still read zeros past the end)."""
-    _chk(x2d)
-    R, Cc = x2d.shape
-    ld = pad_to(R, 64) + 64 if ld is None else ld
-    if out is None:
-        out = torch.empty(Cc, ld, dtype=torch.bfloat16, device=x2d.device)
-    _lib.call("sk_cast_bf16_t", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(out), ld, _stream())
-    return out
-
-
 def gemm_bf16_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, accumulate=False, act=0, batch=1, sA=0, sB=0, sC=0,
                  sbias=0, splitk=1, ws_tag="gemm", streamk=False):
     """Cout[M,N] = act(A[M,K] B[N,K]^T + bias (+ Cout)) with A, B bfloat16 tensors (K-contiguous, K % 64 == 0).
@@ -180,7 +174,7 @@ def gemm_bf16_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, accumulate=False
     ws = None
     if streamk and _STREAMK_BF16 and batch == 1 and splitk in (0, 1) and M >= 256 and (N % 256 == 0 or N > 1024) and K >= 512:
         splitk = 1
-        ws = workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), ws_tag + "_sk")
+        ws = _streamk_ws()
     if splitk == 0:
         splitk = pick_splitk_bf16(M, N, K, batch)
     if splitk > 1:
@@ -203,7 +197,7 @@ def gemm_bf16_mm(A, B, Cout, M, N, K, lda, ldb, ldc, a_kmajor=False, b_kmajor=Fa
     ws = None
     if streamk and _STREAMK_BF16 and batch == 1 and splitk in (0, 1) and M >= 256 and (N % 256 == 0 or N > 1024) and K >= 512:
         splitk = 1
-        ws = workspace(_lib.load().sk_gemm_streamk_workspace_bytes(), ws_tag + "_sk")
+        ws = _streamk_ws()
     if splitk == 0:
         splitk = pick_splitk_bf16(M, N, K, batch)
     if splitk > 1:
@@ -332,11 +326,16 @@ def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True):
 
 
 # ----------------------------------------------------------------------------- PIT-MSE
-def pit_mse_fwd(mask, mix, srcs, lens, norm_dev=None):
+def pit_mse_fwd(mask, mix, srcs, lens, norm_dev=None, packing=None):
     """mask (T,B,S*F), mix (T,B,F), srcs list of S (T,B,F), lens int32 (B), norm_dev: optional device
     scalar replacing sum(lens)*F (the global norm under data parallelism) ->
-    dict(out (3,), pair (B,S,S), perm_loss (S!,B), best_perm (B))."""
-    T, B, F = mix.shape
+    dict(out (3,), pair (B,S,S), perm_loss (S!,B), best_perm (B)).
+    packing (sepkern.packing.Packing): mask (>= R, S*F), mix and srcs (>= R, F) are PACKED rows (PackedSequence.data)."""
+    if packing is not None:
+        T, B, F = packing.T, packing.B, mix.shape[1]
+        lens = packing.lens
+    else:
+        T, B, F = mix.shape
     S = len(srcs)
     for t in [mask, mix] + list(srcs):
         _chk(t)
@@ -354,18 +353,23 @@ def pit_mse_fwd(mask, mix, srcs, lens, norm_dev=None):
     ws = workspace(_lib.load().sk_pit_workspace_bytes(T, B, S), "pit")
     sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
     _chk(norm_dev)
-    _lib.call("sk_pit_mse_fwd", _ptr(mask), _ptr(mix), sp, _ptr(lens), T, B, F, S, _ptr(norm_dev), _ptr(pair),
-              _ptr(perm_loss), _ptr(best), _ptr(out), _ptr(ws), _stream())
+    _lib.call("sk_pit_mse_fwd", _ptr(mask), _ptr(mix), sp, _ptr(lens), _ptr(packing.offs) if packing is not None else None,
+              T, B, F, S, _ptr(norm_dev), _ptr(pair), _ptr(perm_loss), _ptr(best), _ptr(out), _ptr(ws), _stream())
     return dict(out=out, pair=pair, perm_loss=perm_loss, best_perm=best)
 
 
-def pit_mse_bwd(mask, mix, srcs, best_perm, out, gscale):
-    T, B, F = mix.shape
+def pit_mse_bwd(mask, mix, srcs, best_perm, out, gscale, packing=None):
     S = len(srcs)
     dmask = torch.empty_like(mask)
     sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
     _chk(gscale)
-    _lib.call("sk_pit_mse_bwd", _ptr(mask), _ptr(mix), sp, _ptr(best_perm), _ptr(out), _ptr(gscale), T, B, F, S,
+    if packing is not None:
+        T, B, F, R, offs = packing.T, packing.B, mix.shape[1], packing.R, packing.offs
+        if mask.shape[0] > R:
+            dmask[R:].zero_()            # tail rows of an (Rp, .) buffer stay zero
+    else:
+        (T, B, F), R, offs = mix.shape, 0, None
+    _lib.call("sk_pit_mse_bwd", _ptr(mask), _ptr(mix), sp, _ptr(best_perm), _ptr(out), _ptr(gscale), _ptr(offs), R, T, B, F, S,
               _ptr(dmask), _stream())
     return dmask
 
@@ -424,14 +428,19 @@ def bn_ws(R, Ccols, tag="bn"):
     return workspace(_lib.load().sk_bn_workspace_bytes(R, Ccols), tag)
 
 
-def bn_stats(x2d, mean, var):
+def bn_stats(x2d, mean, var, rows=None, count=None):
+    """mean / biased variance per column over `count` rows of which the first `rows` of x2d are stored and the rest are
+    zero rows that are not (packed sequences: count = B * T_max); defaults: all of x2d's rows, count = rows."""
     R, Cc = x2d.shape
-    _lib.call("sk_bn_stats", _ptr(x2d), R, Cc, _ptr(mean), _ptr(var), _ptr(bn_ws(R, Cc)), _stream())
-
-
-def bn_update_running(mean, var, rmean, rvar, R, momentum):
-    _lib.call("sk_bn_update_running", _ptr(mean), _ptr(var), _ptr(rmean), _ptr(rvar), R, mean.numel(), float(momentum),
+    R = R if rows is None else rows
+    _lib.call("sk_bn_stats", _ptr(x2d), R, Cc, int(R if count is None else count), _ptr(mean), _ptr(var), _ptr(bn_ws(R, Cc)),
               _stream())
+
+
+def bn_update_running(mean, var, rmean, rvar, count, momentum, guard=None):
+    """guard: optional device word (the recurrence's sticky status, lstm_sticky): non-zero = leave the running statistics."""
+    _lib.call("sk_bn_update_running", _ptr(mean), _ptr(var), _ptr(rmean), _ptr(rvar), int(count), mean.numel(), float(momentum),
+              _ptr(guard), _stream())
 
 
 def bn_apply(x2d, mean, var, gamma, beta, out, eps):
@@ -485,12 +494,45 @@ def colsum(x, R, Ccols, ld, out, accumulate=False, ws_tag="bn"):
     _lib.call("sk_colsum", _ptr(x), R, Ccols, ld, _ptr(out), int(accumulate), _ptr(bn_ws(R, Ccols, ws_tag)), _stream())
 
 
-def pad_rows(x2d, ld):
-    """(R, ld) copy of an (R, C) matrix with zero columns C..ld-1, one pass (sk_pad_rows)."""
+def pad_rows(x2d, ld, rows=None):
+    """(rows, ld) copy of an (R, C) matrix with zero columns C..ld-1 and zero rows R..rows-1, one pass (sk_pad_rows)."""
     _chk(x2d)
     R, Cc = x2d.shape
-    out = torch.empty(R, ld, device=x2d.device)
-    _lib.call("sk_pad_rows", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(out), ld, _stream())
+    rows = R if rows is None else rows
+    out = torch.empty(rows, ld, device=x2d.device)
+    _lib.call("sk_pad_rows", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(out), ld, rows, _stream())
+    return out
+
+
+# ----------------------------------------------------------------------------- packed rows
+def pack_rows(padded, pk, out):
+    """(T, B, C) zero-padded (caller's utterance order) -> the first R rows of out (>= R, ld): packed rows."""
+    _chk(padded)
+    _chk(out)
+    _, B, Cc = padded.shape                  # (frames past pk.T, if any, are padding)
+    _lib.call("sk_pack_rows", _ptr(padded), _ptr(pk.offs), _ptr(pk.perm), pk.T, B, Cc, _ptr(out), out.stride(0), _stream())
+
+
+def unpack_rows(packed, pk, out, fill=None):
+    """The first R rows of packed (>= R, ld) -> out (T, B, C) in the caller's utterance order; padded positions get the row
+    `fill` (C floats) or zeros."""
+    _chk(packed)
+    _chk(out)
+    _chk(fill)
+    T, B, Cc = out.shape
+    _lib.call("sk_unpack_rows", _ptr(packed), packed.stride(0), _ptr(pk.offs), _ptr(pk.perm), T, B, Cc, _ptr(fill), _ptr(out),
+              _stream())
+
+
+def hprev_rows(y2d, h0, pk, H, out):
+    """out[r] = [forward-direction output one frame earlier | reverse-direction output one frame later] of packed row r,
+    h0 (2, B, H) where a row has no such neighbour (sk_hprev_rows); out fp32 or bfloat16, (>= R, ld >= 2H)."""
+    _chk(y2d)
+    _chk(h0)
+    bf = out.dtype == torch.bfloat16
+    _chk(out, torch.bfloat16 if bf else torch.float32)
+    _lib.call("sk_hprev_rows", _ptr(y2d), y2d.stride(0), _ptr(h0), _ptr(pk.offs), pk.T, pk.B, H, _ptr(out), out.stride(0), int(bf),
+              _stream())
     return out
 
 
@@ -506,67 +548,47 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
-def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0, dual=False, tagged=False):
-    """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..28);
+def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0, tagged=False):
+    """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..29);
     poll_delay: the forward kernel's polling wave holds its first poll of a step back (units of 0.1 us, 0 = the library's
-    choice, 31 = none); dual: the forward kernel with two streams per workgroup (8 units x both directions) where the
-    shape allows it -- same results up to the rounding of a different summation order over K; tagged (forward, fp32): the
-    exchanged h carries the step's epoch in its two low mantissa bits and nothing else is signalled (mode bit 29)."""
+    choice, 31 = none); tagged (forward, fp32): the exchanged h carries the step's epoch in its two low mantissa bits and
+    nothing else is signalled (mode bit 29)."""
     return ((0x20000 if half else 0) | ((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) |
             (0x200000 if repflags else 0) | (0x400000 if spread else 0) | ((int(poll_delay) & 31) << 23) |
-            (0x10000000 if dual else 0) | (0x20000000 if tagged else 0))
+            (0x20000000 if tagged else 0))
 
 
-def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0, steps=None):
+def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0, offs=None,
+             rows=None):
     """bf16=True: W_hh and h_{t-1} enter the matrix cores rounded to bf16 (fp32 accumulate, fp32 state).
     half=True: 8-unit / 256-thread workgroups, two per CU (include/sepkern.h, mode bit 17); blockmap 0..2: which
-    workgroups share an XCD / a CU (mode bits 18..19; speed only).  steps=(s0, s1): only that range of processing
-    steps (sk_lstm_fwd_range: consecutive calls on the same workspace advance one sequence)."""
+    workgroups share an XCD / a CU (mode bits 18..19; speed only).  offs (int32, T+1): the sequence tensors are PACKED
+    rows (lens sorted descending; `rows` of them: the launch's algorithmic work for the profile); None: zero-padded (T, B, .)."""
     ws = lstm_ws(T, B, H)
     mode = int(mode) | (0x10000 if bf16 else 0) | (0x20000 if half else 0) | ((int(blockmap) & 3) << 18)
-    s0, s1 = (0, T) if steps is None else steps
-    with _timed("lstm_fwd_kernel", 2.0 * (s1 - s0) * B * 2 * 4 * H * H):
-        _lib.call("sk_lstm_fwd_range", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(y), _ptr(gates), _ptr(cs),
-                  _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, s0, s1, _stream())
+    _chk(offs, torch.int32)
+    with _timed("lstm_fwd_kernel", 2.0 * (T * B if rows is None else rows) * 2 * 4 * H * H):
+        _lib.call("sk_lstm_fwd", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(offs), _ptr(y), _ptr(gates), _ptr(cs),
+                  _ptr(hn), _ptr(cn), _ptr(ws), T, B, H, mode, _stream())
     return ws
 
 
 def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=None, dcn=None, bf16=False,
-             dbias=None, dg_first=None, steps=None, dgx_bf16=None):
-    """dbias ((B+15)//16, 2, 4H) and dg_first (2, B, 4H): optional by-products (include/sepkern.h) from which the
-    caller gets the bias gradients and, with lstm_whh_grad, dW_hh without another pass over dgx.  steps=(s0, s1): only
-    that range of processing steps (sk_lstm_bwd_range: consecutive calls on the same workspace advance one sequence).
-    dgx_bf16: a (rows >= T*B, ld >= 8H) bfloat16 tensor that receives dgx as bf16 as well (sk_lstm_bwd_twin)."""
+             dbias=None, dgx_bf16=None, offs=None, rows=None):
+    """dbias ((B+15)//16, 2, 4H): optional by-product (include/sepkern.h), its column sum is the bias gradient.
+    dgx_bf16: a (rows, ld >= 8H) bfloat16 tensor that receives dgx as bf16 as well.  offs: as lstm_fwd."""
     ws = lstm_ws(T, B, H)
     mode = int(mode) | (0x10000 if bf16 else 0)
-    for t in (dbias, dg_first):
-        _chk(t)
+    _chk(dbias)
+    _chk(offs, torch.int32)
     _chk(dgx_bf16, torch.bfloat16)
-    if dgx_bf16 is not None and (dgx_bf16.dim() != 2 or dgx_bf16.shape[0] < T * B or dgx_bf16.stride(1) != 1):
-        raise _lib.SepkernError("lstm_bwd: the bf16 twin must be a row-major (>= T*B, ld) matrix")
-    s0, s1 = (0, T) if steps is None else steps
-    with _timed("lstm_bwd_kernel", 2.0 * (s1 - s0) * B * 2 * 4 * H * H):
-        _lib.call("sk_lstm_bwd_twin", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
-                  _ptr(lens), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(dbias), _ptr(dg_first), _ptr(ws), T, B, H, mode,
-                  s0, s1, _ptr(dgx_bf16), 0 if dgx_bf16 is None else dgx_bf16.stride(0), _stream())
+    if dgx_bf16 is not None and (dgx_bf16.dim() != 2 or dgx_bf16.stride(1) != 1):
+        raise _lib.SepkernError("lstm_bwd: the bf16 twin must be a row-major (rows, ld) matrix")
+    with _timed("lstm_bwd_kernel", 2.0 * (T * B if rows is None else rows) * 2 * 4 * H * H):
+        _lib.call("sk_lstm_bwd", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
+                  _ptr(lens), _ptr(offs), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(dbias), _ptr(dgx_bf16),
+                  0 if dgx_bf16 is None else dgx_bf16.stride(0), _ptr(ws), T, B, H, mode, _stream())
     return ws
-
-
-def lstm_whh_grad(dgx, y, h0, dg_first, out, T, B, H, accumulate=False, bf16=False, ws_tag="gemm", variant=0):
-    """dW_hh (2,4H,H) [+]= sum_t dG_t^T h_{prev(t)} for both directions, WITHOUT materialising h_prev: the recurrent
-    input of step t is the layer's own output one step earlier in processing order, so
-      forward : dgx[1:, :, 0]^T  y[:-1, :, :H]   (rows past a sequence's end have dG = 0)
-      reverse : dgx[:-1, :, 1]^T y[1:, :, H:]    (y is 0 past the end, so the step at len-1 contributes nothing here)
-    as ONE batched GEMM over K = (T-1) B rows with per-direction operand offsets, plus the rank-B term of the steps
-    that start from h0: dg_first[d]^T h0[d] (lstm_bwd's by-product)."""
-    acc = accumulate
-    if T > 1:
-        A = dgx.view(-1)[B * 8 * H:]                     # direction 0 starts at t = 1; direction 1 at t = 0, +4H
-        gemm(A, y, out, 4 * H, H, (T - 1) * B, 8 * H, 2 * H, H, transA=True, accumulate=acc, batch=2,
-             sA=4 * H - B * 8 * H, sB=B * 2 * H + H, sC=4 * H * H, splitk=0, ws_tag=ws_tag, bf16=bf16, variant=variant)
-        acc = True
-    gemm(dg_first, h0, out, 4 * H, H, B, 4 * H, H, H, transA=True, accumulate=acc, batch=2, sA=B * 4 * H, sB=B * H,
-         sC=4 * H * H, ws_tag=ws_tag, bf16=bf16)
 
 
 def gate_rows(src, H, back=False, out=None, accumulate=False, cols=None):

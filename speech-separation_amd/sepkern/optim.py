@@ -37,6 +37,8 @@ class ClipAdam:
         eng = getattr(self.model, "_engine", None)
         ops.grad_norm(g, self.max_norm, self.scal, guard=eng.guard if eng is not None else None)
         ops.clip_adam(p, g, self.m, self.v, self.scal, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
+        if eng is not None:
+            eng.version += 1            # bf16 operand copies of the weights made before this update are stale now
         return self.scal
 
     def skipped(self):

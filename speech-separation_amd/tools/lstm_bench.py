@@ -7,7 +7,8 @@ or rounding-order level).
     python tools/lstm_bench.py [--bf16] [--T 400] [--B 32] [--H 896] [--rounds 7] [--fwd "0,0;1,0;1,2"] [--bwd "0;1"]
 
 --fwd / --bwd: lists of "half,map,poll1,repflags" (sk_lstm_fwd / sk_lstm_bwd mode bits 17, 18..19, 20, 21; trailing
-fields default to 0); 5th field: minimum number of batch groups per workgroup (mode bits 8..15); 6th: one flag per 128-byte line; 7th: hold-back of the first poll after the own flag store, x 0.1 us (0 = library's choice, 31 = none); 8th (forward): two streams per workgroup (mode bit 28); 9th (forward): tagged data instead of flags (mode bit 29).
+fields default to 0); 5th field: minimum number of batch groups per workgroup (mode bits 8..15); 6th: one flag per 128-byte line; 7th: hold-back of the first poll after the own flag store, x 0.1 us (0 = library's choice, 31 = none); 8th (forward): tagged data instead of flags (mode bit 29).
+--ragged: lengths stepping down from T to 5T/6 over the batch, PACKED rows (the engine's layout).
 """
 import argparse
 import os
@@ -36,29 +37,32 @@ def main():
     gx = torch.randn(T, B, 2, 4 * H, device="cuda") * 0.5
     whh = torch.randn(2, 4 * H, H, device="cuda") / 30
     h0, c0 = torch.randn(2, B, H, device="cuda"), torch.randn(2, B, H, device="cuda")
-    lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    from sepkern.packing import Packing
+    lens_h = [T] * B
     if a.ragged:
-        lens[1::3] = max(1, (5 * T) // 6)
+        lens_h = sorted((T - (b * (T // 6)) // max(1, B - 1) for b in range(B)), reverse=True)
+    pk = Packing.from_lens(lens_h, "cuda")
+    lens, offs = pk.lens, (pk.offs if a.ragged else None)
     dy = torch.randn(T, B, 2 * H, device="cuda")
     def parse(spec):
         out = []
         for s in spec.split(";"):
             if s:
                 v = [int(x) for x in s.split(",")]
-                out.append(tuple(v + [0] * (9 - len(v))))
+                out.append(tuple(v + [0] * (8 - len(v))))
         return out
     fwd_vars, bwd_vars = parse(a.fwd), parse(a.bwd)
 
     def bits(var):
-        return ops.lstm_variant_bits(bool(var[0]), var[1], bool(var[2]), bool(var[3]), bool(var[5]), var[6], dual=bool(var[7]), tagged=bool(var[8])) | (var[4] << 8)
+        return ops.lstm_variant_bits(bool(var[0]), var[1], bool(var[2]), bool(var[3]), bool(var[5]), var[6], tagged=bool(var[7])) | (var[4] << 8)
 
     def run_fwd(var):
         g = gx.clone()
-        y, cs = torch.empty(T, B, 2 * H, device="cuda"), torch.empty(T, B, 2, H, device="cuda")
+        y, cs = torch.zeros(T, B, 2 * H, device="cuda"), torch.zeros(T, B, 2, H, device="cuda")
         hn, cn = torch.empty(2, B, H, device="cuda"), torch.empty(2, B, H, device="cuda")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, hn, cn, T, B, H, 1 | bits(var), bf16=bf)
+        ws = ops.lstm_fwd(g, whh, h0, c0, lens, y, g, cs, hn, cn, T, B, H, 1 | bits(var), bf16=bf, offs=offs)
         e1.record()
         torch.cuda.synchronize()
         ops.lstm_status(ws)
@@ -70,7 +74,7 @@ def main():
         dh0, dc0 = torch.empty(2, B, H, device="cuda"), torch.empty(2, B, H, device="cuda")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, lens, gg, dh0, dc0, T, B, H, 1 | bits(var), bf16=bf)
+        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, lens, gg, dh0, dc0, T, B, H, 1 | bits(var), bf16=bf, offs=offs)
         e1.record()
         torch.cuda.synchronize()
         ops.lstm_status(ws)
@@ -99,10 +103,10 @@ def main():
     print("BLSTM recurrence, T=%d B=%d H=%d %s%s: us per step (median / min over %d rounds), max |diff| vs first variant"
           % (T, B, H, "bf16" if bf else "fp32", " ragged" if a.ragged else "", a.rounds))
     for v in fwd_vars:
-        print("  fwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d dual=%d tagged=%d : %7.3f / %7.3f   diff %.3g"
+        print("  fwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d tagged=%d : %7.3f / %7.3f   diff %.3g"
               % (v + (1e3 * statistics.median(tf[v]) / T, 1e3 * min(tf[v]) / T, df[v])))
     for v in bwd_vars:
-        print("  bwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d dual=%d tagged=%d : %7.3f / %7.3f   diff %.3g"
+        print("  bwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d tagged=%d : %7.3f / %7.3f   diff %.3g"
               % (v + (1e3 * statistics.median(tb[v]) / T, 1e3 * min(tb[v]) / T, db[v])))
 
 

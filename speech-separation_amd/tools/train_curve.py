@@ -29,13 +29,13 @@ def main():
         model.hidden_generator = torch.Generator(device="cuda")
         model.hidden_generator.manual_seed(1234)
         opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
-        mix, srcs, lens, _ = bench.make_batch(torch, ops, synth, 32, 400, 2, 0)
+        mix, srcs, pk, _, _ = bench.make_batch(torch, ops, synth, 32, 400, 2, 0)
         out = []
         acc = torch.zeros(1, device="cuda")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            loss, norm = uPIT.compute_loss_padded(model, mix, srcs, lens)
+            loss, norm = uPIT.compute_loss_packed(model, mix, srcs, pk)
             loss.backward()
             opt.step()
             if i % 20 == 0 or i == steps - 1:
@@ -45,7 +45,7 @@ def main():
         v = float(loss.detach())
         assert v == v and v > 0
         opt.check()
-        frames = int(lens.sum().item()) * steps
+        frames = pk.R * steps
         print("%s  loss by step  %s" % (dtype, "  ".join("%d:%.5f" % (i, float(l)) for i, l in out)), flush=True)
         # the bench times 20 steps (0.8 s); this is the same step sustained for `steps` steps (clocks settle)
         print("%s  sustained: %d steps in %.2f s = %.3f ms/step = %.1f frames/s" % (dtype, steps, secs, 1e3 * secs / steps,

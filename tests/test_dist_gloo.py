@@ -147,12 +147,15 @@ def _bn_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from sepkern import dist as skdist
     g = torch.Generator().manual_seed(3)
-    xs = [torch.randn(n, 5, generator=g) * (1 + i) + i for i, n in enumerate((7, 12))]      # unequal shard sizes
+    # rank 0: a grid of B = 2 utterances x T = 5 frames, rank 1: B = 3 x T = 4 -- the global batch's grid is 5 x 5 frames, of
+    # which the 3 that no rank's own grid holds are zero padding (rank 1's utterances end before the global longest one)
+    grids = ((2, 5), (3, 4))
+    xs = [torch.randn(b * t, 5, generator=g) * (1 + i) + i for i, (b, t) in enumerate(grids)]
     x = xs[rank]
-    mean, var, n = skdist.combine_bn_stats(x.mean(0), x.var(0, unbiased=False), x.shape[0])
+    mean, var, n = skdist.combine_bn_stats(x.mean(0), x.var(0, unbiased=False), *grids[rank])
     dg, db = skdist.allreduce_bn_sums(x.sum(0), (x * x).sum(0))
-    allx = torch.cat(xs)
-    ok = (n == 19.0 and torch.allclose(mean, allx.mean(0), atol=1e-6) and
+    allx = torch.cat(xs + [torch.zeros(3, 5)])
+    ok = (n == 25.0 and torch.allclose(mean, allx.mean(0), atol=1e-6) and
           torch.allclose(var, allx.var(0, unbiased=False), rtol=1e-5) and
           torch.allclose(dg, allx.sum(0), rtol=1e-6) and torch.allclose(db, (allx * allx).sum(0), rtol=1e-6))
     q.put((rank, bool(ok)))
@@ -161,7 +164,7 @@ def _bn_worker(rank, world, port, q):
 
 def test_bn_statistics_of_the_global_batch_over_two_ranks():
     """The optional BatchNorm exchange of the data-parallel path (sepkern.dist.combine_bn_stats / allreduce_bn_sums):
-    per-rank (count, mean, biased variance) combine to the statistics of the union, per-channel sums add up."""
+    per-rank (grid, mean, biased variance) combine to the statistics of the global batch's zero-padded grid, per-channel sums add up."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

@@ -175,7 +175,7 @@ def test_gemm_splitk_is_deterministic_and_matches_fp64(ops, M, N, K, S):
     assert torch.equal(outs[0], outs[1])                     # fixed-order slab reduction: bitwise reproducible
 
 
-@pytest.mark.parametrize("variant", [3, 4, 5])
+@pytest.mark.parametrize("variant", [3, 4])
 @pytest.mark.parametrize("M,N,K,tA,tB,S", [(300, 260, 512, False, True, 1), (700, 260, 528, False, False, 1), (516, 132, 1024, True, False, 1),
                                             (1000, 772, 1792, False, True, 1), (517, 1792, 3584, False, False, 2),
                                             (1028, 132, 4096, True, False, 4), (256, 128, 16, False, True, 1),
@@ -404,6 +404,17 @@ def test_pit_mse_fwd_bwd_matches_oracle(ops, S):
     dm = ops.pit_mse_bwd(dev(mask), dev(mix), [dev(s) for s in srcs], res["best_perm"], res["out"],
                          torch.ones(1).cuda())
     np.testing.assert_allclose(dm.cpu().permute(1, 0, 2).numpy(), mo.grad.numpy(), rtol=1e-5, atol=1e-10)
+    # the same on PACKED rows (PackedSequence.data, what the collator hands over): only the valid frames exist
+    from sepkern.packing import Packing
+    pk = Packing.from_lens(lens.tolist(), "cuda")
+    pm, px, ps = pk.pack(dev(mask)), pk.pack(dev(mix)), [pk.pack(dev(s)) for s in srcs]
+    assert pm.shape == (pk.Rp, S * F) and pk.R == int(lens.sum())
+    res2 = ops.pit_mse_fwd(pm, px, ps, None, packing=pk)
+    np.testing.assert_allclose(res2["out"].cpu().numpy(), out, rtol=2e-6)
+    np.testing.assert_allclose(res2["perm_loss"].cpu().numpy(), losses.detach().numpy(), rtol=2e-6)
+    assert res2["best_perm"].cpu().tolist() == idx.tolist()
+    dm2 = ops.pit_mse_bwd(pm, px, ps, res2["best_perm"], res2["out"], torch.ones(1).cuda(), packing=pk)
+    np.testing.assert_allclose(pk.unpack(dm2).cpu().permute(1, 0, 2).numpy(), mo.grad.numpy(), rtol=1e-5, atol=1e-10)
 
 
 # ------------------------------------------------------------------------------------ BN / colsum / sigmoid
@@ -424,8 +435,15 @@ def test_bn_stats_apply_backward(ops):
     ops.bn_stats(dev(x), mean, var)
     np.testing.assert_allclose(mean.cpu().numpy(), x.double().mean(0).numpy(), atol=1e-6)
     np.testing.assert_allclose(var.cpu().numpy(), x.double().var(0, unbiased=False).numpy(), rtol=2e-5)
+    # packed rows: only the 700 non-zero rows are stored, the statistics still cover all R = 1000 positions
+    mean2, var2 = torch.empty(Cc).cuda(), torch.empty(Cc).cuda()
+    ops.bn_stats(dev(x[:700].contiguous()), mean2, var2, count=R)
+    np.testing.assert_allclose(mean2.cpu().numpy(), mean.cpu().numpy(), atol=1e-6)
+    np.testing.assert_allclose(var2.cpu().numpy(), var.cpu().numpy(), rtol=2e-5)
     rm, rv = torch.zeros(Cc).cuda(), torch.ones(Cc).cuda()
-    ops.bn_update_running(mean, var, rm, rv, R, 0.1)
+    ops.bn_update_running(mean, var, rm, rv, R, 0.1, guard=torch.ones(1, dtype=torch.int32).cuda())
+    assert float(rm.abs().sum()) == 0 and bool((rv == 1).all())          # a raised guard word: running statistics untouched
+    ops.bn_update_running(mean, var, rm, rv, R, 0.1, guard=torch.zeros(1, dtype=torch.int32).cuda())
     np.testing.assert_allclose(rm.cpu().numpy(), bn.running_mean.numpy(), atol=1e-6)
     np.testing.assert_allclose(rv.cpu().numpy(), bn.running_var.numpy(), rtol=2e-5)
     out = torch.empty(R, Cc).cuda()
@@ -510,6 +528,32 @@ def _layer_case(T, B, H, I, lens, seed):
     return w, x, h0, c0
 
 
+class _Rows:
+    """The two row layouts of the recurrence entry points behind one face: zero-padded (T, B, .) (offs = NULL) and
+    PACKED rows (torch's PackedSequence.data layout, sepkern.packing.Packing)."""
+
+    def __init__(self, layout, T, B, lens):
+        from sepkern.packing import Packing
+        self.packed, self.T, self.B = layout == "packed", T, B
+        self.pk = Packing.from_lens(lens, "cuda")
+        self.offs = self.pk.offs if self.packed else None
+        self.R = self.pk.Rp if self.packed else T * B
+        self.lens = torch.tensor(lens, dtype=torch.int32).cuda()
+        self.valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
+
+    def put(self, t):                    # (T, B, ...) host or device tensor -> this layout's rows on the device
+        t = t.cuda()
+        return self.pk.pack(t.reshape(self.T, self.B, -1)).clone() if self.packed else t.reshape(self.T * self.B, -1).clone()
+
+    def get(self, rows, C):              # rows -> (T, B, C), zeros at padded positions
+        rows = rows.reshape(self.R, -1)
+        return self.pk.unpack(rows) if self.packed else rows.view(self.T, self.B, C)
+
+    def new(self, C, fill=float("nan")):
+        return torch.full((self.R, C), fill).cuda()
+
+
+@pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("mode", [2, 1])
 @pytest.mark.parametrize("T,B,H,I,lens", [
     (5, 3, 8, 6, [5, 3, 1]),
@@ -519,7 +563,7 @@ def _layer_case(T, B, H, I, lens, seed):
     (5, 100, 600, 20, [5] * 40 + [4] * 30 + [2] * 29 + [1]),     # the reference's default batch: 3 batch groups per workgroup
     (4, 40, 896, 16, [4] * 17 + [3] * 20 + [1] * 3),             # 3 batch groups over 2 workgroup rows, last one ragged
 ])
-def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
+def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, layout, T, B, H, I, lens):
     w, x, h0, c0 = _layer_case(T, B, H, I, lens, seed=T * 100 + H)
     # ---- oracle with autograd
     wr = [[tuple(t.clone().requires_grad_(True) for t in w[0][d]) for d in range(2)]]
@@ -530,44 +574,52 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
     dhn, dcn = torch.randn(2, B, H, generator=gd), torch.randn(2, B, H, generator=gd)   # the final state feeds a later pass (RSH)
     ((y_ref * dy).sum() + (hn_ref * dhn).sum() + (cn_ref * dcn).sum()).backward()
     # ---- kernels
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+    rw = _Rows(layout, T, B, lens)
+    R = rw.R
     wih = torch.stack([w[0][d][0] for d in range(2)]).cuda()          # (2,4H,I)
     whh = torch.stack([w[0][d][1] for d in range(2)]).cuda()          # (2,4H,H)
     bsum = torch.stack([w[0][d][2] + w[0][d][3] for d in range(2)]).reshape(-1).cuda()
-    R = T * B
-    gx = torch.empty(T, B, 2, 4 * H).cuda()
+    xr = rw.put(x)
+    gx = rw.new(8 * H)
     # gx in the recurrence's gate-interleaved order (4u + g): reordered rows of W_ih and of the bias, plain GEMM
-    ops.gemm(dev(x), ops.gate_rows(wih.view(8 * H, I), H), gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=ops.gate_rows(bsum, H))
-    y = torch.full((T, B, 2 * H), float("nan")).cuda()
-    cs = torch.empty(T, B, 2, H).cuda()
+    ops.gemm(xr, ops.gate_rows(wih.view(8 * H, I), H), gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=ops.gate_rows(bsum, H))
+    y = rw.new(2 * H)
+    cs = rw.new(2 * H)
     hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
-    ws = ops.lstm_fwd(gx, whh, dev(h0), dev(c0), lens_d, y, gx, cs, hn, cn, T, B, H, mode)
+    ws = ops.lstm_fwd(gx, whh, dev(h0), dev(c0), rw.lens, y, gx, cs, hn, cn, T, B, H, mode, offs=rw.offs)
     ops.lstm_status(ws)
     tol = dict(rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), **tol)
+    if rw.packed and rw.pk.Rp > rw.pk.R:
+        assert bool(torch.isnan(y[rw.pk.R:]).all())                  # rows past the packed data are nobody's to write
+    np.testing.assert_allclose(rw.get(y, 2 * H).cpu().numpy(), y_ref.detach().numpy(), **tol)
     np.testing.assert_allclose(hn.cpu().numpy(), hn_ref.detach().numpy(), **tol)
     np.testing.assert_allclose(cn.cpu().numpy(), cn_ref.detach().numpy(), **tol)
     dh0, dc0 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
     nbg = (B + 15) // 16
-    dbias = torch.full((nbg, 2, 4 * H), float("nan")).cuda()         # by-products: bias-gradient partials ...
-    dg_first = torch.full((2, B, 4 * H), float("nan")).cuda()        # ... and the dG of the steps that start from h0
-    ws = ops.lstm_bwd(dev(dy), whh, gx, cs, dev(c0), lens_d, gx, dh0, dc0, T, B, H, mode, dhn=dev(dhn), dcn=dev(dcn),
-                      dbias=dbias, dg_first=dg_first)
+    dbias = torch.full((nbg, 2, 4 * H), float("nan")).cuda()         # by-product: bias-gradient partials
+    ws = ops.lstm_bwd(rw.put(dy), whh, gx, cs, dev(c0), rw.lens, gx, dh0, dc0, T, B, H, mode, dhn=dev(dhn), dcn=dev(dcn),
+                      dbias=dbias, offs=rw.offs)
     ops.lstm_status(ws)
     gtol = dict(rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(dh0.cpu().numpy(), h0r.grad.numpy(), **gtol)
     np.testing.assert_allclose(dc0.cpu().numpy(), c0r.grad.numpy(), **gtol)
-    dgx = ops.gates_interleaved(gx.view(R, 2, 4 * H), H, back=True).cpu().double()      # back to torch's gate-major order
+    dgx_pad = rw.get(gx, 8 * H).contiguous()                         # (T, B, 8H), zero at padded positions in either layout
+    if rw.packed:
+        assert bool((dgx_pad[~rw.valid] == 0).all())
+    dgx = ops.gates_interleaved(dgx_pad.view(T * B, 2, 4 * H), H, back=True).cpu().double()   # back to torch's gate-major order
     assert torch.isfinite(dgx).all()
-    # dW_hh without a materialised h_prev: time-shifted product with the layer output + the h0 steps
+    # dW_hh as the engine forms it: the recurrent inputs of the PACKED rows gathered (sk_hprev_rows), one batched product
+    pk = rw.pk
+    yp, dgp = pk.pack(rw.get(y, 2 * H).contiguous()), pk.pack(dgx_pad)
+    hp = ops.hprev_rows(yp, dev(h0), pk, H, pk.rows(2 * H))
     dwhh_gi = torch.full((2, 4 * H, H), float("nan")).cuda()
-    ops.lstm_whh_grad(gx, y, dev(h0), dg_first, dwhh_gi, T, B, H)
+    ops.gemm(dgp, hp, dwhh_gi, 4 * H, H, pk.Rp, 8 * H, 2 * H, H, transA=True, batch=2, sA=4 * H, sB=H, sC=4 * H * H, splitk=0)
     dwhh = ops.gate_rows(dwhh_gi, H, back=True)                       # rows come out interleaved, like dgx
     dwhh2 = ops.gate_rows(dwhh_gi, H, back=True, out=dwhh.clone(), accumulate=True)
     db = dbias.cpu().double().sum(0)                                  # (2, 4H)
     for d in range(2):
         w_ih_g, w_hh_g, b_ih_g, b_hh_g = (t.grad for t in wr[0][d])
-        np.testing.assert_allclose((dgx[:, d].t() @ x.double().view(R, I)).numpy(), w_ih_g.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose((dgx[:, d].t() @ x.double().view(T * B, I)).numpy(), w_ih_g.numpy(), rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(dwhh[d].cpu().numpy(), w_hh_g.numpy(), rtol=1e-4, atol=2e-5)
         np.testing.assert_allclose(dwhh2[d].cpu().numpy(), 2 * w_hh_g.numpy(), rtol=1e-4, atol=4e-5)
         np.testing.assert_allclose(dgx[:, d].sum(0).numpy(), b_ih_g.numpy(), rtol=1e-4, atol=2e-5)
@@ -575,6 +627,63 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
         np.testing.assert_allclose(b_hh_g.numpy(), b_ih_g.numpy())
 
 
+@pytest.mark.parametrize("lens", [[9, 7, 7, 3], [5, 5, 5], [6] + [1] * 40, [4, 4, 2, 1], [1]])
+def test_pack_unpack_and_recurrent_input_rows(ops, lens):
+    """sk_pack_rows / sk_unpack_rows / sk_hprev_rows against torch's own PackedSequence: the packed rows ARE
+    pack_padded_sequence(...).data, unpacking restores the padded tensor (or puts a fill row at padded positions), an unsorted
+    batch goes through `perm`, and the recurrent-input rows are the output one frame earlier / later or h0."""
+    from torch.nn.utils.rnn import pack_padded_sequence
+    from sepkern.packing import Packing
+    g = torch.Generator().manual_seed(len(lens))
+    T, B, C, H = max(lens), len(lens), 13, 8
+    x = torch.randn(T, B, C, generator=g)
+    for b, n in enumerate(lens):
+        x[n:, b] = 0
+    pk = Packing.from_lens(lens, "cuda")
+    ref = pack_padded_sequence(x, torch.tensor(lens), enforce_sorted=True)
+    assert pk.R == ref.data.shape[0] and pk.offs_host[-1] == pk.R
+    assert np.array_equal(np.diff(pk.offs_host), ref.batch_sizes.numpy())
+    pk2 = Packing.from_batch_sizes(ref.batch_sizes, "cuda")
+    assert np.array_equal(pk2.lens_host, np.asarray(lens)) and np.array_equal(pk2.offs_host, pk.offs_host)
+    rows = pk.pack(dev(x))
+    assert torch.equal(rows[:pk.R].cpu(), ref.data) and float(rows[pk.R:].abs().sum()) == 0
+    assert torch.equal(pk.unpack(rows).cpu(), x)
+    fill = torch.randn(C, generator=g)
+    want = x.clone()
+    for b, n in enumerate(lens):
+        want[n:, b] = fill
+    if not pk.uniform:
+        assert torch.equal(pk.unpack(rows, fill=dev(fill)).cpu(), want)
+    # an unsorted batch: sorted through perm, restored in the caller's order
+    order = torch.randperm(B, generator=g)
+    xs, ls = x[:, order].contiguous(), [lens[int(i)] for i in order]
+    pks = Packing.from_lens(ls, "cuda")
+    rs = pks.pack(dev(xs))
+    assert torch.equal(pks.unpack(rs).cpu(), xs)
+    order_s = pks.perm_host if pks.perm_host is not None else np.arange(B)      # sorted position -> the caller's utterance
+    assert list(pks.lens_host) == sorted(ls, reverse=True) and [ls[int(i)] for i in order_s] == list(pks.lens_host)
+    for t in (0, T - 1):
+        n_t = int(pks.offs_host[t + 1] - pks.offs_host[t])
+        assert torch.equal(rs[pks.offs_host[t]:pks.offs_host[t] + n_t].cpu(), xs[t, torch.as_tensor(order_s[:n_t].astype(np.int64))])
+    hs = torch.randn(2, B, H, generator=g)
+    assert torch.equal(pks.unsort_batch(pks.sort_batch(dev(hs), 1), 1).cpu(), hs)
+    # recurrent inputs
+    y = torch.randn(T, B, 2 * H, generator=g)
+    h0 = torch.randn(2, B, H, generator=g)
+    want = torch.zeros(T, B, 2 * H)
+    for b, n in enumerate(lens):
+        for t in range(n):
+            want[t, b, :H] = y[t - 1, b, :H] if t > 0 else h0[0, b]
+            want[t, b, H:] = y[t + 1, b, H:] if t + 1 < n else h0[1, b]
+    yp = pk.pack(dev(y))
+    hp = ops.hprev_rows(yp, dev(h0), pk, H, pk.rows(2 * H))
+    assert torch.equal(pk.unpack(hp).cpu(), want) and float(hp[pk.R:].abs().sum()) == 0
+    hb = ops.hprev_rows(yp, dev(h0), pk, H, torch.zeros(pk.Rp + 64, 64, dtype=torch.bfloat16).cuda())
+    assert torch.equal(hb[:pk.R, :2 * H].float().cpu(), pk.pack(want.cuda())[:pk.R].cpu().bfloat16().float())
+    assert float(hb[pk.R:].float().abs().sum()) == 0 and float(hb[:, 2 * H:].float().abs().sum()) == 0
+
+
+@pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("mode", [2, 1])
 @pytest.mark.parametrize("T,B,H,I,lens", [
     (5, 3, 8, 6, [5, 3, 1]),
@@ -583,7 +692,7 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, T, B, H, I, lens):
     (4, 32, 896, 24, [4] * 20 + [3] * 12),
     (4, 40, 1024, 16, [4] * 17 + [3] * 20 + [1] * 3),
 ])
-def test_lstm_layer_bf16_matches_bf16_oracle(ops, mode, T, B, H, I, lens):
+def test_lstm_layer_bf16_matches_bf16_oracle(ops, mode, layout, T, B, H, I, lens):
     """The recurrence with bf16 matrix-core inputs (mode bit 16; BASELINE configs[3]) against the CPU computation of
     the same arithmetic (oracle/upit_bf16.py: W_hh, h_{t-1} and dG_t rounded to bf16 inside the products)."""
     from oracle import upit_bf16 as OB
@@ -595,27 +704,27 @@ def test_lstm_layer_bf16_matches_bf16_oracle(ops, mode, T, B, H, I, lens):
     dy = torch.randn(T, B, 2 * H, generator=gd)
     dhn, dcn = torch.randn(2, B, H, generator=gd), torch.randn(2, B, H, generator=gd)
     ((y_ref * dy).sum() + (hn_ref * dhn).sum() + (cn_ref * dcn).sum()).backward()
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+    rw = _Rows(layout, T, B, lens)
+    R = rw.R
     wih = torch.stack([w[0][d][0] for d in range(2)]).cuda()
     whh = torch.stack([w[0][d][1] for d in range(2)]).cuda()
     bsum = torch.stack([w[0][d][2] + w[0][d][3] for d in range(2)]).reshape(-1).cuda()
-    R = T * B
-    gx = torch.empty(T, B, 2, 4 * H).cuda()
-    ops.gemm(dev(x), ops.gate_rows(wih.view(8 * H, I), H), gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=ops.gate_rows(bsum, H),
+    gx = rw.new(8 * H)
+    ops.gemm(rw.put(x), ops.gate_rows(wih.view(8 * H, I), H), gx, R, 8 * H, I, I, I, 8 * H, transB=True, bias=ops.gate_rows(bsum, H),
              bf16=True)
-    y = torch.full((T, B, 2 * H), float("nan")).cuda()
-    cs = torch.empty(T, B, 2, H).cuda()
+    y = rw.new(2 * H)
+    cs = rw.new(2 * H)
     hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
-    ws = ops.lstm_fwd(gx, whh, dev(h0), dev(c0), lens_d, y, gx, cs, hn, cn, T, B, H, mode, bf16=True)
+    ws = ops.lstm_fwd(gx, whh, dev(h0), dev(c0), rw.lens, y, gx, cs, hn, cn, T, B, H, mode, bf16=True, offs=rw.offs)
     ops.lstm_status(ws)
     # a rounding-order difference in fp32 can flip a bf16 rounding of one h (2^-9 relative on one term of H)
     tol = dict(rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(y.cpu().numpy(), y_ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(rw.get(y, 2 * H).cpu().numpy(), y_ref.detach().numpy(), **tol)
     np.testing.assert_allclose(hn.cpu().numpy(), hn_ref.detach().numpy(), **tol)
     np.testing.assert_allclose(cn.cpu().numpy(), cn_ref.detach().numpy(), **tol)
     dh0, dc0 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
-    ws = ops.lstm_bwd(dev(dy), whh, gx, cs, dev(c0), lens_d, gx, dh0, dc0, T, B, H, mode, dhn=dev(dhn), dcn=dev(dcn),
-                      bf16=True)
+    ws = ops.lstm_bwd(rw.put(dy), whh, gx, cs, dev(c0), rw.lens, gx, dh0, dc0, T, B, H, mode, dhn=dev(dhn), dcn=dev(dcn),
+                      bf16=True, offs=rw.offs)
     ops.lstm_status(ws)
 
     def close(a, ref, what):
@@ -623,7 +732,7 @@ def test_lstm_layer_bf16_matches_bf16_oracle(ops, mode, T, B, H, I, lens):
         assert err < 3e-3, (what, err)
     close(dh0.cpu(), h0r.grad, "dh0")
     close(dc0.cpu(), c0r.grad, "dc0")
-    dgx = ops.gates_interleaved(gx.view(R, 2, 4 * H), H, back=True).cpu()
+    dgx = ops.gates_interleaved(rw.get(gx, 8 * H).contiguous().view(T * B, 2, 4 * H), H, back=True).cpu()
     assert torch.isfinite(dgx).all()
     for d in range(2):
         close(dgx[:, d].sum(0), wr[0][d][2].grad, "db dir %d" % d)     # column sums of dG = bias gradient
@@ -652,15 +761,14 @@ def test_gemm_bf16_nt_equals_fp64_product_of_rounded_operands(ops, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), torch.sigmoid(ref).float().numpy(), atol=2e-5)   # pre-activations of O(sqrt(K))
 
 
-def test_gemm_bf16_nt_splitk_batch_accumulate_and_transposed_copy(ops):
-    """The weight-gradient form: A and B are TRANSPOSED bf16 copies (sk_cast_bf16_t) of (R, M) and (R, N) matrices,
-    K = R split into slabs, a batch of 2 with strides, accumulation into C; bitwise reproducible."""
+def test_gemm_bf16_nt_splitk_batch_accumulate(ops):
+    """The NT form with K split into slabs, a batch of 2 with strides, accumulation into C; bitwise reproducible."""
     g = torch.Generator().manual_seed(7)
     R, M, N = 1000, 300, 140
     X, Y = torch.randn(R, 2 * M, generator=g), torch.randn(R, 2 * N, generator=g)
-    Xt, Yt = ops.cast_bf16_t(dev(X)), ops.cast_bf16_t(dev(Y))
+    Xt, Yt = ops.cast_bf16(dev(X.t().contiguous())), ops.cast_bf16(dev(Y.t().contiguous()))     # (2M, ld), (2N, ld): K-contiguous
     ld = Xt.shape[1]
-    assert Xt.shape == (2 * M, ld) and ld % 64 == 0 and ld >= R + 64
+    assert Xt.shape == (2 * M, ld) and ld % 64 == 0 and ld >= R
     np.testing.assert_array_equal(Xt[:, :R].float().cpu().numpy(), X.t().bfloat16().float().numpy())
     assert float(Xt[:, R:].float().abs().sum()) == 0.0
     C0 = torch.randn(2, M, N, generator=g)
@@ -675,12 +783,6 @@ def test_gemm_bf16_nt_splitk_batch_accumulate_and_transposed_copy(ops):
         ref = C0[z].double() + X[:, z * M:(z + 1) * M].bfloat16().double().t() @ Y[:, z * N:(z + 1) * N].bfloat16().double()
         err = float((outs[0][z].cpu().double() - ref).abs().max() / ref.abs().max())
         assert err < 2e-6, (z, err)
-    # a product that starts B rows into the copies still sees zeros past the end (the time-shifted dW_hh product)
-    C = torch.zeros(M, N).cuda()
-    off = 32
-    ops.gemm_bf16_nt(Xt[:, off:], Yt, C, M, N, Kp, ld, ld, N)
-    ref = X[off:, :M].bfloat16().double().t() @ Y[:R - off, :N].bfloat16().double()
-    assert float((C.cpu().double() - ref).abs().max() / ref.abs().max()) < 2e-6
 
 
 @pytest.mark.parametrize("akm,bkm", [(False, True), (True, False), (True, True)])
@@ -761,25 +863,25 @@ def test_gemm_bf16_stream_k_kernel(ops, M, N, K, akm, bkm):
     assert int(ws[:65536].max()) == 0
 
 
+@pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("T,B,H,lens", [(9, 32, 896, [9] * 20 + [7] * 8 + [2] * 4), (7, 40, 600, [7] * 17 + [5] * 20 + [1] * 3),
                                         (6, 16, 64, [6] * 10 + [3] * 6)])
-def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H, lens):
+def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, layout, T, B, H, lens):
     """The speed-only variants of the persistent recurrence (include/sepkern.h, mode bits 17..27: 8-unit workgroups, block
     -> stream maps, one polling wave, replicated flags, poll hold-back) change which workgroup computes what and how the
     hand-off is signalled, never the arithmetic: outputs equal the default's bit for bit."""
     g = torch.Generator().manual_seed(H + T)
-    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    rw = _Rows(layout, T, B, lens)
+    gx = rw.put(torch.randn(T, B, 2, 4 * H, generator=g) * 0.5)
     whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
     h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
+    dy = rw.put(torch.randn(T, B, 2 * H, generator=g))
 
     def fwd(bits):
         gg = gx.clone()
-        y = torch.zeros(T, B, 2 * H).cuda()
-        cs = torch.zeros(T, B, 2, H).cuda()
+        y, cs = rw.new(2 * H, 0.0), rw.new(2 * H, 0.0)
         hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
-        ws = ops.lstm_fwd(gg, whh, h0, c0, lens_d, y, gg, cs, hn, cn, T, B, H, 1 | bits)
+        ws = ops.lstm_fwd(gg, whh, h0, c0, rw.lens, y, gg, cs, hn, cn, T, B, H, 1 | bits, offs=rw.offs)
         ops.lstm_status(ws)
         return y, gg, cs, hn, cn
 
@@ -788,20 +890,22 @@ def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H,
         gg = gates.clone()
         dh0, dc0 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
         dbias = torch.empty((B + 15) // 16, 2, 4 * H).cuda()
-        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, lens_d, gg, dh0, dc0, T, B, H, 1 | bits, dbias=dbias)
+        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, rw.lens, gg, dh0, dc0, T, B, H, 1 | bits, dbias=dbias, offs=rw.offs)
         ops.lstm_status(ws)
         return gg, dh0, dc0, dbias
 
-    valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
+    def rows_of(a):          # gates / cs are defined at valid steps only (padded layout: compare those)
+        if a.dim() == 2 and a.shape[0] == rw.R and not rw.packed and a.shape[1] in (8 * H, 2 * H):
+            return a.view(T, B, -1)[rw.valid]
+        return a
+
     ref = fwd(ops.lstm_variant_bits(False, 0, False, False, False, 31))                # r01 geometry, no hold-back
     for variant in [(False, 1, True, False, False, 0), (False, 1, True, True, False, 8), (False, 2, False, False, False, 31),
                     (True, 0, False, False, False, 31), (True, 2, True, True, False, 4), (False, 1, True, False, True, 0),
                     (False, 0, False, False, True, 31)]:
         out = fwd(ops.lstm_variant_bits(*variant))
         for a, b in zip(out, ref):
-            if a.dim() == 4 and a.shape[-1] == 4 * H:                                # gates: defined at valid steps only
-                a, b = a[valid], b[valid]
-            assert torch.equal(a, b), variant
+            assert torch.equal(rows_of(a), rows_of(b)), variant
     bref = bwd(ops.lstm_variant_bits(False, 0, False, False, False, 31), ref)
     for variant in [(False, 1, False, False, False, 31), (False, 2, False, False, False, 6), (False, 1, False, False, True, 0)]:
         out = bwd(ops.lstm_variant_bits(*variant), ref)
@@ -809,80 +913,41 @@ def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, T, B, H,
             assert torch.equal(a, b), variant
 
 
-@pytest.mark.parametrize("T,B,H,lens,delay", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1], 0), (9, 32, 1024, [9] * 31 + [3], 31),
-                                              (40, 16, 896, [40] * 9 + [17] * 7, 4), (7, 20, 300, [7] * 7 + [4] * 13, 0), (6, 20, 600, [6] * 7 + [4] * 13, 0),
-                                              (11, 3, 320, [11, 5, 1], 0)])
-def test_lstm_two_stream_forward_kernel(ops, T, B, H, lens, delay):
-    """lstm_fwd2_kernel (mode bit 28: workgroups of 8 units x both directions, MFMA waves and cell waves, no workgroup
-    barrier in the time loop) against the one-stream kernel: same values up to the rounding of summing four K quarters
-    instead of two K halves (1e-6 absolute on O(1) activations over the whole sequence), bit-for-bit reproducible from run
-    to run, and a sequence advanced in two launches equals one launch bit for bit.  H = 600 (38 unit groups: no four-way K
-    split) silently takes the one-stream kernel: then the results are identical."""
-    g = torch.Generator().manual_seed(7 * H + T)
-    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
-    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
-    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
-
-    def fwd(bits, ranges=(None,)):
-        gg = gx.clone()
-        y = torch.full((T, B, 2 * H), float("nan")).cuda()
-        cs = torch.zeros(T, B, 2, H).cuda()
-        hn, cn = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
-        for r in ranges:
-            ws = ops.lstm_fwd(gg, whh, h0, c0, lens_d, y, gg, cs, hn, cn, T, B, H, 1 | bits, steps=r)
-        ops.lstm_status(ws)
-        return y, gg, cs, hn, cn
-
-    valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
-    ref = fwd(ops.lstm_variant_bits(False, 1, True, False, False, 0))
-    dual = ops.lstm_variant_bits(False, 1, True, False, False, delay, dual=True)
-    out = fwd(dual)
-    again = fwd(dual)
-    cut = fwd(dual, [(0, T // 3), (T // 3, T)])
-    for a, b, c_, e in zip(out, ref, again, cut):
-        if a.dim() == 4 and a.shape[-1] == 4 * H:
-            a, b, c_, e = a[valid], b[valid], c_[valid], e[valid]
-        if a.dim() == 4:                                                          # cs: defined at valid steps only
-            a, b, c_, e = a[valid], b[valid], c_[valid], e[valid]
-        assert torch.isfinite(a).all()
-        assert float((a - b).abs().max()) < (1e-30 if H == 600 else 3e-6)
-        assert torch.equal(a, c_) and torch.equal(a, e)
-
-
+@pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("T,B,H,lens,delay", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1], 0), (30, 16, 896, [30] * 9 + [17] * 7, 31),
                                               (9, 100, 600, [9] * 60 + [4] * 40, 4), (7, 20, 300, [7] * 7 + [4] * 13, 8), (11, 3, 64, [11, 5, 1], 0)])
-def test_lstm_forward_tagged_hand_off(ops, T, B, H, lens, delay):
+def test_lstm_forward_tagged_hand_off(ops, layout, T, B, H, lens, delay):
     """Mode bit 29 (fp32 forward): the exchanged h carries the step's epoch in its two low mantissa bits, producers publish
     without drain / barrier / flag, consumers pull, check every word and pull again what was not there yet.  The product
     then runs on h with its two low bits replaced (3 ulp): results within 2e-6 of the flag protocol's, bit-reproducible from
-    run to run (also with NO hold-back, where first pulls regularly come too early and are repeated), step ranges
-    bit-identical to one launch, stale epochs of an earlier sequence in the workspace never accepted (T = 30 after T = 12
-    on one workspace: 30 % 4 == 2 is the colliding case without the zeroing)."""
+    run to run (also with NO hold-back, where first pulls regularly come too early and are repeated), one launch per step
+    (mode 2) bit-identical to the persistent launch, stale epochs of an earlier sequence in the workspace never accepted
+    (T = 30 after T = 12 on one workspace: 30 % 4 == 2 is the colliding case without the zeroing)."""
     g = torch.Generator().manual_seed(11 * H + T)
-    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
+    rw = _Rows(layout, T, B, lens)
+    gx = rw.put(torch.randn(T, B, 2, 4 * H, generator=g) * 0.5)
     whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
     h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
 
-    def fwd(bits, ranges=(None,)):
+    def fwd(bits, mode=1):
         gg = gx.clone()
-        y = torch.full((T, B, 2 * H), float("nan")).cuda()
-        cs = torch.zeros(T, B, 2, H).cuda()
+        y, cs = rw.new(2 * H, 0.0), rw.new(2 * H, 0.0)
         hn, cn = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
-        for r in ranges:
-            ws = ops.lstm_fwd(gg, whh, h0, c0, lens_d, y, gg, cs, hn, cn, T, B, H, 1 | bits, steps=r)
+        ws = ops.lstm_fwd(gg, whh, h0, c0, rw.lens, y, gg, cs, hn, cn, T, B, H, mode | bits, offs=rw.offs)
         ops.lstm_status(ws)
         return y, gg, cs, hn, cn
 
-    valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
+    def rows_of(a):
+        if a.dim() == 2 and a.shape[0] == rw.R and not rw.packed:
+            return a.view(T, B, -1)[rw.valid]
+        return a[:rw.pk.R] if (a.dim() == 2 and a.shape[0] == rw.R) else a
+
     ref = fwd(ops.lstm_variant_bits(False, 1, True, False, False, 0))
     tg = ops.lstm_variant_bits(False, 1, True, False, False, delay, tagged=True)
     out, again = fwd(tg), fwd(tg)
-    cut = fwd(tg, [(0, T // 3), (T // 3, T)])
-    for a, b, c_, e in zip(out, ref, again, cut):
-        if a.dim() == 4:                                                          # gates / cs: defined at valid steps only
-            a, b, c_, e = a[valid], b[valid], c_[valid], e[valid]
+    steps = fwd(tg, mode=2)
+    for a, b, c_, e in zip(out, ref, again, steps):
+        a, b, c_, e = rows_of(a), rows_of(b), rows_of(c_), rows_of(e)
         assert torch.isfinite(a).all()
         assert float((a - b).abs().max()) < 2e-6
         assert torch.equal(a, c_) and torch.equal(a, e)
@@ -891,158 +956,31 @@ def test_lstm_forward_tagged_hand_off(ops, T, B, H, lens, delay):
 @pytest.mark.parametrize("bf16", [False, True])
 @pytest.mark.parametrize("T,B,H,lens", [(9, 32, 896, [9] * 20 + [7] * 8 + [2] * 4), (6, 20, 304, [6] * 7 + [4] * 13), (5, 3, 64, [5, 3, 1])])
 def test_lstm_backward_bf16_twin_of_dgx(ops, T, B, H, lens, bf16):
-    """sk_lstm_bwd_twin (r03): the backward recurrence also writes dgx as bf16 into a caller-supplied (rows, ld) matrix.  The twin
-    equals the RNE rounding of the fp32 dgx of the same launch entry by entry (zero rows past a sequence's end included), what lies
-    outside the (T B) x 8H block is not touched, and the fp32 results are those of the launch without a twin."""
+    """The backward recurrence also writes dgx as bf16 into a caller-supplied (rows, ld) matrix (sk_lstm_bwd, dgx_bf16).  The
+    twin equals the RNE rounding of the fp32 dgx of the same launch entry by entry (padded layout: zero rows past a sequence's
+    end included), what lies outside the rows x 8H block is not touched, and the fp32 results are those of the launch
+    without a twin.  Packed rows: the same, on the R valid rows."""
     g = torch.Generator().manual_seed(7 * H + T)
-    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
-    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
-    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
-    gates = gx.clone()
-    y, cs = torch.zeros(T, B, 2 * H).cuda(), torch.zeros(T, B, 2, H).cuda()
-    ops.lstm_status(ops.lstm_fwd(gates, whh, h0, c0, lens_d, y, gates, cs, None, None, T, B, H, 1, bf16=bf16))
-    R, ld = T * B, 8 * H + 64
-    outs = []
-    for twin in (None, torch.full((R + 5, ld), 7.0, dtype=torch.bfloat16).cuda()):
-        gg = gates.clone()
-        dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
-        ops.lstm_status(ops.lstm_bwd(dy, whh, gg, cs, c0, lens_d, gg, dh0, dc0, T, B, H, 1, bf16=bf16, dgx_bf16=twin))
-        outs.append((gg, dh0, dc0))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-    dgx = outs[1][0].view(R, 8 * H)
-    assert torch.equal(twin[:R, :8 * H], dgx.to(torch.bfloat16))
-    assert float(dgx.abs().max()) > 0
-    assert bool((twin[R:] == 7).all()) and bool((twin[:, 8 * H:] == 7).all())
-
-
-@pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("T,B,H,lens,cuts", [(10, 32, 896, [10] * 20 + [7] * 8 + [2] * 4, (5,)), (9, 20, 300, [9] * 7 + [4] * 13, (2, 7)),
-                                             (8, 16, 64, [8] * 10 + [3] * 6, (1, 4))])
-def test_lstm_forward_in_step_ranges_equals_one_launch(ops, mode, bf16, T, B, H, lens, cuts):
-    """sk_lstm_fwd_range: a sequence advanced by consecutive launches over [0, s1), [s1, s2), ... [sk, T) on one workspace
-    gives, bit for bit, what one launch over [0, T) gives -- outputs, saved gates / cell states and the final state (the
-    engine splits a layer in two to run half of the next input projection beside the second launch)."""
-    g = torch.Generator().manual_seed(3 * H + T)
-    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
-    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
-    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
-
-    def fwd(ranges):
-        gg = gx.clone()
-        y = torch.zeros(T, B, 2 * H).cuda()
-        cs = torch.zeros(T, B, 2, H).cuda()
-        hn, cn = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
-        for r in ranges:
-            ws = ops.lstm_fwd(gg, whh, h0, c0, lens_d, y, gg, cs, hn, cn, T, B, H, mode, bf16=bf16, steps=r)
-        ops.lstm_status(ws)
-        return y, gg, cs, hn, cn
-
-    valid = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).cuda()
-    ref = fwd([None])
-    edges = (0,) + tuple(cuts) + (T,)
-    out = fwd(list(zip(edges[:-1], edges[1:])))
-    for a, b in zip(out, ref):
-        if a.dim() == 4 and a.shape[-1] == 4 * H:
-            a, b = a[valid], b[valid]
-        assert torch.equal(a, b)
-    with pytest.raises(Exception):
-        ops.lstm_fwd(gx, whh, h0, c0, lens_d, out[0], None, None, None, None, T, B, H, mode, steps=(3, 3))
-
-
-@pytest.mark.parametrize("T,B,H,lens,delay", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1], 31), (30, 16, 896, [30] * 9 + [17] * 7, 6),
-                                              (9, 100, 600, [9] * 60 + [4] * 40, 31), (7, 20, 300, [7] * 7 + [4] * 13, 8), (11, 3, 64, [11, 5, 1], 31)])
-def test_lstm_backward_tagged_hand_off(ops, T, B, H, lens, delay):
-    """Mode bit 29 in the backward recurrence (fp32): dG carries the step's epoch in the two low mantissa bits of its words,
-    producers publish without drain / barrier / flag, every wave checks each sub-block of its ring before multiplying it and
-    pulls it again while words are missing.  Results within 2e-6 relative of the flag protocol's (dG enters the product with
-    two bits replaced), bit-reproducible, step ranges bit-identical to one launch, dh0 / dc0 / bias sums / dg_first included."""
-    g = torch.Generator().manual_seed(13 * H + T)
-    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
-    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
-    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
-    dhn, dcn = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
-    gates = gx.clone()
-    y, cs = torch.zeros(T, B, 2 * H).cuda(), torch.zeros(T, B, 2, H).cuda()
-    ws = ops.lstm_fwd(gates, whh, h0, c0, lens_d, y, gates, cs, None, None, T, B, H, 1)
-    ops.lstm_status(ws)
-
-    def bwd(bits, ranges=(None,)):
-        gg = gates.clone()
-        dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
-        dbias = torch.zeros((B + 15) // 16, 2, 4 * H).cuda()
-        dgf = torch.zeros(2, B, 4 * H).cuda()
-        for r in ranges:
-            w = ops.lstm_bwd(dy, whh, gg, cs, c0, lens_d, gg, dh0, dc0, T, B, H, 1 | bits, dhn=dhn, dcn=dcn, dbias=dbias, dg_first=dgf,
-                             steps=r)
-        ops.lstm_status(w)
-        return gg, dh0, dc0, dbias, dgf
-
-    ref = bwd(ops.lstm_variant_bits(False, 1, False, False, False, 31))
-    tg = ops.lstm_variant_bits(False, 1, False, False, False, delay, tagged=True)
-    out, again = bwd(tg), bwd(tg)
-    cut = bwd(tg, [(0, T // 3), (T // 3, T)])
-    for i, (a, b, c_, e) in enumerate(zip(out, ref, again, cut)):
-        assert torch.isfinite(a).all()
-        scale = float(b.abs().max()) + 1e-30
-        assert float((a - b).abs().max()) / scale < 2e-6, i
-        assert torch.equal(a, c_)
-        if i == 3:          # dbias: per-launch sums are added (another rounding than one sum)
-            assert torch.allclose(a, e, rtol=1e-5, atol=1e-5)
-        else:
-            assert torch.equal(a, e), i
-
-
-@pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("T,B,H,lens,cuts", [(10, 32, 896, [10] * 20 + [7] * 8 + [2] * 4, (5,)), (9, 20, 300, [9] * 7 + [4] * 13, (2, 7)),
-                                             (8, 16, 64, [8] * 10 + [3] * 6, (1, 4))])
-def test_lstm_backward_in_step_ranges_equals_one_launch(ops, mode, bf16, T, B, H, lens, cuts):
-    """sk_lstm_bwd_range: the backward recurrence advanced by consecutive launches over [0, s1), [s1, s2), ... [sk, T) gives,
-    bit for bit, what one launch gives for dgx, dh0 / dc0 and dg_first, and the same bias-gradient partials up to the
-    rounding of adding per-launch sums; and after s steps the rows t >= T - s of the forward direction's dgx and t < s of the reverse one's already
-    hold their final values (what the engine's split backward schedule relies on)."""
-    g = torch.Generator().manual_seed(5 * H + T)
-    gx = (torch.randn(T, B, 2, 4 * H, generator=g) * 0.5).cuda()
-    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
-    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    dy = torch.randn(T, B, 2 * H, generator=g).cuda()
-    dhn, dcn = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
-    lens_d = torch.tensor(lens, dtype=torch.int32).cuda()
-    gates = gx.clone()
-    y, cs = torch.zeros(T, B, 2 * H).cuda(), torch.zeros(T, B, 2, H).cuda()
-    ws = ops.lstm_fwd(gates, whh, h0, c0, lens_d, y, gates, cs, None, None, T, B, H, mode, bf16=bf16)
-    ops.lstm_status(ws)
-
-    def bwd(ranges, probe=None):
-        gg = gates.clone()
-        dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
-        dbias = torch.zeros((B + 15) // 16, 2, 4 * H).cuda()
-        dgf = torch.zeros(2, B, 4 * H).cuda()
-        snap = None
-        for i, r in enumerate(ranges):
-            w = ops.lstm_bwd(dy, whh, gg, cs, c0, lens_d, gg, dh0, dc0, T, B, H, mode, dhn=dhn, dcn=dcn, bf16=bf16, dbias=dbias,
-                             dg_first=dgf, steps=r)
-            if probe is not None and i == 0:
-                torch.cuda.synchronize()
-                snap = gg.clone()
-        ops.lstm_status(w)
-        return (gg, dh0, dc0, dbias, dgf), snap
-
-    ref, _ = bwd([None])
-    edges = (0,) + tuple(cuts) + (T,)
-    out, snap = bwd(list(zip(edges[:-1], edges[1:])), probe=True)
-    for i, (a, b) in enumerate(zip(out, ref)):
-        if i == 3:          # dbias: per-launch sums are ADDED to it, (s_0..s_4) + (s_5..s_9) is another rounding than one sum
-            assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
-        else:
+    for layout in ("padded", "packed"):
+        rw = _Rows(layout, T, B, lens)
+        gates = rw.put(torch.randn(T, B, 2, 4 * H, generator=g) * 0.5)
+        whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+        h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+        dy = rw.put(torch.randn(T, B, 2 * H, generator=g))
+        y, cs = rw.new(2 * H, 0.0), rw.new(2 * H, 0.0)
+        ops.lstm_status(ops.lstm_fwd(gates, whh, h0, c0, rw.lens, y, gates, cs, None, None, T, B, H, 1, bf16=bf16, offs=rw.offs))
+        R = rw.pk.R if rw.packed else T * B
+        ld = 8 * H + 64
+        outs = []
+        for twin in (None, torch.full((R + 5, ld), 7.0, dtype=torch.bfloat16).cuda()):
+            gg = gates.clone()
+            dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+            ops.lstm_status(ops.lstm_bwd(dy, whh, gg, cs, c0, rw.lens, gg, dh0, dc0, T, B, H, 1, bf16=bf16, dgx_bf16=twin,
+                                         offs=rw.offs))
+            outs.append((gg, dh0, dc0))
+        for a, b in zip(*outs):
             assert torch.equal(a, b)
-    s1 = cuts[0]
-    assert torch.equal(snap[T - s1:, :, 0], ref[0][T - s1:, :, 0])      # forward direction: the last s1 time steps are done
-    assert torch.equal(snap[:s1, :, 1], ref[0][:s1, :, 1])              # reverse direction: the first s1
+        dgx = outs[1][0][:R]
+        assert torch.equal(twin[:R, :8 * H], dgx.to(torch.bfloat16))
+        assert float(dgx.abs().max()) > 0
+        assert bool((twin[R:] == 7).all()) and bool((twin[:, 8 * H:] == 7).all())

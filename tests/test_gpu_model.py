@@ -310,8 +310,6 @@ def test_coscheduled_backward_is_bitwise_the_serial_backward(arch):
     model.next_hidden = (h0, c0)
     arch.compute_loss(model, 0, batch)[0].backward()          # builds the engine
     assert model._engine.overlap, "co-scheduling is expected to be on by default"
-    model._engine.fwd_split = False                            # (changes the order of sums: its own test below)
-    model._engine.bwd_split = False                            # (likewise: half sums of the weight gradients)
     model._engine.var_side = model._engine.var_main            # same GEMM kernel on either stream (the default picks the
                                                                # register-staged one beside a recurrence: other K order)
     g_ser, l_ser = grads(False)
@@ -319,94 +317,6 @@ def test_coscheduled_backward_is_bitwise_the_serial_backward(arch):
         g_co, l_co = grads(True)
         assert l_co == l_ser
         assert torch.equal(g_co, g_ser)
-
-
-def test_split_forward_recurrences_change_rounding_only(arch):
-    """Forward co-scheduling (engine.forward): layers 0..L-2 run their recurrence in two launches of T/2 steps and half of
-    the next layer's input projection is computed beside the second launch, the other half after it.  Same products,
-    summed as (first K half) + (second K half) in a per-row order: loss and gradients agree with the unsplit schedule to
-    fp32 rounding, run after run bit for bit (a missing stream dependency would show up as run-to-run differences)."""
-    H, L, S, B, T = 896, 3, 2, 32, 48
-    torch.manual_seed(12)
-    rng = np.random.default_rng(12)
-    model = arch.SepDNN(0, num_spk=str(S), hidden_dim=str(H), num_layers=str(L))
-    model.cuda()
-    model.train()
-    lens = sorted([int(v) for v in rng.integers(T // 3, T + 1, B)])
-    lens[-1] = T
-    samples = []
-    for n in lens:
-        d = {"mix": np.abs(rng.standard_normal((n, 257))).astype(np.float32)}
-        for s in range(S):
-            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((n, 257))).astype(np.float32) * 0.6
-        samples.append(d)
-    batch = arch.Collator("mix")(samples)
-    h0, c0 = torch.randn(2 * L, B, H).cuda(), torch.randn(2 * L, B, H).cuda()
-
-    def grads(split):
-        model._engine.fwd_split = split
-        model.next_hidden = (h0, c0)
-        loss, _ = arch.compute_loss(model, 0, batch)
-        loss.backward()
-        torch.cuda.synchronize()
-        return model._engine.grad.clone(), float(loss)
-
-    model.next_hidden = (h0, c0)
-    arch.compute_loss(model, 0, batch)[0].backward()          # builds the engine
-    assert model._engine.overlap
-    g0, l0 = grads(False)
-    g1, l1 = grads(True)
-    assert abs(l1 - l0) <= 1e-6 * abs(l0)
-    assert float((g1 - g0).norm() / g0.norm()) < 2e-5
-    for _ in range(3):
-        g2, l2 = grads(True)
-        assert l2 == l1 and torch.equal(g2, g1)
-
-
-def test_split_backward_recurrences_change_rounding_only(arch):
-    """Backward co-scheduling, second form (engine.backward, SEPKERN_BWD_SPLIT=1): every layer's backward recurrence runs as two
-    launches of T/2 steps and the half of its OWN weight-gradient products whose rows are final after the first launch
-    (forward direction t >= T/2, reverse direction t < T/2) runs beside the second; the other half is accumulated onto it
-    later.  Same products in two partial sums: loss identical, gradients agree with the unsplit schedule to fp32
-    rounding, and run after run bit for bit (a missing stream dependency would show up as run-to-run differences)."""
-    H, L, S, B, T = 896, 3, 2, 32, 48
-    torch.manual_seed(13)
-    rng = np.random.default_rng(13)
-    model = arch.SepDNN(0, num_spk=str(S), hidden_dim=str(H), num_layers=str(L))
-    model.cuda()
-    model.train()
-    lens = sorted([int(v) for v in rng.integers(T // 3, T + 1, B)])
-    lens[-1] = T
-    samples = []
-    for n in lens:
-        d = {"mix": np.abs(rng.standard_normal((n, 257))).astype(np.float32)}
-        for s in range(S):
-            d["source%d" % (s + 1)] = np.abs(rng.standard_normal((n, 257))).astype(np.float32) * 0.6
-        samples.append(d)
-    batch = arch.Collator("mix")(samples)
-    h0, c0 = torch.randn(2 * L, B, H).cuda(), torch.randn(2 * L, B, H).cuda()
-
-    def grads(split):
-        model._engine.bwd_split = split
-        model.next_hidden = (h0, c0)
-        loss, _ = arch.compute_loss(model, 0, batch)
-        loss.backward()
-        torch.cuda.synchronize()
-        model.check_status()
-        return model._engine.grad.clone(), float(loss.detach())
-
-    model.next_hidden = (h0, c0)
-    arch.compute_loss(model, 0, batch)[0].backward()          # builds the engine
-    assert model._engine.overlap
-    g0, l0 = grads(False)
-    g1, l1 = grads(True)
-    assert l1 == l0                                           # the forward pass is untouched
-    assert float((g1 - g0).norm() / g0.norm()) < 2e-6
-    worst = float(((g1 - g0).abs() / (g0.abs() + 1e-3 * g0.abs().max())).max())
-    assert worst < 1e-3, worst
-    for _ in range(3):
-        g2, l2 = grads(True)
-        assert l2 == l1 and torch.equal(g2, g1)
 
 
 def test_data_parallel_sync_bn_equals_global_batch(tmp_path):
