@@ -214,6 +214,11 @@ def main():
         local = 0
         os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)
+    # rehearsals only: SEPKERN_LSTM_MODE_BY_RANK="0,2" gives every rank its own recurrence mode (one persistent grid beside
+    # ranks that launch per step: the chunked gradient exchange then runs next to a persistent kernel on a one-GPU box)
+    by_rank = os.environ.get("SEPKERN_LSTM_MODE_BY_RANK")
+    if by_rank:
+        os.environ["SEPKERN_LSTM_MODE"] = by_rank.split(",")[rank % len(by_rank.split(","))]
     from sepkern import dist as skdist
     skdist.init_from_env()                                # nccl (= RCCL over xGMI) unless SEPKERN_DIST_BACKEND says otherwise
 

@@ -230,22 +230,32 @@ def _i64(vals, device):
     return torch.tensor(vals, dtype=torch.int64, device=device)
 
 
-def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, stride_t=None, stride_f=None):
+def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, stride_t=None, stride_f=None, lengths=None):
     """STFT (n_fft 512, hop 128, reflect-centred, periodic Hann) of a list of 1-D waveforms.
 
-    wavs: list of 1-D CUDA tensors, float32 in [-1,1) or int16 PCM (scaled by 1/32768 in-kernel).
+    wavs: list of 1-D CUDA tensors, float32 in [-1,1) or int16 PCM (scaled by 1/32768 in-kernel) -- or, with
+    `lengths` (samples per utterance), ONE 1-D CUDA tensor holding the utterances back to back (a batch that crossed
+    PCIe as one copy).
     layout "TF": returns list of (T_u, 257) tensors; "FT": list of (257, T_u) (the reference's npz layout).
     With `out` given, writes element (t,f) of utterance u at out_offs[u] + t*stride_t[u] + f*stride_f[u].
     """
-    dev = wavs[0].device
-    pcm16 = wavs[0].dtype == torch.int16
-    for w in wavs:
-        _chk(w, torch.int16 if pcm16 else torch.float32)
-        if w.dim() != 1 or w.numel() <= 256:
-            raise _lib.SepkernError("stft needs 1-D waveforms longer than n_fft/2 samples")
-    ns = [int(w.numel()) for w in wavs]
+    if lengths is not None:
+        cat = wavs.contiguous()
+        ns = [int(n) for n in lengths]
+        dev, pcm16 = cat.device, cat.dtype == torch.int16
+        _chk(cat, torch.int16 if pcm16 else torch.float32)
+        if cat.dim() != 1 or sum(ns) != cat.numel() or min(ns) <= 256:
+            raise _lib.SepkernError("stft needs 1-D waveforms longer than n_fft/2 samples (and lengths that add up)")
+    else:
+        dev = wavs[0].device
+        pcm16 = wavs[0].dtype == torch.int16
+        for w in wavs:
+            _chk(w, torch.int16 if pcm16 else torch.float32)
+            if w.dim() != 1 or w.numel() <= 256:
+                raise _lib.SepkernError("stft needs 1-D waveforms longer than n_fft/2 samples")
+        ns = [int(w.numel()) for w in wavs]
+        cat = torch.cat(wavs) if len(wavs) > 1 else wavs[0].contiguous()
     Ts = [1 + n // 128 for n in ns]
-    cat = torch.cat(wavs) if len(wavs) > 1 else wavs[0].contiguous()
     woffs, acc = [], 0
     for n in ns:
         woffs.append(acc)
@@ -267,56 +277,63 @@ def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, s
     d_woffs, d_ns = _i64(woffs, dev), torch.tensor(ns, dtype=torch.int32, device=dev)
     d_ooffs, d_st, d_sf = _i64(out_offs, dev), _i64(stride_t, dev), _i64(stride_f, dev)
     frame_major = all(int(v) == 1 for v in stride_f)
-    _lib.call("sk_stft", _ptr(cat), int(pcm16), _ptr(d_woffs), _ptr(d_ns), len(wavs), 512, 128, int(want_complex),
+    _lib.call("sk_stft", _ptr(cat), int(pcm16), _ptr(d_woffs), _ptr(d_ns), len(ns), 512, 128, int(want_complex),
               _ptr(out), _ptr(d_ooffs), _ptr(d_st), _ptr(d_sf), int(frame_major), max(Ts), _stream())
     return ret if ret is not None else out
+
+
+def mask_istft_flat(mixcat, maskcat, Ts, S, want_pcm=True, want_float=True):
+    """Mask-apply + iSTFT on buffers that crossed PCIe as ONE copy each: mixcat = the utterances' (257, T_u) complex64
+    spectra back to back (flattened), maskcat = None or, per utterance and source (utterance-major), the (257, T_u) float32
+    masks back to back.  Returns (wav float32 flat or None, pcm int16 flat or None, offsets): source s of utterance u is
+    the 128 (T_u - 1) samples at offsets[u * S + s]."""
+    dev = mixcat.device
+    nutt, F = len(Ts), 257
+    _chk(mixcat, torch.complex64)
+    _chk(maskcat)
+    if mixcat.numel() != F * sum(Ts) or (maskcat is not None and maskcat.numel() != F * S * sum(Ts)):
+        raise _lib.SepkernError("mask_istft: buffer sizes do not match the frame counts")
+    moffs, koffs, ooffs, am, ak, ao = [], [], [], 0, 0, 0
+    for T in Ts:
+        moffs.append(am)
+        am += T * F
+        for s in range(S):
+            koffs.append(ak)
+            ak += T * F
+            ooffs.append(ao)
+            ao += 128 * (T - 1)
+    wav = torch.empty(ao, dtype=torch.float32, device=dev) if want_float else None
+    pcm = torch.empty(ao, dtype=torch.int16, device=dev) if want_pcm else None
+    d_moffs, d_mst, d_msf = _i64(moffs, dev), _i64([1] * nutt, dev), _i64(list(Ts), dev)
+    d_koffs = d_kst = d_ksf = None
+    if maskcat is not None:
+        d_koffs, d_kst, d_ksf = _i64(koffs, dev), d_mst, d_msf
+    d_T, d_ooffs = torch.tensor(list(Ts), dtype=torch.int32, device=dev), _i64(ooffs, dev)
+    _lib.call("sk_mask_istft", _ptr(mixcat), _ptr(d_moffs), _ptr(d_mst), _ptr(d_msf),
+              _ptr(maskcat), _ptr(d_koffs), _ptr(d_kst), _ptr(d_ksf),
+              _ptr(d_T), nutt, S, 512, 128, _ptr(wav), _ptr(pcm), _ptr(d_ooffs), max(Ts), _stream())
+    return wav, pcm, ooffs
 
 
 def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True):
     """Mask-apply + iSTFT.  mix_specs: list of (257, T_u) complex64 CUDA tensors (the reference's
     feats_test layout); masks: None or list (per utterance) of lists (per source) of (257, T_u) float32.
     Returns (list of lists of float32 waveforms or None, list of lists of int16 waveforms or None)."""
-    dev = mix_specs[0].device
     nutt = len(mix_specs)
     S = len(masks[0]) if masks is not None else 1
     Ts = [int(m.shape[1]) for m in mix_specs]
-    F = 257
     for m in mix_specs:
         _chk(m, torch.complex64)
-        if m.shape[0] != F:
+        if m.shape[0] != 257:
             raise _lib.SepkernError("mask_istft expects (257, T) spectra")
     mixcat = torch.cat([m.contiguous().view(-1) for m in mix_specs])
-    moffs, acc = [], 0
-    for T in Ts:
-        moffs.append(acc)
-        acc += T * F
-    mst, msf = [1] * nutt, list(Ts)
+    maskcat = None
     if masks is not None:
-        flat = []
-        koffs, acc = [], 0
         for u in range(nutt):
             for s in range(S):
                 _chk(masks[u][s])
-                flat.append(masks[u][s].contiguous().view(-1))
-                koffs.append(acc)
-                acc += Ts[u] * F
-        maskcat = torch.cat(flat)
-        kst, ksf = [1] * nutt, list(Ts)
-    ooffs, acc = [], 0
-    for u in range(nutt):
-        for s in range(S):
-            ooffs.append(acc)
-            acc += 128 * (Ts[u] - 1)
-    wav = torch.empty(acc, dtype=torch.float32, device=dev) if want_float else None
-    pcm = torch.empty(acc, dtype=torch.int16, device=dev) if want_pcm else None
-    d_moffs, d_mst, d_msf = _i64(moffs, dev), _i64(mst, dev), _i64(msf, dev)
-    d_koffs = d_kst = d_ksf = None
-    if masks is not None:
-        d_koffs, d_kst, d_ksf = _i64(koffs, dev), _i64(kst, dev), _i64(ksf, dev)
-    d_T, d_ooffs = torch.tensor(Ts, dtype=torch.int32, device=dev), _i64(ooffs, dev)
-    _lib.call("sk_mask_istft", _ptr(mixcat), _ptr(d_moffs), _ptr(d_mst), _ptr(d_msf),
-              _ptr(maskcat) if masks is not None else None, _ptr(d_koffs), _ptr(d_kst), _ptr(d_ksf),
-              _ptr(d_T), nutt, S, 512, 128, _ptr(wav), _ptr(pcm), _ptr(d_ooffs), max(Ts), _stream())
+        maskcat = torch.cat([masks[u][s].contiguous().view(-1) for u in range(nutt) for s in range(S)])
+    wav, pcm, ooffs = mask_istft_flat(mixcat, maskcat, Ts, S, want_pcm, want_float)
 
     def split(buf):
         if buf is None:

@@ -18,6 +18,8 @@ class ClipAdam:
         self.step_count = 0
         self._bound = None
         self.m = self.v = self.scal = None
+        self._seen_host = self._seen_ev = None      # skipped_nowait(): last skipped-step count copied to the host
+        self._seen = 0
 
     def _state(self):
         p, g = self.model.flat_parameters()
@@ -39,7 +41,23 @@ class ClipAdam:
         ops.clip_adam(p, g, self.m, self.v, self.scal, self.lr, self.betas[0], self.betas[1], self.eps, self.step_count)
         if eng is not None:
             eng.version += 1            # bf16 operand copies of the weights made before this update are stale now
+        # the skipped-step counter also travels to a pinned host word behind every step (4 bytes, asynchronous): a driver
+        # can notice a skipped step one step later without ever synchronising (skipped_nowait)
+        if self._seen_ev is None or self._seen_ev.query():
+            if self._seen_ev is not None:
+                self._seen = int(self._seen_host[0])
+            if self._seen_host is None:
+                self._seen_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+            self._seen_host.copy_(self.scal[3:4], non_blocking=True)
+            self._seen_ev = torch.cuda.Event()
+            self._seen_ev.record()
         return self.scal
+
+    def skipped_nowait(self):
+        """The skipped-step count as of the last step whose 4-byte copy has landed (never blocks, may lag a step or two)."""
+        if self._seen_ev is not None and self._seen_ev.query():
+            self._seen = int(self._seen_host[0])
+        return self._seen
 
     def skipped(self):
         """Number of optimizer steps skipped so far because their gradients were flagged (synchronises)."""
@@ -62,5 +80,6 @@ class ClipAdam:
         self._state()
         self.step_count = int(sd["step"])
         self.scal.zero_()
+        self._seen, self._seen_ev = 0, None
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])

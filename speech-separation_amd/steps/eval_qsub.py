@@ -41,6 +41,7 @@ def get_args(argv=None):
   parser.add_argument("--batch-size", type=int, help="Batch size", default=100)
   parser.add_argument("--seed", type=int, default=None, help="seed for the random h0/c0 (archs/uPIT.py:121-127)")
   parser.add_argument("--writers", type=int, default=4, help="threads compressing and writing the npz files")
+  parser.add_argument("--num-workers", type=int, default=4, help="loader processes inflating the test features")
   return parser.parse_args(argv)
 
 
@@ -81,6 +82,8 @@ def main(argv=None):
   rank, world, local = skdist.init_from_env()
   gpu = local if world > 1 else args.gpu_id
   torch.cuda.set_device(gpu)
+  from sepkern.data import host_threads
+  host_threads()
   m = load_arch(args.arch_file)
   if rank == 0:
     print("mask generation with", args.arch_file, "on", world, "GPU(s)")
@@ -90,12 +93,16 @@ def main(argv=None):
   os.makedirs(args.dirout, exist_ok=True)
   model = restore_model(m, args, gpu)
   pending = []
+  import time
+  t_start, n_frames = time.perf_counter(), 0
   if len(mine):
-    batches = DataLoader(mine, batch_size=min(args.batch_size, len(mine)), shuffle=False, collate_fn=dataset.collator)
+    batches = DataLoader(mine, batch_size=min(args.batch_size, len(mine)), shuffle=False, collate_fn=dataset.collator,
+                         num_workers=max(0, args.num_workers))
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, args.writers)) as pool, torch.no_grad():
       for batch in batches:
         if hasattr(m, "estimate_masks"):
           for name, arrays in m.estimate_masks(model, batch):
+            n_frames += next(iter(arrays.values())).shape[1]
             pending.append(pool.submit(write_masks, args.dirout, name, arrays))
         else:                                   # an arch module that only implements the reference protocol
           m.compute_masks(model, batch, args.dirout)
@@ -106,6 +113,8 @@ def main(argv=None):
     torch.distributed.destroy_process_group()
   if rank == 0:
     print("wrote masks for", len(dataset), "utterances to", args.dirout)
+    dt = time.perf_counter() - t_start
+    print("eval_qsub: %d frames (this rank) in %.2f s = %.0f frames/s" % (n_frames, dt, n_frames / max(dt, 1e-9)), file=sys.stderr)
 
 
 if __name__ == '__main__':

@@ -16,11 +16,17 @@ What is organised differently here, on the host side only:
     the cross-validation set is sharded too, rank 0 writes the files;
   * checkpoints also carry the optimizer state (NNN.opt), which the reference loses on resume (:107);
   * a recurrence launch that timed out never reaches the weights (the fused optimizer skips that step on the
-    device) and is reported when the epoch ends.
+    device) and is reported when the epoch ends;
+  * batches are staged on the GPU AHEAD of the step that consumes them (sepkern.data.Prefetcher: loader workers inflate
+    and pack in parallel, a thread copies through pinned memory on its own stream, --prefetch batches deep): the
+    reference inflates, packs and copies each batch synchronously in front of its step (:113-117), which at 36 ms per
+    step is the bound.  --prefetch 0 --num-workers 1 is the reference's loop.  Every epoch's wall time and frames/s go
+    to stderr.
 """
 import argparse
 import os
 import sys
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.abspath(os.path.join(HERE, ".."))
@@ -50,7 +56,11 @@ def get_args(argv=None):
   parser.add_argument("--learning-rate", type=float, help="Learning rate", default=0.001)
   parser.add_argument("--torch-optimizer", action="store_true",
                       help="use torch clip_grad_norm_ + optim.Adam instead of the fused kernel")
-  parser.add_argument("--num-workers", type=int, default=1)
+  parser.add_argument("--num-workers", type=int, default=None,
+                      help="loader processes (default: 8 for npz features -- zlib inflate of ~1 MB per utterance is the "
+                           "loader's cost --, 2 with --wav-input; capped by the CPUs this process may use)")
+  parser.add_argument("--prefetch", type=int, default=2,
+                      help="batches staged on the GPU ahead of the step (pinned memory, own copy stream); 0: off")
   parser.add_argument("--wav-input", action="store_true",
                       help="read <data-dir>/wav.scp and compute the STFT features on the GPU inside the step "
                            "(arch must provide WavTrainSet) instead of loading feats_train.scp npz files")
@@ -127,16 +137,37 @@ def training_batches(m, args, rank, world):
   from sepkern import dist as skdist
   dataset = m.WavTrainSet(args.data_dir) if args.wav_input else m.TrainSet(args.data_dir, args.train_copy_location)
   seed = args.seed if args.seed is not None else 0
-  if world == 1:
-    gen = None
-    if args.seed is not None:
-      gen = torch.Generator()                    # re-seeded per epoch by reseed_epoch(): a resumed run shuffles alike
-      gen.manual_seed(seed)
-    return DataLoader(dataset, batch_size=args.batch_size, shuffle=True, collate_fn=dataset.collator,
-                      num_workers=args.num_workers, generator=gen), gen
-  counts = dataset.frame_counts() if hasattr(dataset, "frame_counts") else None
+  workers = loader_workers(args, world)
+  extra = dict(persistent_workers=True, prefetch_factor=2) if workers > 0 else {}      # workers live across epochs
+  if world == 1 and args.seed is None:           # the reference's shuffled loader, order from the global RNG
+    loader = DataLoader(dataset, batch_size=args.batch_size, shuffle=True, collate_fn=dataset.collator,
+                        num_workers=workers, **extra)
+    return staged(loader, args), None
+  # with --seed (or several ranks) the order of an epoch is a function of (seed, epoch) alone -- EpochShards, whatever the
+  # loader draws from its generator for itself (a persistent-worker loader draws a base seed on its first epoch only), so
+  # that `--start-epoch N` continues exactly where an uninterrupted run would be
+  counts = dataset.frame_counts() if (world > 1 and hasattr(dataset, "frame_counts")) else None
   shards = skdist.EpochShards(len(dataset), args.batch_size, rank, world, lengths=counts, seed=seed)
-  return DataLoader(dataset, batch_sampler=shards, collate_fn=dataset.collator, num_workers=args.num_workers), shards
+  loader = DataLoader(dataset, batch_sampler=shards, collate_fn=dataset.collator, num_workers=workers, **extra)
+  return staged(loader, args), shards
+
+
+def loader_workers(args, world):
+  if args.num_workers is not None:
+    return max(0, args.num_workers)
+  try:
+    cpus = len(os.sched_getaffinity(0))
+  except AttributeError:
+    cpus = os.cpu_count() or 1
+  return max(1, min(2 if args.wav_input else 8, cpus // max(1, world) - 2))
+
+
+def staged(loader, args):
+  """The loader's batches staged on the GPU ahead of their step (--prefetch N > 0), or the loader as it is."""
+  if args.prefetch <= 0:
+    return loader
+  from sepkern.data import Prefetcher
+  return Prefetcher(loader, torch.device("cuda", torch.cuda.current_device()), depth=args.prefetch)
 
 
 def validation_batches(m, args, rank, world):
@@ -197,6 +228,10 @@ def resume(model, optimizer, run, args):
 POLL_EVERY = 50      # steps between two reads of the optimizer's skipped-step counter (one small host sync each)
 
 
+def rank_of():
+  return torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+
+
 def recover_from_timeout(model, optimizer, newly_skipped, epoch):
   """A persistent recurrence launch timed out (its bounded wait gave up: the grid was not co-resident).  The device
   already kept that step away from the weights on EVERY rank (the guard word is all-reduced with the gradients, so the
@@ -240,8 +275,11 @@ def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
     acc.add_(win)
     win = torch.zeros_like(win)
 
+  t_epoch = time.perf_counter()
+  frames = torch.zeros(1, device=dev, dtype=torch.float64)
   for i, batch in enumerate(batches):
     loss, norm = m.compute_loss(model, epoch, batch)
+    frames += norm.double() / world
     win[0] += loss.detach().double() * norm.double()
     # under data parallelism `norm` is already the global frame count: every rank adds its 1/world share
     win[1] += norm.double() / world
@@ -256,11 +294,21 @@ def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
         continue
       torch.nn.utils.clip_grad_norm_(model.parameters(), CLIP_NORM)
     optimizer.step()
-    if (i + 1) % POLL_EVERY == 0:
+    # (the counter's asynchronous host copy, one step behind: after a timed-out launch the run switches to per-step
+    # launches within a step or two instead of skipping every step up to the next poll)
+    if (i + 1) % POLL_EVERY == 0 or (fused and optimizer.skipped_nowait() > seen):
       close_window()
   close_window()
   if world > 1:
     torch.distributed.all_reduce(acc)
+    torch.distributed.all_reduce(frames)
+  # wall time and frames/s of the epoch as the user sees it (data loading included): stderr, the reference's stdout
+  # lines stay as they are.  norm = frames x feat_dim (archs/uPIT.py:197).  (One host sync per epoch, here.)
+  n_frames = float(frames.item()) / float(getattr(model, "feat_dim", 257))
+  dt = time.perf_counter() - t_epoch
+  if rank_of() == 0:
+    print("train: epoch %d: %d steps, %.0f frames in %.2f s = %.0f frames/s" % (epoch + 1, i + 1, n_frames, dt, n_frames / dt),
+          file=sys.stderr, flush=True)
   return acc
 
 
@@ -341,6 +389,8 @@ def main(argv=None):
     print("Using GPU", gpu, "of", world)
   m = __import__(args.arch_file)
   torch.cuda.set_device(gpu)
+  from sepkern.data import host_threads
+  host_threads()                                 # (the arithmetic is on the GPU; see sepkern.data.host_threads)
 
   run = RunDir(args.dirout, chief)
   train_batches, shards = training_batches(m, args, rank, world)

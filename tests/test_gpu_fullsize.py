@@ -47,41 +47,61 @@ def _batch(S, seed):
     return samples
 
 
-def _run_pair(S, dtype, oracle_mod, seed):
+def _run_pair(S, dtype, oracle_mod, seed, handoffs=(None,)):
+    """One training step of the HIP path per entry of `handoffs` (None: the engine's default forward-recurrence hand-off;
+    else a SEPKERN_LSTM_FWD value) and ONE of the oracle (a minute of host time): a list of result dicts."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need an MI355X")
     import uPIT
-    torch.set_num_threads(_threads())
-    torch.manual_seed(seed)
-    model = uPIT.SepDNN(0, num_spk=str(S), hidden_dim=str(H), num_layers=str(L), dtype=dtype)
-    model.cuda()
-    model.train()
-    orc = OU.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
-    orc.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
-    orc.train()
-    samples = _batch(S, seed)
-    h0, c0 = torch.randn(2 * L, B, H), torch.randn(2 * L, B, H)
-    # HIP path first (so a kernel fault is not hidden behind a minute of oracle time)
-    batch = uPIT.Collator("mix")(samples)
-    model.next_hidden = (h0.cuda(), c0.cuda())
-    loss, norm = uPIT.compute_loss(model, 0, batch)
-    loss.backward()
-    best = model.last_best_perm.cpu().numpy()
-    grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
-    model.next_hidden = (h0.cuda(), c0.cuda())
-    model.hidden = model.init_hidden(B)
-    with torch.no_grad():
-        mask = model(batch["mix"]).cpu().numpy()                  # train-mode BN: batch statistics, as in the step
-    torch.cuda.synchronize()
     from sepkern import ops
-    ops.lstm_status(ops.lstm_ws(T, B, H))
+    torch.set_num_threads(_threads())
+    samples = _batch(S, seed)
+    batch = uPIT.Collator("mix")(samples)
+    runs, state = [], None
+    for spec in handoffs:
+        old = os.environ.get("SEPKERN_LSTM_FWD")
+        if spec is not None:
+            os.environ["SEPKERN_LSTM_FWD"] = spec                 # read when the engine is built (first use of the model)
+        try:
+            torch.manual_seed(seed)
+            model = uPIT.SepDNN(0, num_spk=str(S), hidden_dim=str(H), num_layers=str(L), dtype=dtype)
+            model.cuda()
+            model.train()
+            if state is None:
+                state = {k: v.cpu() for k, v in model.state_dict().items()}
+                h0, c0 = torch.randn(2 * L, B, H), torch.randn(2 * L, B, H)
+            # HIP path first (so a kernel fault is not hidden behind a minute of oracle time)
+            model.next_hidden = (h0.cuda(), c0.cuda())
+            loss, norm = uPIT.compute_loss(model, 0, batch)
+        finally:
+            if spec is not None:
+                if old is None:
+                    del os.environ["SEPKERN_LSTM_FWD"]
+                else:
+                    os.environ["SEPKERN_LSTM_FWD"] = old
+        loss.backward()
+        best = model.last_best_perm.cpu().numpy()
+        grads = {k: p.grad.detach().cpu().double() for k, p in model.named_parameters()}
+        model.next_hidden = (h0.cuda(), c0.cuda())
+        model.hidden = model.init_hidden(B)
+        with torch.no_grad():
+            mask = model(batch["mix"]).cpu().numpy()              # train-mode BN: batch statistics, as in the step
+        torch.cuda.synchronize()
+        ops.lstm_status(ops.lstm_ws(T, B, H))
+        runs.append(dict(loss=float(loss), norm=float(norm), best=best, grads=grads, mask=mask,
+                         tagged=bool(model._engine.tagged_fwd)))
+        del model
     # oracle
+    orc = OU.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
+    orc.load_state_dict(state)
+    orc.train()
     lo, no, aux = oracle_mod.compute_loss(orc, OU.collate(samples), (h0, c0))
     lo.backward()
     og = {k: p.grad.detach().double() for k, p in orc.named_parameters()}
-    return dict(loss=float(loss), norm=float(norm), best=best, grads=grads, mask=mask, lo=float(lo.detach()),
-                no=float(no), obest=aux["indices"].numpy(), og=og, omask=aux["mask_out"].detach().numpy(),
-                losses=aux["losses"].detach().numpy())
+    for r in runs:
+        r.update(lo=float(lo.detach()), no=float(no), obest=aux["indices"].numpy(), og=og, omask=aux["mask_out"].detach().numpy(),
+                 losses=aux["losses"].detach().numpy())
+    return runs
 
 
 def _same_perms(r):
@@ -93,8 +113,17 @@ def _same_perms(r):
 
 
 def test_fp32_step_32x400_matches_oracle():
-    """configs[1]: masks <= 1e-4 relative, loss 1e-5, same permutations, every parameter gradient <= 2e-4 rel-L2."""
-    r = _run_pair(2, "fp32", OU, 21)
+    """configs[1]: masks <= 1e-4 relative, loss 1e-5, same permutations, every parameter gradient <= 2e-4 rel-L2 -- with the
+    forward recurrence's shipped hand-off ("the data is the flag": the operand h carries a 2-bit epoch, <= 3 ulp) AND with
+    the exact one (flags), both against the same oracle step."""
+    tagged, exact = _run_pair(2, "fp32", OU, 21, handoffs=(None, "0,1,1,0,0,0,0"))
+    assert tagged["tagged"] and not exact["tagged"]
+    for r in (tagged, exact):
+        _check_fp32(r)
+    assert tagged["loss"] != exact["loss"] or not np.array_equal(tagged["mask"], exact["mask"])   # (they ARE two arithmetics)
+
+
+def _check_fp32(r):
     assert r["norm"] == r["no"]
     np.testing.assert_allclose(r["loss"], r["lo"], rtol=1e-5)
     _same_perms(r)
@@ -118,7 +147,7 @@ def test_bf16_3spk_step_32x400_matches_bf16_oracle():
     term), so the gates are the bf16 ones (~1e-2 absolute on masks): masks 5e-3 absolute, loss 5e-4
     relative, gradients 1e-2 relative L2, same permutations."""
     from oracle import upit_bf16 as OB
-    r = _run_pair(3, "bf16", OB, 22)
+    (r,) = _run_pair(3, "bf16", OB, 22)
     assert r["norm"] == r["no"]
     np.testing.assert_allclose(r["loss"], r["lo"], rtol=5e-4)
     _same_perms(r)

@@ -387,11 +387,15 @@ def test_timed_out_recurrence_never_reaches_the_weights(arch):
     assert opt.skipped() == 0
     before = model.flat_parameters()[0].clone()
     m_before = opt.m.clone()
+    rm_before, rv_before = model.bn.running_mean.clone(), model.bn.running_var.clone()
+    assert float(rm_before.abs().sum()) > 0           # (the clean step did update them)
     ws = ops.lstm_ws(T, B, H)
     ops.lstm_sticky(ws).fill_(1)                      # what an aborting workgroup does (csrc/lstm.hip, wait_flags)
     scal = one_step()
     assert float(scal[2]) == 1.0 and opt.skipped() == 1
     assert torch.equal(model.flat_parameters()[0], before) and torch.equal(opt.m, m_before)
+    # ... nor the BatchNorm running statistics a checkpoint would hold (the forward of such a step is garbage too)
+    assert torch.equal(model.bn.running_mean, rm_before) and torch.equal(model.bn.running_var, rv_before)
     with pytest.raises(SepkernError):
         opt.check()
     with pytest.raises(SepkernError):
@@ -403,10 +407,10 @@ def test_timed_out_recurrence_never_reaches_the_weights(arch):
 
 
 def test_training_driver_recovers_in_process_from_a_timed_out_launch(arch, capsys):
-    """steps/train_qsub.py::train_epoch polls the fused optimizer's skipped-step counter every POLL_EVERY steps: after a
-    timed-out persistent launch (simulated: the sticky word set) it clears the word, drops the loss terms of that window,
-    switches the engine to one launch per step IN THIS PROCESS and goes on training -- instead of skipping every later
-    step of the epoch and dying at its end."""
+    """steps/train_qsub.py::train_epoch watches the fused optimizer's skipped-step counter (its asynchronous host copy
+    after every step, a synchronous read every POLL_EVERY steps): after a timed-out persistent launch (simulated: the sticky
+    word set) it clears the word, drops the loss terms of that window, switches the engine to one launch per step IN THIS
+    PROCESS and goes on training -- instead of skipping every later step of the epoch and dying at its end."""
     import importlib
     from sepkern import ops
     from sepkern.optim import ClipAdam
@@ -434,10 +438,11 @@ def test_training_driver_recovers_in_process_from_a_timed_out_launch(arch, capsy
         acc = tq.train_epoch(arch, model, opt, [batch] * 6, 1, 1, False)
     finally:
         tq.POLL_EVERY = old
-    assert opt.skipped() == 2                                   # the first window of two steps; none after the recovery
+    assert 1 <= opt.skipped() <= 2                              # noticed a step or two later; none after the recovery
     assert model._engine.lstm_mode == 2
     assert "continuing with one launch per step" in capsys.readouterr().err
-    assert not torch.equal(model.flat_parameters()[0], before)  # the four later steps were applied
+    assert not torch.equal(model.flat_parameters()[0], before)  # the later steps were applied
+    assert bool(torch.isfinite(model.bn.running_var).all()) and bool(torch.isfinite(model.bn.running_mean).all())
     value = float(acc[0] / acc[1])
     assert np.isfinite(value) and 0 < value < 2 * clean
     tq.report_failures(model, opt, 1)                           # nothing left to report

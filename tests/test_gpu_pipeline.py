@@ -236,6 +236,22 @@ def test_bench_launches_its_own_ranks_when_no_launcher_did():
     d2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
     assert d2["distributed"]["grad_allreduce"] == "chunked-overlapped"
     assert d2["config"]["mean_loss"] == d["config"]["mean_loss"]
+    assert d2["distributed"]["lstm_per_step_launches_by_rank"] == [1, 1]
+    # ... and beside a PERSISTENT recurrence: rank 0 keeps its one-launch grid (mode 0), rank 1 launches per step, the chunks
+    # of the gradient go out on the communication stream while rank 0's persistent backward kernels run (GradReducer's
+    # stream / event ordering next to a persistent grid; on a node every rank is persistent and the backend is RCCL).
+    # `distinct_devices` is a CHECKED field: 1 here (both ranks on cuda:0), == world_size on a real node.
+    r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--hidden", "64",
+                         "--layers", "2", "--batch", "4", "--frames", "40"], cwd=root,
+                        env=dict({k: v for k, v in env.items() if k != "SEPKERN_LSTM_MODE"}, SEPKERN_DP_OVERLAP="1",
+                                 SEPKERN_LSTM_MODE_BY_RANK="0,2"), capture_output=True, text=True, timeout=400)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    d3 = json.loads([l for l in r3.stdout.splitlines() if l.startswith("{")][0])
+    dd3 = d3["distributed"]
+    assert dd3["grad_allreduce"] == "chunked-overlapped" and dd3["world_size"] == 2 and dd3["distinct_devices"] == 1 < dd3["world_size"]
+    assert dd3["lstm_per_step_launches_by_rank"] in ([0, 1], [1, 1])      # ([1, 1]: rank 0's grid timed out beside rank 1 and fell back)
+    assert (dd3["lstm_per_step_launches_by_rank"] == [0, 1]) == ("lstm_fallback" not in d3)
+    assert abs(d3["config"]["mean_loss"] - d["config"]["mean_loss"]) <= 1e-5 * d["config"]["mean_loss"]
     # a rank that fails takes the job down with a non-zero code instead of leaving the others in a collective
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--hidden", "63"],
                          cwd=root, env=env, capture_output=True, text=True, timeout=400)
@@ -269,3 +285,92 @@ def test_bench_line_carries_the_contract_fields():
     assert ms == sorted(ms, reverse=True)                          # largest share of the step first
     for k in ("lstm_fwd_kernel", "lstm_bwd_kernel"):
         assert by[k]["us_per_time_step"] > by[k]["mfma_floor_us"] > 0 and by[k]["handoff_us"] > 0
+
+
+def test_staged_batches_equal_the_plain_loader_and_keep_up_with_the_step(tmp_path):
+    """steps/train_qsub.py's loop through sepkern.data.Prefetcher (batches staged on the GPU ahead of their step, as packed
+    rows) -- VERDICT r03 item 2:
+      * numerics: a staged batch gives the same loss and gradients as the same batch handed over by the plain loader
+        (npz path: bit for bit -- the same PackedSequence.data, copied by another route; wav path: the same STFT kernel);
+      * rate: an epoch of train_epoch THROUGH the loader + staging runs at >= 0.6 of the rate of the same steps on batches
+        that are already resident on the GPU (on this 20-step corpus the epoch's start-up -- one loader batch being built
+        from scratch -- is a visible share; on 2 000 utterances the factor is 0.91, profiles/r04_stage_walls.txt)."""
+    sys.path.insert(0, os.path.join(PKG, "archs"))
+    sys.path.insert(0, STEPS)
+    import importlib
+    import uPIT
+    from torch.utils.data import DataLoader
+    from sepkern import synth
+    from sepkern.data import Prefetcher, host_threads
+    from sepkern.optim import ClipAdam
+    tq = importlib.import_module("train_qsub")
+    host_threads()
+    root = str(tmp_path)
+    wavroot, data = os.path.join(root, "wav8k"), os.path.join(root, "data", "syn")
+    ids = synth.write_wav_tree(wavroot, 320, num_spk=2, min_s=1.0, max_s=3.0)
+    synth.write_data_dir(data, wavroot, ids)
+    run(os.path.join(STEPS, "extract_feats.py"), data, "train", os.path.join(root, "feats"))
+    torch.manual_seed(9)
+    model = uPIT.SepDNN(0, hidden_dim="600", num_layers="2")           # the reference's own size (archs/uPIT.py:115)
+    model.cuda()
+    model.train()
+    dev = torch.device("cuda", 0)
+    # ---- numerics
+    for ds in (uPIT.TrainSet(data), uPIT.WavTrainSet(data)):
+        batch = ds.collator([ds[i] for i in range(7)])
+        staged = Prefetcher.stage(batch, dev)
+        assert set(staged) >= {"packed"} and staged["packed"][2].B == 7
+        h = (torch.randn(4, 7, 600).cuda(), torch.randn(4, 7, 600).cuda())
+        got = []
+        for b in (batch, staged):
+            model.next_hidden = h
+            loss, norm = uPIT.compute_loss(model, 0, b)
+            loss.backward()
+            got.append((float(loss), float(norm), model.flat_parameters()[1].clone()))
+        assert got[0][:2] == got[1][:2] and torch.equal(got[0][2], got[1][2])
+    # ---- rate
+    opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
+    ds = uPIT.TrainSet(data)
+    loader = DataLoader(ds, batch_size=16, shuffle=True, collate_fn=ds.collator, num_workers=6, persistent_workers=True,
+                        prefetch_factor=2)
+    pf = Prefetcher(loader, dev, depth=2)
+    resident = list(pf)
+    assert len(resident) == 20 and sum(b["packed"][2].B for b in resident) == 320
+
+    def epoch(batches):
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        acc = tq.train_epoch(uPIT, model, opt, batches, 0, 1, False)
+        value = float(acc[0] / acc[1])
+        assert np.isfinite(value) and float(acc[1]) == sum(b["packed"][2].R for b in resident) * 257
+        return time.perf_counter() - t0
+    epoch(resident)                                                    # warm-up (allocator, workspaces)
+    t_res = min(epoch(resident) for _ in range(2))
+    epoch(pf)
+    t_pf = min(epoch(pf) for _ in range(2))
+    assert opt.skipped() == 0
+    assert t_res / t_pf >= 0.6, "epoch through the loader %.3f s, on resident batches %.3f s" % (t_pf, t_res)
+
+
+def test_bench_ragged_line_and_numerics_field():
+    """`bench.py --ragged` (SURVEY.md 8d's variable-length set: U(24k, 64k) samples, a different batch every step, packed
+    rows): frames_per_step counts the valid frames only, the workload string says so, and config.numerics names the forward
+    recurrence's hand-off (tagged by default, exact with SEPKERN_LSTM_FWD=0,1,1,0,0,0,0) -- VERDICT r03 items 1 and 3."""
+    import json
+    root = os.path.dirname(PKG)
+    out = {}
+    for tag, env in (("tagged", {}), ("exact", {"SEPKERN_LSTM_FWD": "0,1,1,0,0,0,0"})):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--hidden", "320", "--layers", "2",
+                            "--batch", "32", "--ragged", "--no-cpu-baseline"], cwd=root, env=dict(os.environ, **env),
+                           capture_output=True, text=True, timeout=400)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    d = out["tagged"]
+    assert "U(24000, 64000)" in d["config"]["workload"] and "packed rows" in d["config"]["workload"]
+    assert 32 * 188 <= d["config"]["frames_per_step"] <= 32 * 501
+    assert abs(d["value"] - d["config"]["frames_per_step"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert "tagged" in d["config"]["numerics"] and "3 ulp" in d["config"]["numerics"]
+    assert "exact hand-off" in out["exact"]["config"]["numerics"] and "tagged" not in out["exact"]["config"]["numerics"].split(";")[0]
+    # same seeds, same batches: the two hand-offs agree on the loss to fp32 rounding
+    assert abs(out["exact"]["config"]["mean_loss"] - d["config"]["mean_loss"]) <= 2e-5 * d["config"]["mean_loss"]
