@@ -189,11 +189,16 @@ int sk_hprev_rows(const float* y, int ldy, const float* h0, const int32_t* offs,
  * inputs (this one IS arithmetic: BASELINE configs[3]); bit 17 8-unit / 256-thread workgroups, two per CU; bits 18..19
  * block id -> stream map; bit 20 one polling wave per workgroup; bit 21 flags replicated per XCD; bit 22 one flag per
  * 128-byte line; bits 23..27 hold-back of a step's first poll in units of 0.1 us (0 = the library's choice, 31 = none);
- * bit 29 (fp32 forward): "the data is the flag" -- every exchanged h word carries the step's epoch in its two low mantissa
- * bits, producers publish without drain / barrier / flag, consumers hold back, pull, check every word and pull again
- * what was not complete; the next step's product runs on the tagged words (<= 3 ulp = 3.6e-7 relative), everything stored
- * (y, gates, cs, states) is exact.  The engine ships it for the fp32 forward recurrence and says so in bench.py's line
- * (config.numerics); SEPKERN_LSTM_FWD=0,1,1,0,0,8,0,0 selects the exact hand-off. */
+ * bit 28 (fp32 forward, 8-wave workgroups, H <= 896): the product h W_hh^T by the EXACT three-way bf16 split of both fp32
+ * operands on the bf16 matrix pipe -- x = hi + mid + lo with three bf16 pieces (24 significand bits = 3 x 8), nine exact piece
+ * products per element pair added into fp32 accumulators by v_mfma_f32_16x16x32_bf16: an fp32 product in another summation
+ * order (results within 2e-6 of the fp32-MFMA kernel's, no operand perturbed), 144 instead of 256 matrix-pipe cycles per 32 k.
+ * W_hh is split once per launch, h by its producer (three bf16 images, flags hand-off).  The engine ships it for the fp32
+ * forward recurrence (35.6 vs 36.6 ms per training step at 3 x 896; bench.py's config.numerics names it);
+ * bit 29 (fp32 forward; not together with bit 28): "the data is the flag" -- every exchanged h word carries the step's epoch
+ * in its two low mantissa bits, producers publish without drain / barrier / flag, consumers hold back, pull, check every word
+ * and pull again what was not complete; the next step's product runs on the tagged words (<= 3 ulp = 3.6e-7 relative),
+ * everything stored (y, gates, cs, states) is exact.  The r03 default; still the engine's choice for H > 896. */
 size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 const int32_t* offs, float* y, float* gates, float* cs, float* hn, float* cn, void* ws,

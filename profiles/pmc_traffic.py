@@ -14,9 +14,9 @@ import json
 import os
 import sys
 
-KEYS = ("gemm_f32_kernel", "gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "cast_t_kernel", "lstm_fwd_kernel",
+KEYS = ("gemm_f32_kernel", "gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "hprev_rows_kernel", "lstm_fwd_kernel",
         "lstm_bwd_kernel", "clip_adam", "pit_pair", "pit_bwd", "bn_apply", "bn_bwd", "splitk_reduce", "colred", "sumsq")
-BF16_ONLY = ("gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "cast_t_kernel")
+BF16_ONLY = ("gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel")
 
 
 def kernel_source_id(root):

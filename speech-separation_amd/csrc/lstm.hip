@@ -51,6 +51,41 @@ __device__ __forceinline__ bf16x8 pack8(const float4& a, const float4& b) {
 // element offset (bf16 units) of k, row b in the bf16 image
 __device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((((k >> 3) & 3) * 16 + b) << 3) + (k & 7); }
 
+// S3 variant of the forward kernel (mode bit 28): the fp32 product h W_hh^T on the bf16 matrix pipe by an EXACT three-way
+// split.  An fp32 value x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits = 3 x 8: hi = the top
+// 8 by truncation; x - hi is exact and has <= 16 significant bits; again for mid; what is left IS a bf16).  w h is the sum
+// of the nine piece products, each exact in fp32 (8 x 8 bits), added into fp32 accumulators by nine
+// v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each): an fp32
+// product in another summation order, 144 instead of 256 matrix-pipe cycles per 32 k.  W_hh is split once per launch (three
+// register pieces: 168 instead of 112 VGPRs), h by its producer before it publishes (three bf16 images: 6 instead of 4
+// bytes per cell).  Same arithmetic as gemm.hip's gemm_f32_kernel_split3.
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const unsigned xu = __builtin_bit_cast(unsigned, x);
+  const float r = x - __builtin_bit_cast(float, xu & 0xffff0000u);  // exact
+  const unsigned ru = __builtin_bit_cast(unsigned, r);
+  const float q = r - __builtin_bit_cast(float, ru & 0xffff0000u);  // exact, <= 8 significant bits
+  hi = xu >> 16;
+  mid = ru >> 16;
+  lo = __builtin_bit_cast(unsigned, q) >> 16;
+}
+// 8 consecutive-k fp32 values -> the three bf16x8 piece vectors
+__device__ __forceinline__ void split3x8(const float4& a, const float4& b, bf16x8& hi, bf16x8& mid, bf16x8& lo) {
+  const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  u32x4 H, M, L;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split3(v[2 * j], h0, m0, l0);
+    split3(v[2 * j + 1], h1, m1, l1);
+    H[j] = h0 | (h1 << 16);
+    M[j] = m0 | (m1 << 16);
+    L[j] = l0 | (l1 << 16);
+  }
+  hi = __builtin_bit_cast(bf16x8, H);
+  mid = __builtin_bit_cast(bf16x8, M);
+  lo = __builtin_bit_cast(bf16x8, L);
+}
+
 constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 // Poll cadence (units of 64 clocks, s_sleep): a poll is a write-through-coherent load that competes with the CU's own
 // publish traffic and with everybody's flag lines; diagnostic builds vary it (make -C csrc variant NAME=.. DEFS=..)
@@ -324,16 +359,21 @@ __device__ __forceinline__ void decode_block(int L, int NUG, int nby, int map, i
 // NW = waves per workgroup.  8: 16 hidden units per workgroup (4 gate-row tiles x 2 K halves), one workgroup per CU.
 // 4: 8 units per workgroup (2 tiles x 2 K halves), TWO workgroups per CU that belong to different streams: while one
 // waits for its hand-off the other has the matrix pipe, so a step costs the chain plus HALF the MFMA time.
-template <int KS, bool BF, int NW>
+template <int KS, bool BF, int NW, bool S3 = false>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
+  static_assert(!(BF && S3) && (!S3 || NW == 8), "S3 is an fp32 variant of the 8-wave kernel");
+  constexpr bool B16 = BF || S3;          // the exchanged operand travels as bf16 image(s)
   constexpr int HP = 16 * KS;
   constexpr int MT = NW / 2;              // gate-row tiles (4 units each) per workgroup
   constexpr int NT = NW * 64;
   constexpr int NUG = HP / (4 * MT);      // unit groups = workgroups per (direction, batch-group block)
-  constexpr int NCH = BF ? HP / 32 : KS;  // 1 KB chunks of the h image (16 k each in fp32, 32 k in bf16)
+  constexpr int NCH = B16 ? HP / 32 : KS; // 1 KB chunks of ONE h image (16 k each in fp32, 32 k in bf16)
   constexpr int NQ = NCH / 2;             // chunks per wave (one K half)
+  constexpr int NP = S3 ? 3 : 1;          // bf16 piece images (S3: hi, mid, lo)
+  constexpr int PIECE = 256 * NCH;        // floats per bf16 piece image (NCH KB)
+  constexpr int NPC = NP * NCH;           // 1 KB pieces a workgroup pulls per step
   static_assert(NCH % 2 == 0, "image chunks must split into two K halves");
-  __shared__ __attribute__((aligned(16))) float hs[16 * HP];  // B-operand image of h_{s-1}: [k/4][16 rows][4]
+  __shared__ __attribute__((aligned(16))) float hs[S3 ? 3 * PIECE : 16 * HP];  // B-operand image(s) of h_{s-1}
   __shared__ __attribute__((aligned(16))) float red[MT][64][4];
   __shared__ float st_c[GMAX][64 * MT], st_h[GMAX][64 * MT];  // per-group cell state of the owner lanes
   __shared__ long long st_tpub[GMAX];                         // wave 0: when this workgroup raised the group's flag
@@ -348,8 +388,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   // ---- W_hh slice -> registers.  MFMA A operand: lane l supplies A[i = l&15][k = l>>4];
   //      row i = 4*unit_local + gate; k of (chunk q, r) = 16 (kh*NQ + q) + 4 (l>>4) + r.
   //      bf16: lane l supplies A[i = l&15][k = 32 chunk + 8 (l>>4) + 0..7] as 8 bf16.
-  float wreg[BF ? 1 : 4 * NQ];
+  float wreg[B16 ? 1 : 4 * NQ];
   bf16x8 wb[BF ? NQ : 1];
+  bf16x8 w1[S3 ? NQ : 1], w2[S3 ? NQ : 1], w3[S3 ? NQ : 1];  // S3: the hi / mid / lo pieces of the slice
   {
     const int i = lane & 15, kq = lane >> 4;
     const int unit_i = ug * (4 * MT) + 4 * mt + (i >> 2), g_i = i & 3;
@@ -357,12 +398,15 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
     const float* wrow = a.whh + ((size_t)dir * 4 * H + (size_t)g_i * H + unit_i) * H;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      if (BF) {
+      if (B16) {
         const int k = 32 * (kh * NQ + q) + 8 * kq;
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
         if (rowok && k < H) v0 = *reinterpret_cast<const float4*>(wrow + k);
         if (rowok && k + 4 < H) v1 = *reinterpret_cast<const float4*>(wrow + k + 4);
-        wb[q] = pack8(v0, v1);
+        if (S3)
+          split3x8(v0, v1, w1[q], w2[q], w3[q]);
+        else
+          wb[q] = pack8(v0, v1);
       } else {
         const int k = 16 * (kh * NQ + q) + 4 * kq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -379,7 +423,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   const int unit = ug * (4 * MT) + 4 * mt + u_l;
   const bool owner = kh == 0;  // this wave carries cells
   const int oi = mt * 64 + lane;
-  const size_t xblk = (size_t)16 * HP;  // floats per (parity, dir, batch group) exchange block
+  const size_t xblk = S3 ? (size_t)3 * PIECE : (size_t)16 * HP;  // floats per (parity, dir, batch group) exchange block
   const int xoff = ((unit >> 2) * 16 + bl) * 4 + (unit & 3);  // fp32 image position of (k = unit, row = bl)
   const size_t hst = (size_t)2 * NBG * 16 * HP;           // second state array (bf16: exact h between step launches)
 
@@ -393,7 +437,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
           h = a.h0[((size_t)dir * B + b) * H + unit];
         } else {
           c = a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
-          if (BF || (a.opt & 8))
+          if (B16 || (a.opt & 8))
             h = a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
           else
             h = __hip_atomic_load(a.xbuf + ((size_t)(((a.s_begin - 1) & 1) * 2 + dir) * NBG + bg) * xblk + xoff, SK_RLX, SK_AGENT);
@@ -410,14 +454,14 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   const int fs = (a.opt & 4) ? FSPREAD : 1;  // option: every flag in a 128-byte line of its own (flag stores do not serialise on a line)
   bool aborted = false;
   long long t_self = 0;  // tagged hand-off: when this wave was done with the previous step
-  // first row of a time step: offs[t] (packed) or t * B (padded); the table entry of the NEXT step is fetched a step ahead
-  // (a scalar load at the top of a step would sit in front of the step's gx fetch: +0.15 us per step when it was there)
-  auto row_base = [&](int tt) { return a.offs ? a.offs[tt] : tt * B; };
-  int rb_next = row_base(dir ? T - 1 - a.s_begin : a.s_begin);
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
     const int t = dir ? T - 1 - s : s;
-    const int rb = rb_next;
-    if (s + 1 < a.s_end) rb_next = row_base(dir ? T - 2 - s : s + 1);
+    // First row of the time step: offs[t] (packed rows) or t * B (padded; callers pass offs = NULL for batches whose lengths
+    // are all equal, where the two layouts coincide).  One scalar load, used at once.  Fetching it a step ahead measured WORSE
+    // on one device in one call (profiles/r04_lstm_fwd_row_base_fetch_ab.txt: 6.05 us per step as here, 6.19 as a vector load
+    // -- its vmcnt wait at the next step's top also waits for this step's bulk stores --, 6.33 as a scalar load -- every LDS
+    // wait of the step becomes a wait for lgkmcnt(0)).
+    const int rb = a.offs ? a.offs[t] : t * B;
     for (int gi = 0; gi < G; ++gi) {
       const int bg = by * G + gi;
       if (bg >= NBG) break;
@@ -440,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       // barrier in between.  fp32: all 8 waves pull (56 pieces); bf16 (28 pieces, latency-bound): only the four
       // waves that own no cells, so nothing of the hand-off queues behind the owners' bulk stores (measured:
       // the split costs 2 % in fp32 and gains 1.5 % in bf16).
-      const bool tagged = !BF && (a.opt & 8);
+      const bool tagged = !B16 && (a.opt & 8);
       if (tagged && s > 0) {
         // option (mode bit 29, fp32): THE DATA IS THE FLAG.  Every exchanged word carries the step's epoch in its two low
         // mantissa bits ((s + 1) & 3 for h_s: 3 ulp at most, the product then runs on the tagged values), producers publish
@@ -499,7 +543,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         __syncthreads();
       }
       if (s == 0) {
-        if (BF) {
+        if (B16) {
           for (int i = tid; i < 16 * (HP / 8); i += NT) {
             const int bb = i & 15, c8 = i >> 4;  // row, k/8
             const int brow = bg * 16 + bb, k = 8 * c8;
@@ -507,7 +551,16 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
             const float* hp0 = a.h0 + ((size_t)dir * B + brow) * H + k;
             if (brow < B && k < H) v0 = *reinterpret_cast<const float4*>(hp0);
             if (brow < B && k + 4 < H) v1 = *reinterpret_cast<const float4*>(hp0 + 4);
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(hs) + bf_img(k, bb)) = pack8(v0, v1);
+            __bf16* img = reinterpret_cast<__bf16*>(hs) + bf_img(k, bb);
+            if (S3) {
+              bf16x8 p1, p2, p3;
+              split3x8(v0, v1, p1, p2, p3);
+              *reinterpret_cast<bf16x8*>(img) = p1;
+              *reinterpret_cast<bf16x8*>(img + 2 * PIECE) = p2;
+              *reinterpret_cast<bf16x8*>(img + 4 * PIECE) = p3;
+            } else {
+              *reinterpret_cast<bf16x8*>(img) = pack8(v0, v1);
+            }
           }
         } else {
           for (int i = tid; i < 16 * (HP / 4); i += NT) {
@@ -523,22 +576,22 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       } else if (!BF || !owner) {
         constexpr int PP = NUG / NCH;            // unit groups (flags) per 1 KB piece
         constexpr int NCW = BF ? NW / 2 : NW;    // consumer waves
-        static_assert(PP * ((NCH + NCW - 1) / NCW) <= 64, "one lane per polled flag");
+        static_assert(PP * ((NPC + NCW - 1) / NCW) <= 64, "one lane per polled flag");
         const int wq = BF ? w - NW / 2 : w;
         bool ok = true;
         if (s > a.s_begin) {
           if (a.opt & 1) {
             ok = !s_abort;  // wave 0 polled for the workgroup (above)
           } else {
-            const int piece = wq + NCW * (lane / PP);
-            const int idx = (lane < PP * ((NCH + NCW - 1) / NCW) && piece < NCH) ? piece * PP + lane % PP : -1;
+            const int piece = wq + NCW * (lane / PP);  // (S3: piece p of every image comes from the same unit groups)
+            const int idx = (lane < PP * ((NPC + NCW - 1) / NCW) && piece < NPC) ? (piece % NCH) * PP + lane % PP : -1;
             ok = wait_flags_sel(myflags, idx < 0 ? idx : idx * fs, (unsigned)s, a.ctrl, lane);
             if (!ok && lane == 0) s_abort = 1;
           }
         }
         if (ok) {
           const float* src = ((s - 1) & 1) ? xb1 : xb0;
-          for (int p = wq; p < NCH; p += NCW) dma_piece(src + p * 256, hs + p * 256, lane);
+          for (int p = wq; p < NPC; p += NCW) dma_piece(src + p * 256, hs + p * 256, lane);
           wait_vmcnt<0>();
         }
       }
@@ -554,7 +607,26 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         const float* hp = &hs[(kh * NQ) * 256 + lane * 4];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-          if (BF) {
+          if (S3) {
+            // nine exact piece products per 32 k, the small ones first; chunks alternate between two accumulators
+            const bf16x8 h1 = *reinterpret_cast<const bf16x8*>(hp + q * 256);
+            const bf16x8 h2 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + PIECE);
+            const bf16x8 h3 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + 2 * PIECE);
+            f32x4 ac = (q & 1) ? acc1 : acc0;
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h3, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h2, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h3, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h1, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h3, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h2, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h1, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h2, ac, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h1, ac, 0, 0, 0);
+            if (q & 1)
+              acc1 = ac;
+            else
+              acc0 = ac;
+          } else if (BF) {
             const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hp + q * 256);
             if (q & 1)
               acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[q], hb, acc1, 0, 0, 0);
@@ -594,7 +666,23 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
           st_h[gi][oi] = h_reg;
         }
         // 6. publish h_s first (write-through) ...
-        if (BF) {
+        if (S3) {
+          // as the bf16 kernel: lane bl gathers the 4 units of this wave's tile for batch row bl, splits them and stores 4 bf16
+          // = 8 bytes per piece image at k = unit0 .. unit0+3
+          const float hv = cellok ? h_reg : 0.f;
+          const float hq[4] = {hv, __shfl(hv, bl + 16, 64), __shfl(hv, bl + 32, 64), __shfl(hv, bl + 48, 64)};
+          if (lane < 16) {
+            unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split3(hq[j], p1[j], p2[j], p3[j]);
+            float* xdst = (s & 1) ? xb1 : xb0;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(xdst, 0, (int)(xblk * 4), 0x00020000);
+            const unsigned off = (unsigned)(bf_img(ug * (4 * MT) + 4 * mt, bl) * 2);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16)}, rs, off, 0, 16 /* sc1 */);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16)}, rs, off + 4u * PIECE, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2){p3[0] | (p3[1] << 16), p3[2] | (p3[3] << 16)}, rs, off + 8u * PIECE, 0, 16);
+          }
+        } else if (BF) {
           // the 4 units of this wave's tile for batch row bl sit in lanes bl, 16+bl, 32+bl, 48+bl: lane bl
           // gathers them and stores 4 bf16 = 8 bytes at k = unit0 .. unit0+3 of the image
           const float hv = cellok ? h_reg : 0.f;
@@ -652,7 +740,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = st_c[gi][oi];
       } else {
         a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_c[gi][oi];
-        if (BF || (a.opt & 8)) a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_h[gi][oi];
+        if (B16 || (a.opt & 8)) a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_h[gi][oi];
       }
     }
   }
@@ -854,7 +942,9 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
   if (owner) *reinterpret_cast<f32x4*>(&st_db[oi][0]) = f32x4{0.f, 0.f, 0.f, 0.f};  // read and written by the same lane only
   bool aborted = false;
   // first row of a time step: offs[t] (packed) or t * B (padded).  The step processed NEXT is the one the forward pass
-  // processed BEFORE this one, so its table entry is also the row base of this step's c_{prev}: fetched a step ahead
+  // processed BEFORE this one, so its table entry is also the row base of this step's c_{prev}: one scalar load per step,
+  // used by this step's c_{prev} fetch and as the next step's row base (measured neutral in this kernel, whose waits inside
+  // the step are counted vmcnt waits on its DMA ring)
   auto row_base = [&](int tt) { return (tt < 0 || tt >= T) ? 0 : (a.offs ? a.offs[tt] : tt * B); };
   int rb_next = row_base(dir ? a.s_begin : T - 1 - a.s_begin);
   for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
@@ -1058,6 +1148,15 @@ int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
   return 0;
 }
 
+int dispatch_fwd_s3(int KS, const FwdArgs& a, int nblocks, hipStream_t st) {
+  switch (KS) {
+    case 20: hipLaunchKernelGGL((lstm_fwd_kernel<20, false, 8, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a); break;
+    case 40: hipLaunchKernelGGL((lstm_fwd_kernel<40, false, 8, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a); break;
+    default: hipLaunchKernelGGL((lstm_fwd_kernel<56, false, 8, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a); break;
+  }
+  return 0;
+}
+
 int dispatch_fwd(int KS, bool bf, const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
   if (bf) switch (KS) {
       case 20: return launch_fwd<20, true>(a, half, nblocks, st);
@@ -1140,11 +1239,13 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   int opt = (mode >> 20) & 7;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD;
                                         // bit 22: one flag per 128-byte line
   if (opt & 4) opt &= ~2;              // one flag per line: no replicas on top (the flag block is sized for either)
-  const bool tagged = ((mode >> 29) & 1) && !((mode >> 16) & 1) && !((mode >> 17) & 1);  // bit 29 (fp32, 8-wave workgroups)
+  // bit 28 (fp32, 8-wave workgroups): the product by the exact three-way bf16 split on the bf16 matrix pipe (S3)
+  const bool s3 = ((mode >> 28) & 1) && !bf && !half && pick_ks(H, true) != 64;  // (KS = 64: 168 + 88 registers do not fit)
+  const bool tagged = ((mode >> 29) & 1) && !((mode >> 16) & 1) && !((mode >> 17) & 1) && !s3;  // bit 29 (fp32, 8-wave workgroups)
   if (tagged) opt |= 8;                // the data is the flag (lstm_fwd_kernel)
   int poll_delay = (mode >> 23) & 31;  // bits 23..27: FwdArgs::poll_delay, units of 0.1 us; 0 = choose, 31 = none
   mode &= 0xff;
-  const WsLayout L = ws_layout(B, H, bf);
+  const WsLayout L = ws_layout(B, H, bf || s3);  // (S3 exchanges bf16 images: the bf16 unit-group counts)
   hipStream_t st = (hipStream_t)stream;
   char* base = (char*)ws;
   FwdArgs a;
@@ -1170,11 +1271,11 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
     SK_CHECK_HIP(hipMemsetAsync(base + L.xbuf, 0, L.state - L.xbuf, st));
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T;
-    dispatch_fwd(L.KS, bf, a, half, nblocks, st);
+    s3 ? dispatch_fwd_s3(L.KS, a, nblocks, st) : dispatch_fwd(L.KS, bf, a, half, nblocks, st);
   } else {  // one launch per step: the state travels through the workspace
     for (int s = 0; s < T; ++s) {
       a.s_begin = s; a.s_end = s + 1;
-      dispatch_fwd(L.KS, bf, a, half, nblocks, st);
+      s3 ? dispatch_fwd_s3(L.KS, a, nblocks, st) : dispatch_fwd(L.KS, bf, a, half, nblocks, st);
     }
   }
   SK_CHECK_LAUNCH("sk_lstm_fwd");

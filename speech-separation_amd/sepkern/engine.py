@@ -118,18 +118,23 @@ class Engine:
         self.lstm_mode = int(os.environ.get("SEPKERN_LSTM_MODE", "0"))
 
         # hand-off geometry / protocol of the persistent recurrences (speed only): "half,map,poll1,repflags,
-        # spread,delay,tagged".  Forward: streams dealt to XCD groups, one polling wave, first poll held back (delay 0 = the
-        # library's choice); bf16: one flag per 128-byte line on top.  fp32 forward: THE DATA IS THE FLAG (tagged = 1, hold-back
-        # 0.8 us): the exchanged h carries the step's epoch in its two low mantissa bits -- h entering the next step's product
-        # is perturbed by at most 3 ulp, everything stored is exact; SEPKERN_LSTM_FWD=0,1,1,0,0,0,0 is the exact hand-off
-        # (0.5 ms per training step slower; bench.py's config.numerics says which one ran).  Backward: the XCD map only.
+        # spread,delay,tagged,split3".  Forward: streams dealt to XCD groups, one polling wave, first poll held back (delay 0 =
+        # the library's choice); bf16: one flag per 128-byte line on top.  fp32 forward (r04): the product h W_hh^T by the EXACT
+        # three-way bf16 split of both operands on the bf16 matrix pipe (split3 = 1: nine exact piece products per element pair,
+        # fp32 accumulators -- an fp32 product in another summation order, no operand is perturbed; 35.6 vs 36.6 ms per
+        # training step against the r03 default).  That r03 default, "the data is the flag" (SEPKERN_LSTM_FWD=0,1,1,0,0,8,1,0:
+        # the exchanged h carries the step's epoch in its two low mantissa bits, <= 3 ulp on the operand), remains for hidden
+        # sizes whose register slice does not fit the split (H > 896); SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 is the plain fp32-MFMA
+        # product with flags.  bench.py's config.numerics says which one ran.  Backward: the XCD map only.
         def variant(env, default):
             v = [int(x) for x in os.environ.get(env, default).split(",")]
-            v += [0] * (7 - len(v))
-            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5], tagged=bool(v[6]))
-        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0,0" if self.bf16 else "0,1,1,0,0,8,1")
-        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31,0")
-        self.tagged_fwd = bool(self.fwd_bits & 0x20000000) and not self.bf16
+            v += [0] * (8 - len(v))
+            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5], tagged=bool(v[6]), split3=bool(v[7]))
+        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0,0,0" if self.bf16 else
+                                ("0,1,1,0,0,0,0,1" if hidden <= 896 else "0,1,1,0,0,8,1,0"))
+        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31,0,0")
+        self.split3_fwd = bool(self.fwd_bits & 0x10000000) and not self.bf16 and hidden <= 896
+        self.tagged_fwd = bool(self.fwd_bits & 0x20000000) and not self.bf16 and not self.split3_fwd
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one: the
         # recurrence keeps its one-workgroup-per-CU grid and the GEMM blocks become CO-RESIDENT on its CUs -- a persistent
         # workgroup leaves >= 124 VGPRs per SIMD lane and >= 69 KB of LDS free, and the matrix pipe idle during its
@@ -280,7 +285,8 @@ class Engine:
             raise SepkernError("forward: input is %s, expected (>= %d, %d) packed rows" % (tuple(x2d.shape), pk.R, self.I))
         T, B, R, Rp = pk.T, pk.B, pk.R, pk.Rp
         H, L, O, I0 = self.H, self.L, self.O, self.I
-        lens, offs = pk.lens, pk.offs
+        lens = pk.lens
+        offs = None if pk.uniform else pk.offs      # equal lengths: packed rows ARE the (T, B) grid, no table to read
         dev = x2d.device
         saved = []
         cache = {}
@@ -412,7 +418,8 @@ class Engine:
         pk = ctx["pk"]
         T, B, R, Rp = pk.T, pk.B, pk.R, pk.Rp
         H, L, O, I0 = self.H, self.L, self.O, self.I
-        lens, offs = pk.lens, pk.offs
+        lens = pk.lens
+        offs = None if pk.uniform else pk.offs      # equal lengths: packed rows ARE the (T, B) grid, no table to read
         dev = dmask.device
         acc = not self.grads_fresh
         h0, c0 = ctx["h0"], ctx["c0"]

@@ -565,14 +565,15 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
-def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0, tagged=False):
+def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0, tagged=False, split3=False):
     """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..29);
     poll_delay: the forward kernel's polling wave holds its first poll of a step back (units of 0.1 us, 0 = the library's
     choice, 31 = none); tagged (forward, fp32): the exchanged h carries the step's epoch in its two low mantissa bits and
-    nothing else is signalled (mode bit 29)."""
+    nothing else is signalled (mode bit 29); split3 (forward, fp32): the product h W_hh^T by the exact three-way bf16 split
+    of both operands on the bf16 matrix pipe (mode bit 28; flags hand-off, the tagged one does not combine with it)."""
     return ((0x20000 if half else 0) | ((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) |
             (0x200000 if repflags else 0) | (0x400000 if spread else 0) | ((int(poll_delay) & 31) << 23) |
-            (0x20000000 if tagged else 0))
+            (0x20000000 if tagged else 0) | (0x10000000 if split3 else 0))
 
 
 def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0, offs=None,

@@ -27,6 +27,9 @@ def main():
         d = int(sys.argv[sys.argv.index("--tagged") + 1])
         fbits = ops.lstm_variant_bits(False, 1, True, False, False, d, tagged=True)
         bbits = ops.lstm_variant_bits(False, 1, False, False, False, 31)
+    elif "--split3" in sys.argv:                     # forward: exact three-way bf16 split of the product (mode bit 28), flags
+        fbits = ops.lstm_variant_bits(False, 1, True, False, False, 0, split3=True)
+        bbits = ops.lstm_variant_bits(False, 1, False, False, False, 31)
     elif "--legacy" in sys.argv:
         fbits = bbits = 0
     else:

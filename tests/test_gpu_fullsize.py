@@ -89,7 +89,7 @@ def _run_pair(S, dtype, oracle_mod, seed, handoffs=(None,)):
         torch.cuda.synchronize()
         ops.lstm_status(ops.lstm_ws(T, B, H))
         runs.append(dict(loss=float(loss), norm=float(norm), best=best, grads=grads, mask=mask,
-                         tagged=bool(model._engine.tagged_fwd)))
+                         tagged=bool(model._engine.tagged_fwd), split3=bool(model._engine.split3_fwd)))
         del model
     # oracle
     orc = OU.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
@@ -114,13 +114,14 @@ def _same_perms(r):
 
 def test_fp32_step_32x400_matches_oracle():
     """configs[1]: masks <= 1e-4 relative, loss 1e-5, same permutations, every parameter gradient <= 2e-4 rel-L2 -- with the
-    forward recurrence's shipped hand-off ("the data is the flag": the operand h carries a 2-bit epoch, <= 3 ulp) AND with
-    the exact one (flags), both against the same oracle step."""
-    tagged, exact = _run_pair(2, "fp32", OU, 21, handoffs=(None, "0,1,1,0,0,0,0"))
-    assert tagged["tagged"] and not exact["tagged"]
-    for r in (tagged, exact):
+    forward recurrence as shipped (the product by the exact three-way bf16 split, flags), with the r03 default ("the data is
+    the flag": the operand h carries a 2-bit epoch, <= 3 ulp) AND with the plain fp32-MFMA product and flags, all three
+    against the same oracle step."""
+    split3, tagged, plain = _run_pair(2, "fp32", OU, 21, handoffs=(None, "0,1,1,0,0,8,1,0", "0,1,1,0,0,0,0,0"))
+    assert split3["split3"] and not split3["tagged"] and tagged["tagged"] and not (plain["tagged"] or plain["split3"])
+    for r in (split3, tagged, plain):
         _check_fp32(r)
-    assert tagged["loss"] != exact["loss"] or not np.array_equal(tagged["mask"], exact["mask"])   # (they ARE two arithmetics)
+    assert tagged["loss"] != plain["loss"] or not np.array_equal(tagged["mask"], plain["mask"])   # (they ARE different arithmetics)
 
 
 def _check_fp32(r):

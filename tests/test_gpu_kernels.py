@@ -984,3 +984,44 @@ def test_lstm_backward_bf16_twin_of_dgx(ops, T, B, H, lens, bf16):
         assert torch.equal(twin[:R, :8 * H], dgx.to(torch.bfloat16))
         assert float(dgx.abs().max()) > 0
         assert bool((twin[R:] == 7).all()) and bool((twin[:, 8 * H:] == 7).all())
+
+
+@pytest.mark.parametrize("layout", ["padded", "packed"])
+@pytest.mark.parametrize("T,B,H,lens", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1]), (9, 100, 600, [9] * 60 + [4] * 40),
+                                        (7, 20, 300, [7] * 7 + [4] * 13), (11, 3, 64, [11, 5, 1])])
+def test_lstm_forward_exact_bf16_split_is_an_fp32_product(ops, layout, T, B, H, lens):
+    """Mode bit 28 (fp32 forward): h W_hh^T by the exact three-way bf16 split of both operands on the bf16 matrix pipe -- nine
+    exact piece products per element pair, fp32 accumulators: the fp32 recurrence in another summation order.  Outputs agree
+    with the fp32-MFMA kernel's to 2e-6 (as two fp32 summation orders do), are bit-reproducible, equal in per-step launch
+    mode, and 50 x closer to it than the bf16-input recurrence is."""
+    g = torch.Generator().manual_seed(13 * H + T)
+    rw = _Rows(layout, T, B, lens)
+    gx = rw.put(torch.randn(T, B, 2, 4 * H, generator=g) * 0.5)
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+
+    def fwd(bits, mode=1, bf16=False):
+        gg = gx.clone()
+        y, cs = rw.new(2 * H, 0.0), rw.new(2 * H, 0.0)
+        hn, cn = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+        ws = ops.lstm_fwd(gg, whh, h0, c0, rw.lens, y, gg, cs, hn, cn, T, B, H, mode | bits, offs=rw.offs, bf16=bf16)
+        ops.lstm_status(ws)
+        return y, gg, cs, hn, cn
+
+    def rows_of(a):
+        if a.dim() == 2 and a.shape[0] == rw.R and not rw.packed:
+            return a.view(T, B, -1)[rw.valid]
+        return a[:rw.pk.R] if (a.dim() == 2 and a.shape[0] == rw.R) else a
+
+    ref = fwd(ops.lstm_variant_bits(False, 1, True, False, False, 0))
+    s3 = ops.lstm_variant_bits(False, 1, True, False, False, 0, split3=True)
+    out, again, steps = fwd(s3), fwd(s3), fwd(s3, mode=2)
+    low = fwd(ops.lstm_variant_bits(False, 1, True, False, True, 0), bf16=True)
+    for a, b, c_, e, lo in zip(out, ref, again, steps, low):
+        a, b, c_, e, lo = rows_of(a), rows_of(b), rows_of(c_), rows_of(e), rows_of(lo)
+        assert torch.isfinite(a).all()
+        err = float((a - b).abs().max())
+        assert err < 2e-6, err
+        assert torch.equal(a, c_) and torch.equal(a, e)
+        if H >= 300:
+            assert err * 50 < float((lo - b).abs().max())

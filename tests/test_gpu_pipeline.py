@@ -356,16 +356,19 @@ def test_staged_batches_equal_the_plain_loader_and_keep_up_with_the_step(tmp_pat
 def test_bench_ragged_line_and_numerics_field():
     """`bench.py --ragged` (SURVEY.md 8d's variable-length set: U(24k, 64k) samples, a different batch every step, packed
     rows): frames_per_step counts the valid frames only, the workload string says so, and config.numerics names the forward
-    recurrence's hand-off (tagged by default, exact with SEPKERN_LSTM_FWD=0,1,1,0,0,0,0) -- VERDICT r03 items 1 and 3."""
+    recurrence's arithmetic (the exact bf16-split product by default, the r03 tagged hand-off or the plain fp32-MFMA product
+    on request) -- VERDICT r03 items 1, 3 and 4."""
     import json
     root = os.path.dirname(PKG)
     out = {}
-    for tag, env in (("tagged", {}), ("exact", {"SEPKERN_LSTM_FWD": "0,1,1,0,0,0,0"})):
+    for tag, env in (("split3", {}), ("tagged", {"SEPKERN_LSTM_FWD": "0,1,1,0,0,8,1,0"}), ("exact", {"SEPKERN_LSTM_FWD": "0,1,1,0,0,0,0,0"})):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "1", "--hidden", "320", "--layers", "2",
                             "--batch", "32", "--ragged", "--no-cpu-baseline"], cwd=root, env=dict(os.environ, **env),
                            capture_output=True, text=True, timeout=400)
         assert r.returncode == 0, r.stderr[-3000:]
         out[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    d = out["split3"]
+    assert "three-way bf16 split" in d["config"]["numerics"]
     d = out["tagged"]
     assert "U(24000, 64000)" in d["config"]["workload"] and "packed rows" in d["config"]["workload"]
     assert 32 * 188 <= d["config"]["frames_per_step"] <= 32 * 501
