@@ -359,7 +359,10 @@ __device__ __forceinline__ void decode_block(int L, int NUG, int nby, int map, i
 // NW = waves per workgroup.  8: 16 hidden units per workgroup (4 gate-row tiles x 2 K halves), one workgroup per CU.
 // 4: 8 units per workgroup (2 tiles x 2 K halves), TWO workgroups per CU that belong to different streams: while one
 // waits for its hand-off the other has the matrix pipe, so a step costs the chain plus HALF the MFMA time.
-template <int KS, bool BF, int NW, bool S3 = false>
+// PK: the sequence tensors are PACKED rows (FwdArgs::offs).  A template parameter, not a run-time test of a.offs: the padded
+// instantiation is then the r03 kernel instruction for instruction (one process measured the run-time form 0.1-0.25 us per
+// step slower on padded batches: the row-base select and the length table in front of the step's gx fetch).
+template <int KS, bool BF, int NW, bool S3 = false, bool PK = false>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   static_assert(!(BF && S3) && (!S3 || NW == 8), "S3 is an fp32 variant of the 8-wave kernel");
   constexpr bool B16 = BF || S3;          // the exchanged operand travels as bf16 image(s)
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   __shared__ float st_c[GMAX][64 * MT], st_h[GMAX][64 * MT];  // per-group cell state of the owner lanes
   __shared__ long long st_tpub[GMAX];                         // wave 0: when this workgroup raised the group's flag
   __shared__ int s_abort;
+  __shared__ int s_len[GMAX * 16];  // lengths of this workgroup's batch rows (loop-invariant: fetched once, not per step)
 
   int ug, by, dir;
   decode_block((int)blockIdx.x, NUG, a.nby, a.map, ug, by, dir);
@@ -448,6 +452,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
     }
   }
   if (tid == 0) s_abort = 0;
+  // (a per-step load of lens[b] sat in front of the step's gx fetch: the two global latencies in series cost the bf16
+  // recurrence, whose matrix phase is too short to hide them, 0.5 us per step)
+  if (PK && tid < G * 16) s_len[tid] = ((by * G + (tid >> 4)) < NBG && (by * G + (tid >> 4)) * 16 + (tid & 15) < B)
+                                           ? a.lens[(by * G + (tid >> 4)) * 16 + (tid & 15)] : 0;
   __syncthreads();
   SK_STAMP_DECL
 
@@ -461,24 +469,28 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
     // on one device in one call (profiles/r04_lstm_fwd_row_base_fetch_ab.txt: 6.05 us per step as here, 6.19 as a vector load
     // -- its vmcnt wait at the next step's top also waits for this step's bulk stores --, 6.33 as a scalar load -- every LDS
     // wait of the step becomes a wait for lgkmcnt(0)).
-    const int rb = a.offs ? a.offs[t] : t * B;
+    const int rb = PK ? a.offs[t] : t * B;
     for (int gi = 0; gi < G; ++gi) {
       const int bg = by * G + gi;
       if (bg >= NBG) break;
       const int b = bg * 16 + bl;
       const bool cellok = owner && unit < H && b < B;
-      const int len_b = (b < B) ? a.lens[b] : 0;
+      const int len_b = PK ? s_len[gi * 16 + bl] : ((b < B) ? a.lens[b] : 0);
       const bool live = cellok && t < len_b;                       // this lane's cell takes part in step t
       const size_t row = (size_t)rb + b;                           // its row in gx / y / gates / cs
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
-      float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
+      // (derived, not a second product: two independent block addresses were what tipped this loop's uniform values over the
+      // scalar register file -- 111 v_readlane reloads per step of the bf16 instantiation instead of 27, +0.4 us per step)
+      float* const xb1 = xb0 + (size_t)2 * NBG * xblk;
       const size_t rep_stride = (size_t)2 * NBG * NUG;
       unsigned* const flags0 = a.flags + (size_t)(dir * NBG + bg) * NUG * fs;  // replica 0 of this stream's flags
       const unsigned* const myflags = flags0 + (size_t)flag_replica(a.opt) * rep_stride;
       SK_STAMP(7);
       // 1. this step's input-projection terms (independent of the recurrence: issue early)
       float4 gxv = make_float4(0.f, 0.f, 0.f, 0.f);  // gate-interleaved layout: i,f,g,o of a cell are one 16-byte access
-      if (live) gxv = *reinterpret_cast<const float4*>(a.gx + (row * 2 + dir) * 4 * H + 4 * (size_t)unit);
+      // (padded layout: the row exists whatever the length says, so the fetch does not wait for it -- the bf16 recurrence's
+      // matrix phase is too short to hide a length read in front of this load)
+      if (PK ? live : cellok) gxv = *reinterpret_cast<const float4*>(a.gx + (row * 2 + dir) * 4 * H + 4 * (size_t)unit);
       // 2./3. h_{s-1} image (16 rows x HP) -> LDS.  Each consumer wave waits for the flags of exactly the unit
       // groups whose 1 KB pieces it pulls and starts its LDS-DMAs as soon as those are up -- no workgroup
       // barrier in between.  fp32: all 8 waves pull (56 pieces); bf16 (28 pieces, latency-bound): only the four
@@ -719,7 +731,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         if (tid == 0) st_tpub[gi] = wall_clock64();  // read back by this same wave when it polls for the next step
       }
       // 7. ... then the bulk stores of the step, off the critical path
-      if (valid || (cellok && !a.offs)) {  // padded layout: y = 0 past a row's end; packed: those rows do not exist
+      if (PK ? valid : cellok) {  // padded layout: y = 0 past a row's end; packed: those rows do not exist
         a.y[row * 2 * H + (size_t)dir * H + unit] = y_out;
         if (a.gates && valid) {
           *reinterpret_cast<f32x4*>(a.gates + (row * 2 + dir) * 4 * H + 4 * (size_t)unit) = acc;
@@ -874,6 +886,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
   __shared__ __attribute__((aligned(16))) float st_db[256][4];  // owner lanes: running sum of their cells' dG (bias gradient)
   __shared__ long long st_tpub[GMAX];  // wave 0: when this workgroup raised the group's flag (see wait_flags)
   __shared__ int s_abort;
+  __shared__ int s_len[GMAX * 16];  // lengths of this workgroup's batch rows (loop-invariant: fetched once, not per step)
 
   int ug, by, dir;
   decode_block((int)blockIdx.x, KS, a.nby, a.map, ug, by, dir);
@@ -936,6 +949,8 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
     }
   }
   if (tid == 0) s_abort = 0;
+  if (tid < G * 16) s_len[tid] = ((by * G + (tid >> 4)) < NBG && (by * G + (tid >> 4)) * 16 + (tid & 15) < B)
+                                     ? a.lens[(by * G + (tid >> 4)) * 16 + (tid & 15)] : 0;
   __syncthreads();
   SK_STAMP_DECL
 
@@ -956,7 +971,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
       if (bg >= NBG) break;
       const int b = bg * 16 + bl;
       const bool cellok = owner && unit < H && b < B;
-      const int len_b = (b < B) ? a.lens[b] : 0;
+      const int len_b = s_len[gi * 16 + bl];
       float* const xb0 = a.xbuf + ((size_t)(0 * 2 + dir) * NBG + bg) * xblk;
       float* const xb1 = a.xbuf + ((size_t)(1 * 2 + dir) * NBG + bg) * xblk;
       const int fs = (a.map & 4) ? FSPREAD : 1;  // option (bit 2 of the map field): one flag per 128-byte line
@@ -1136,11 +1151,24 @@ __global__ __launch_bounds__(256) void gate_rows_kernel(const float* __restrict_
 
 template <int KS, bool BF>
 int launch_fwd(const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
-  if (half)
+  if (a.offs) {
+    if (half)
+      hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 4, false, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 8, false, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a);
+  } else if (half) {
     hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 4>), dim3((unsigned)nblocks), dim3(256), 0, st, a);
-  else
+  } else {
     hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 8>), dim3((unsigned)nblocks), dim3(512), 0, st, a);
+  }
   return 0;
+}
+template <int KS>
+void launch_fwd_s3(const FwdArgs& a, int nblocks, hipStream_t st) {
+  if (a.offs)
+    hipLaunchKernelGGL((lstm_fwd_kernel<KS, false, 8, true, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((lstm_fwd_kernel<KS, false, 8, true, false>), dim3((unsigned)nblocks), dim3(512), 0, st, a);
 }
 template <int KS, bool BF>
 int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
@@ -1150,9 +1178,9 @@ int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
 
 int dispatch_fwd_s3(int KS, const FwdArgs& a, int nblocks, hipStream_t st) {
   switch (KS) {
-    case 20: hipLaunchKernelGGL((lstm_fwd_kernel<20, false, 8, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a); break;
-    case 40: hipLaunchKernelGGL((lstm_fwd_kernel<40, false, 8, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a); break;
-    default: hipLaunchKernelGGL((lstm_fwd_kernel<56, false, 8, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a); break;
+    case 20: launch_fwd_s3<20>(a, nblocks, st); break;
+    case 40: launch_fwd_s3<40>(a, nblocks, st); break;
+    default: launch_fwd_s3<56>(a, nblocks, st); break;
   }
   return 0;
 }
