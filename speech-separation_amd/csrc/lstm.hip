@@ -440,11 +440,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
           c = a.c0[((size_t)dir * B + b) * H + unit];
           h = a.h0[((size_t)dir * B + b) * H + unit];
         } else {
+          // (step launches: c AND h travel through the workspace's state arrays -- the exchange buffer holds h of the stream's
+          // last step in ONE parity slot only, and a stream that has run out of frames no longer writes it)
           c = a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
-          if (B16 || (a.opt & 8))
-            h = a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
-          else
-            h = __hip_atomic_load(a.xbuf + ((size_t)(((a.s_begin - 1) & 1) * 2 + dir) * NBG + bg) * xblk + xoff, SK_RLX, SK_AGENT);
+          h = a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit];
         }
       }
       st_c[gi][oi] = c;
@@ -462,17 +461,24 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   const int fs = (a.opt & 4) ? FSPREAD : 1;  // option: every flag in a 128-byte line of its own (flag stores do not serialise on a line)
   bool aborted = false;
   long long t_self = 0;  // tagged hand-off: when this wave was done with the previous step
-  for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
-    const int t = dir ? T - 1 - s : s;
-    // First row of the time step: offs[t] (packed rows) or t * B (padded; callers pass offs = NULL for batches whose lengths
-    // are all equal, where the two layouts coincide).  One scalar load, used at once.  Fetching it a step ahead measured WORSE
-    // on one device in one call (profiles/r04_lstm_fwd_row_base_fetch_ab.txt: 6.05 us per step as here, 6.19 as a vector load
-    // -- its vmcnt wait at the next step's top also waits for this step's bulk stores --, 6.33 as a scalar load -- every LDS
-    // wait of the step becomes a wait for lgkmcnt(0)).
-    const int rb = PK ? a.offs[t] : t * B;
+  // Packed rows: a stream (direction, batch group) runs only the steps in which its group has a frame at all -- Tg = the
+  // group's longest utterance (its first row: the batch is length-sorted) -- as ITS steps 0 .. Tg-1 (t = s forward, Tg-1-s
+  // reverse); epochs, parities and flags count those.  Streams are independent, so the short groups of a ragged batch leave
+  // the grid early instead of idling through the long group's tail (and leave their CUs to whatever runs beside the grid).
+  const int s_hi = PK ? min(a.s_end, s_len[0]) : a.s_end;
+  for (int s = a.s_begin; s < s_hi && !aborted; ++s) {
     for (int gi = 0; gi < G; ++gi) {
       const int bg = by * G + gi;
       if (bg >= NBG) break;
+      const int Tg = PK ? s_len[gi * 16] : T;
+      if (s >= Tg) break;  // (later groups are shorter still)
+      const int t = dir ? Tg - 1 - s : s;
+      // First row of the time step: offs[t] (packed rows) or t * B (padded; callers pass offs = NULL for batches whose lengths
+      // are all equal, where the two layouts coincide).  One scalar load, used at once.  Fetching it a step ahead measured WORSE
+      // on one device in one call (profiles/r04_lstm_fwd_row_base_fetch_ab.txt: 6.05 us per step as here, 6.19 as a vector load
+      // -- its vmcnt wait at the next step's top also waits for this step's bulk stores --, 6.33 as a scalar load -- every LDS
+      // wait of the step becomes a wait for lgkmcnt(0)).
+      const int rb = PK ? a.offs[t] : t * B;
       const int b = bg * 16 + bl;
       const bool cellok = owner && unit < H && b < B;
       const int len_b = PK ? s_len[gi * 16 + bl] : ((b < B) ? a.lens[b] : 0);
@@ -752,7 +758,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = st_c[gi][oi];
       } else {
         a.state[((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_c[gi][oi];
-        if (B16 || (a.opt & 8)) a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_h[gi][oi];
+        a.state[hst + ((size_t)dir * NBG * 16 + (size_t)bg * 16 + bl) * HP + unit] = st_h[gi][oi];
       }
     }
   }
@@ -961,14 +967,17 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
   // used by this step's c_{prev} fetch and as the next step's row base (measured neutral in this kernel, whose waits inside
   // the step are counted vmcnt waits on its DMA ring)
   auto row_base = [&](int tt) { return (tt < 0 || tt >= T) ? 0 : (a.offs ? a.offs[tt] : tt * B); };
-  int rb_next = row_base(dir ? a.s_begin : T - 1 - a.s_begin);
-  for (int s = a.s_begin; s < a.s_end && !aborted; ++s) {
-    const int t = dir ? s : T - 1 - s;  // reverse of the forward processing order
-    const int rb = rb_next;
-    rb_next = row_base(dir ? t + 1 : t - 1);
+  // (packed rows: a stream runs its group's Tg steps only, as in lstm_fwd_kernel: t = s reverse direction, Tg-1-s forward)
+  const int s_hi = a.offs ? min(a.s_end, s_len[0]) : a.s_end;
+  for (int s = a.s_begin; s < s_hi && !aborted; ++s) {
     for (int gi = 0; gi < G; ++gi) {
       const int bg = by * G + gi;
       if (bg >= NBG) break;
+      const int Tg = a.offs ? s_len[gi * 16] : T;
+      if (s >= Tg) break;
+      const int t = dir ? s : Tg - 1 - s;  // reverse of the forward processing order
+      const int rb = row_base(t);
+      const int rb_next = row_base(dir ? t + 1 : t - 1);
       const int b = bg * 16 + bl;
       const bool cellok = owner && unit < H && b < B;
       const int len_b = s_len[gi * 16 + bl];
@@ -1093,12 +1102,13 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
     const int b = bg * 16 + bl;
     const bool cellok = owner && unit < H && b < B;
     if (a.final_mm) {
-      // gradient wrt the initial state: one more product with the last published dG (s_end == T)
+      // gradient wrt the initial state: one more product with the last published dG (the stream's step Tg - 1)
+      const int Tg = a.offs ? s_len[gi * 16] : T;
       const int fs = (a.map & 4) ? FSPREAD : 1;
       const unsigned* const myflags = a.flags + (size_t)(dir * NBG + bg) * KS * fs;
-      const unsigned xo = (unsigned)(((size_t)((((T - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4);
-      if (T > a.s_begin && w == 0) {
-        if (!wait_flags(myflags, KS, (unsigned)T, a.ctrl, lane, 0LL, fs) && lane == 0) s_abort = 1;
+      const unsigned xo = (unsigned)(((size_t)((((Tg - 1) & 1) * 2 + dir) * NBG + bg) * xblk) * 4);
+      if (Tg > a.s_begin && w == 0) {
+        if (!wait_flags(myflags, KS, (unsigned)Tg, a.ctrl, lane, 0LL, fs) && lane == 0) s_abort = 1;
       }
       __syncthreads();
       if (s_abort) return;

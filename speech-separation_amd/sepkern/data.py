@@ -135,7 +135,7 @@ class Prefetcher:
 
   @staticmethod
   def _tensors(staged):
-    p = staged.get('packed')
+    p = staged.get('packed') if isinstance(staged, dict) else None      # (other batch types pass through as they came)
     if p is not None:
       yield p[0]
       for s in p[1]:
