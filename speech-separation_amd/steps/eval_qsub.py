@@ -40,7 +40,7 @@ def get_args(argv=None):
   parser.add_argument("--model-config", type=str, help="Config file for DNN", default="")
   parser.add_argument("--batch-size", type=int, help="Batch size", default=100)
   parser.add_argument("--seed", type=int, default=None, help="seed for the random h0/c0 (archs/uPIT.py:121-127)")
-  parser.add_argument("--writers", type=int, default=4, help="threads compressing and writing the npz files")
+  parser.add_argument("--writers", type=int, default=8, help="threads compressing and writing the npz files (zlib: ~25 MB/s per thread on spectra at any level)")
   parser.add_argument("--num-workers", type=int, default=4, help="loader processes inflating the test features")
   return parser.parse_args(argv)
 
