@@ -185,3 +185,39 @@ def test_frame_counts_from_file_headers(tmp_path):
         p = str(tmp_path / ("w%d.wav" % n))
         scipy.io.wavfile.write(p, 8000, np.zeros(n, np.int16))
         assert wav_frames(p) == 1 + n // 128
+
+
+@pytest.mark.parametrize("lens", [[9, 7, 7, 3], [5, 5, 5], [1], [6, 1, 1, 1, 1], list(range(40, 0, -1))])
+def test_packing_tables_are_torchs_packed_sequence_layout(lens):
+    """sepkern.packing.Packing (host logic, no GPU): offs / lens are exactly the row layout of torch's PackedSequence --
+    offs[t+1] - offs[t] == batch_sizes[t], row of (t, j) = offs[t] + j -- from lengths and from batch_sizes alike, and an
+    unsorted batch gets the permutation that sorts it (stable) without losing anybody."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speech-separation_amd"))
+    from torch.nn.utils.rnn import pack_padded_sequence
+    from sepkern.packing import Packing
+    T, B = max(lens), len(lens)
+    x = torch.arange(T * B, dtype=torch.float32).view(T, B, 1)
+    ref = pack_padded_sequence(x, torch.tensor(lens), enforce_sorted=True)
+    pk = Packing.from_lens(lens, "cpu")
+    assert (pk.T, pk.B, pk.R) == (T, B, int(sum(lens))) and pk.Rp % 64 == 0 and pk.R <= pk.Rp < pk.R + 64
+    assert np.array_equal(np.diff(pk.offs_host), ref.batch_sizes.numpy()) and pk.offs_host[0] == 0
+    assert pk.uniform == (len(set(lens)) == 1) and pk.perm is None
+    for t in range(T):
+        for j in range(int(ref.batch_sizes[t])):
+            assert float(ref.data[pk.offs_host[t] + j]) == float(x[t, j])
+    pk2 = Packing.from_batch_sizes(ref.batch_sizes, "cpu")
+    assert np.array_equal(pk2.lens_host, np.asarray(lens)) and np.array_equal(pk2.offs_host, pk.offs_host)
+    assert torch.equal(pk.lens, torch.tensor(lens, dtype=torch.int32)) and torch.equal(pk.offs, torch.from_numpy(pk.offs_host))
+    rng = np.random.default_rng(len(lens))
+    order = rng.permutation(B)
+    shuffled = [lens[i] for i in order]
+    pks = Packing.from_lens(shuffled, "cpu")
+    assert list(pks.lens_host) == sorted(lens, reverse=True) and np.array_equal(pks.offs_host, pk.offs_host)
+    if pks.perm is not None:
+        assert sorted(pks.perm_host.tolist()) == list(range(B)) and [shuffled[i] for i in pks.perm_host] == list(pks.lens_host)
+        h = torch.arange(B, dtype=torch.float32).view(1, B, 1)
+        assert torch.equal(pks.unsort_batch(pks.sort_batch(h, 1), 1), h)
+    with pytest.raises(Exception):
+        Packing([3, 5], "cpu")          # not sorted
