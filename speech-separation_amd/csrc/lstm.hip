@@ -627,23 +627,21 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         for (int q = 0; q < NQ; ++q) {
           if (S3) {
             // nine exact piece products per 32 k, the small ones first; chunks alternate between two accumulators
-            const bf16x8 h1 = *reinterpret_cast<const bf16x8*>(hp + q * 256);
-            const bf16x8 h2 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + PIECE);
+            // the piece that is needed first is fetched first, and the nine products alternate between the two accumulators (no
+            // product waits for the one issued just before it): 5.4 vs 5.7 us per step against fetching hi, mid, lo in that
+            // order and chaining all nine of a chunk on one accumulator (an explicit software pipeline of the fetches on top: no change)
             const bf16x8 h3 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + 2 * PIECE);
-            f32x4 ac = (q & 1) ? acc1 : acc0;
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h3, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h2, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h3, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h1, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h3, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h2, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h1, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h2, ac, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h1, ac, 0, 0, 0);
-            if (q & 1)
-              acc1 = ac;
-            else
-              acc0 = ac;
+            const bf16x8 h2 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + PIECE);
+            const bf16x8 h1 = *reinterpret_cast<const bf16x8*>(hp + q * 256);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h3, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h3, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h3, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h2, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h2, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h2, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h1, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h1, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h1, acc0, 0, 0, 0);
           } else if (BF) {
             const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hp + q * 256);
             if (q & 1)

