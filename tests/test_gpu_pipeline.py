@@ -294,7 +294,7 @@ def test_staged_batches_equal_the_plain_loader_and_keep_up_with_the_step(tmp_pat
         (npz path: bit for bit -- the same PackedSequence.data, copied by another route; wav path: the same STFT kernel);
       * rate: an epoch of train_epoch THROUGH the loader + staging runs at >= 0.6 of the rate of the same steps on batches
         that are already resident on the GPU (on this 20-step corpus the epoch's start-up -- one loader batch being built
-        from scratch -- is a visible share; on 2 000 utterances the factor is 0.91, profiles/r04_stage_walls.txt)."""
+        from scratch -- is a visible share; on 2 000 utterances the factor is 0.93, profiles/r04_stage_walls.txt)."""
     sys.path.insert(0, os.path.join(PKG, "archs"))
     sys.path.insert(0, STEPS)
     import importlib
