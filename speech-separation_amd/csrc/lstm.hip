@@ -852,10 +852,16 @@ __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* 
   }
 }
 
+// Position of (out unit m, batch n) in a wave's 16 x 16 partial tile.  Rows 2j and 2j+1 share a 32-word line; which 16-word half
+// a row takes is (m ^ (m >> 2)) & 1, so that BOTH access patterns are conflict-free: the writers of a 32-lane pass hold rows r and
+// r + 4 (opposite halves), the readers rows 4j and 4j + 1 (one line, opposite halves).  The former [16][17] padding was conflict-
+// free for the reads only: SQ_LDS_BANK_CONFLICT was 14 % of this kernel's LDS cycles (profiles/r04_lstm_pmc.txt).
+__device__ __forceinline__ int red_slot(int m, int n) { return (m >> 1) * 32 + 16 * ((m ^ (m >> 2)) & 1) + n; }
+
 // Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
 template <int KS, bool BF>
 __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
-                                            float (*red)[16][17], int w, int lane) {
+                                            float (*red)[256], int w, int lane) {
   // xbase: the exchange buffer (kernel argument: scalar), xoff: byte offset of this stream's block of the step (uniform)
   const unsigned ring_lds = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -867,12 +873,12 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) red[w][4 * (lane >> 4) + r][lane & 15] = acc0[r] + acc1[r];
+  for (int r = 0; r < 4; ++r) red[w][red_slot(4 * (lane >> 4) + r, lane & 15)] = acc0[r] + acc1[r];
   __syncthreads();
   const int m = 4 * (w & 3) + (lane >> 4), n = lane & 15;  // the cell of this lane (owner waves: w < 4)
   float v = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v += red[k][m][n];
+  for (int k = 0; k < 8; ++k) v += red[k][red_slot(m, n)];
   __syncthreads();
   return v;
 }
@@ -885,7 +891,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
   using C = BwdCfg<KS, BF>;
   constexpr int HP = 16 * KS, NQ = C::NQ;
   __shared__ __attribute__((aligned(16))) float ring_all[8][C::DEPTH * C::SB * 256];
-  __shared__ float red[8][16][17];
+  __shared__ float red[8][256];
   __shared__ float st_carry[GMAX][256], st_dc[GMAX][256];  // per-group recurrent state of the owner lanes
   __shared__ __attribute__((aligned(16))) float st_db[256][4];  // owner lanes: running sum of their cells' dG (bias gradient)
   __shared__ long long st_tpub[GMAX];  // wave 0: when this workgroup raised the group's flag (see wait_flags)
