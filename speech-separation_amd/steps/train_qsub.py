@@ -57,8 +57,9 @@ def get_args(argv=None):
   parser.add_argument("--torch-optimizer", action="store_true",
                       help="use torch clip_grad_norm_ + optim.Adam instead of the fused kernel")
   parser.add_argument("--num-workers", type=int, default=None,
-                      help="loader processes (default: 8 for npz features -- zlib inflate of ~1 MB per utterance is the "
-                           "loader's cost --, 2 with --wav-input; capped by the CPUs this process may use)")
+                      help="loader processes (default: up to 12 for npz features -- zlib inflate of ~1 MB per utterance is the "
+                           "loader's cost: 8 feed a 35 ms step, the 13 ms bf16 step wants more --, 2 with --wav-input; capped by "
+                           "the CPUs this process may use)")
   parser.add_argument("--prefetch", type=int, default=2,
                       help="batches staged on the GPU ahead of the step (pinned memory, own copy stream); 0: off")
   parser.add_argument("--wav-input", action="store_true",
@@ -159,7 +160,7 @@ def loader_workers(args, world):
     cpus = len(os.sched_getaffinity(0))
   except AttributeError:
     cpus = os.cpu_count() or 1
-  return max(1, min(2 if args.wav_input else 8, cpus // max(1, world) - 2))
+  return max(1, min(2 if args.wav_input else 12, cpus // max(1, world) - 3))
 
 
 def staged(loader, args):

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--out", default="")
     ap.add_argument("--modes", default="ref,npz,wav")
+    ap.add_argument("--conf", default="", help="extra conf lines, comma separated (e.g. dtype=bf16)")
     ap.add_argument("--keep", action="store_true", help="leave the work directory (tools/loader_probe.py reads its data dirs)")
     a = ap.parse_args()
     from sepkern import synth
@@ -75,6 +76,9 @@ def main():
     conf = os.path.join(work, "conf")
     with open(conf, "w") as f:
         f.write("hidden_dim=%d\nnum_layers=%d\nnum_spk=2\n" % (a.hidden, a.layers))
+        for line in a.conf.split(","):
+            if line:
+                f.write(line + "\n")
     base = [py, os.path.join(steps, "train_qsub.py"), "uPIT", "0", d_tr]
     common = ["--model-config", conf, "--batch-size", str(a.batch), "--num-epochs", "2", "--seed", "3"]
     modes = {"ref": ("train_qsub.py reference loop", ["--num-workers", "1", "--prefetch", "0"]),
