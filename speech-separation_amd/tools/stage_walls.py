@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--modes", default="ref,npz,wav")
     ap.add_argument("--conf", default="", help="extra conf lines, comma separated (e.g. dtype=bf16)")
+    ap.add_argument("--epochs", type=int, default=2, help="training epochs per mode (the last one is the reported rate; > 2: a soak run)")
     ap.add_argument("--keep", action="store_true", help="leave the work directory (tools/loader_probe.py reads its data dirs)")
     a = ap.parse_args()
     from sepkern import synth
@@ -80,7 +81,7 @@ def main():
             if line:
                 f.write(line + "\n")
     base = [py, os.path.join(steps, "train_qsub.py"), "uPIT", "0", d_tr]
-    common = ["--model-config", conf, "--batch-size", str(a.batch), "--num-epochs", "2", "--seed", "3"]
+    common = ["--model-config", conf, "--batch-size", str(a.batch), "--num-epochs", str(a.epochs), "--seed", "3"]
     modes = {"ref": ("train_qsub.py reference loop", ["--num-workers", "1", "--prefetch", "0"]),
              "npz": ("train_qsub.py npz, staged", []),
              "wav": ("train_qsub.py wav-input, staged", ["--wav-input"])}
@@ -90,7 +91,7 @@ def main():
         exp = os.path.join(work, "exp_" + m)
         ok, lines = run(tag, base + [exp] + common + extra, env, out)
         for l in lines:
-            g = re.search(r"epoch 2: .* = (\d+) frames/s", l)
+            g = re.search(r"epoch %d: .* = (\d+) frames/s" % a.epochs, l)
             if g:
                 rates[m] = int(g.group(1))
     exp = os.path.join(work, "exp_" + a.modes.split(",")[-1])
@@ -98,7 +99,7 @@ def main():
     run("eval_qsub.py (masks)", [py, os.path.join(steps, "eval_qsub.py"), os.path.join(PKG, "archs", "uPIT.py"), "0",
                                  os.path.join(exp, "final.mdl"), d_tt, masks, "--model-config", conf, "--batch-size", str(a.batch)], env, out)
     run("reconstruct_sources.py", [py, os.path.join(steps, "reconstruct_sources.py"), d_tt, os.path.join(exp, "output")], env, out)
-    out.append("second-epoch training rates (frames/s): " + ", ".join("%s %d" % kv for kv in rates.items()))
+    out.append("last-epoch training rates (frames/s): " + ", ".join("%s %d" % kv for kv in rates.items()))
     print(out[-1], flush=True)
     if a.out:
         with open(a.out, "w") as f:
