@@ -15,9 +15,11 @@ The features are produced before the timed region by the STFT kernel from synthe
 U(24 000, 64 000) samples from a fixed seed, 32 utterances per step, a DIFFERENT batch every step, frames = the valid
 frames only; not the headline line (that stays the T = 400 configuration BASELINE.json quotes the metric on).
 
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline      the dominant kernel (fp32 MFMA GEMM): algorithmic FLOP / HIP-event time, live in the timed region
   cpu_baseline  the CPU oracle's train step (torch-CPU port of the reference loop) on a bounded sample
+  secondary     (default run on one GPU only) the other one-GPU BASELINE configurations, timed in the same process after the
+                headline's timed region: the variable-length set in fp32 and bf16, bf16 3-speaker, RSH 4-speaker (SECONDARY)
 """
 import argparse
 import json
@@ -44,7 +46,7 @@ def log(msg):
 T_START = time.time()
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -67,7 +69,12 @@ def parse():
     ap.add_argument("--aux", action="store_true", help="also time the STFT / iSTFT kernels (extra JSON fields)")
     ap.add_argument("--arch", choices=["upit", "rsh"], default="upit",
                     help="rsh: the recurrent-selective-hearing arch (BASELINE configs[4]); not the headline metric")
-    return ap.parse_args()
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default run on one GPU only: skip the secondary BASELINE configurations (ragged set, bf16 3-spk, "
+                         "bf16 ragged, RSH 4-spk) that are timed after the headline and reported under \"secondary\"")
+    ap.add_argument("--secondary-only", type=str, default="",
+                    help="comma-separated names from SECONDARY: time only these (diagnostics)")
+    return ap.parse_args(argv)
 
 
 def make_batch(torch, ops, synth, B, T, S, first_utt, nsamp=None, padded_rows=False):
@@ -196,35 +203,15 @@ def launch_ranks(n):
     sys.exit(worst if 0 <= worst < 256 else 1)
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        launch_ranks(args.gpus)                           # never returns
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        sys.exit("bench.py --gpus %d under a launcher that started %d ranks" % (args.gpus, world))
-    # rehearsal on a 1-GPU box: SEPKERN_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 (use with
-    # SEPKERN_DIST_BACKEND=gloo and SEPKERN_LSTM_MODE=2, since two processes cannot both keep a
-    # persistent grid resident on one GPU)
-    if os.environ.get("SEPKERN_BENCH_ONE_DEVICE") == "1":
-        local = 0
-        os.environ["LOCAL_RANK"] = "0"
-    torch.cuda.set_device(local)
-    # rehearsals only: SEPKERN_LSTM_MODE_BY_RANK="0,2" gives every rank its own recurrence mode (one persistent grid beside
-    # ranks that launch per step: the chunked gradient exchange then runs next to a persistent kernel on a one-GPU box)
-    by_rank = os.environ.get("SEPKERN_LSTM_MODE_BY_RANK")
-    if by_rank:
-        os.environ["SEPKERN_LSTM_MODE"] = by_rank.split(",")[rank % len(by_rank.split(","))]
-    from sepkern import dist as skdist
-    skdist.init_from_env()                                # nccl (= RCCL over xGMI) unless SEPKERN_DIST_BACKEND says otherwise
-
+def measure(args, env, standalone_pass=True):
+    """One workload (model, optimizer, resident batches) timed as the module docstring says: W warm-up steps, K timed
+    steps between barrier + synchronize pairs, max over ranks.  Returns (the JSON line's dict without `cpu_baseline` /
+    `aux` / `secondary`, what aux_kernels() needs).  Called once for the headline and -- default run on one GPU -- once
+    per secondary BASELINE configuration, in the same process."""
+    torch, dist, skdist = env.torch, env.dist, env.skdist
+    world, rank, local = env.world, env.rank, env.local
     from sepkern import ops, synth, _lib
     from sepkern.optim import ClipAdam
-    _lib.load()
     import uPIT
     if args.arch == "rsh":
         import RSH as arch_mod
@@ -332,7 +319,7 @@ def main():
     # Untimed extra pass for the roofline's "standalone" figure: the same step with the engine's co-scheduling of
     # weight-gradient GEMMs and recurrences switched off, so every launch has the device to itself.
     prof_alone = None
-    if not args.no_kernel_events and model._engine is not None and model._engine.overlap:
+    if standalone_pass and not args.no_kernel_events and model._engine is not None and model._engine.overlap:
         model._engine.overlap = False
         step()
         torch.cuda.synchronize()
@@ -469,11 +456,106 @@ def main():
             P = sum(2 * 4 * H * ((257 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257 * S
         res["step_tflops"] = round(6.0 * P * frames_per_step / world / (dt / args.steps) / 1e12, 2)
         res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / peak, 4)   # the compute dtype's dense MFMA peak
+    return res, (pcms, T_mean)
+
+
+# The other BASELINE.json configurations that fit one GPU, timed by the DEFAULT run after the headline's timed region (same
+# process, same harness, their own model / optimizer / resident batches), so that the driver's one line witnesses them too:
+#   ragged        SURVEY.md 8d's variable-length set (the WSJ0-2mix-SHAPED batches `north_star` names), fp32, packed rows
+#   bf16_3spk     BASELINE configs[3]: 3-speaker uPIT (6-permutation PIT loss), bf16, 32 x 400
+#   bf16_ragged   the same arithmetic on the variable-length set (2 speakers, as the ragged set is defined)
+#   rsh_4spk      BASELINE configs[4]'s one-GPU shape: RSH 2 x 600, 4 speakers, 32 x 400
+SECONDARY = (
+    ("ragged", dict(ragged=True)),
+    ("bf16_3spk", dict(dtype="bf16", num_spk=3)),
+    ("bf16_ragged", dict(dtype="bf16", ragged=True)),
+    ("rsh_4spk", dict(arch="rsh", hidden=600, layers=2, num_spk=4)),
+)
+SECONDARY_STEPS, SECONDARY_WARMUP = 20, 3
+
+
+def is_headline(args):
+    """True when the command line asks for BASELINE configs[1] itself (no workload flag given)."""
+    d = parse([])
+    return all(getattr(args, k) == getattr(d, k) for k in
+               ("hidden", "layers", "num_spk", "batch", "frames", "dtype", "ragged", "padded_rows", "arch"))
+
+
+def secondary_workloads(args, env, only=None):
+    """{name: {value, ms_per_step, frames_per_step, dtype, step_frac_of_mfma_peak, by_kernel, ...}} for SECONDARY.  A
+    workload that fails is reported as {"error": ...}: the headline line is printed either way."""
+    out = {}
+    for name, over in SECONDARY:
+        if only and name not in only:
+            continue
+        a = argparse.Namespace(**vars(args))
+        a.steps, a.warmup, a.no_kernel_events, a.aux = SECONDARY_STEPS, SECONDARY_WARMUP, False, False
+        for k, v in over.items():
+            setattr(a, k, v)
+        log("secondary workload %s" % name)
+        try:
+            r, _ = measure(a, env, standalone_pass=False)
+        except (Exception, SystemExit) as e:            # noqa: BLE001 -- reported, not swallowed
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            log("secondary workload %s FAILED: %s" % (name, out[name]["error"]))
+            continue
+        finally:
+            import gc
+            gc.collect()
+            env.torch.cuda.empty_cache()
+        rf = r.get("roofline", {})
+        out[name] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                     "warmup": r["warmup"], "frames_per_step": r["config"]["frames_per_step"], "dtype": r["dtype"],
+                     "workload": r["config"]["workload"], "numerics": r["config"]["numerics"],
+                     "mean_loss": r["config"]["mean_loss"], "step_tflops": r.get("step_tflops"),
+                     "step_frac_of_mfma_peak": r.get("step_frac_of_mfma_peak"),
+                     "roofline_kernel": rf.get("kernel"), "roofline_frac": rf.get("frac"),
+                     "by_kernel": {k: {f: v[f] for f in ("ms_per_step", "achieved", "frac", "us_per_time_step", "handoff_us")
+                                       if f in v} for k, v in rf.get("by_kernel", {}).items()}}
+        if "lstm_fallback" in r:
+            out[name]["lstm_fallback"] = r["lstm_fallback"]
+        log("secondary workload %s: %.3f ms/step, %.0f frames/s" % (name, r["ms_per_step"], r["value"]))
+    return out
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                           # never returns
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit("bench.py --gpus %d under a launcher that started %d ranks" % (args.gpus, world))
+    # rehearsal on a 1-GPU box: SEPKERN_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 (use with
+    # SEPKERN_DIST_BACKEND=gloo and SEPKERN_LSTM_MODE=2, since two processes cannot both keep a
+    # persistent grid resident on one GPU)
+    if os.environ.get("SEPKERN_BENCH_ONE_DEVICE") == "1":
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
+    torch.cuda.set_device(local)
+    # rehearsals only: SEPKERN_LSTM_MODE_BY_RANK="0,2" gives every rank its own recurrence mode (one persistent grid beside
+    # ranks that launch per step: the chunked gradient exchange then runs next to a persistent kernel on a one-GPU box)
+    by_rank = os.environ.get("SEPKERN_LSTM_MODE_BY_RANK")
+    if by_rank:
+        os.environ["SEPKERN_LSTM_MODE"] = by_rank.split(",")[rank % len(by_rank.split(","))]
+    from sepkern import dist as skdist
+    skdist.init_from_env()                                # nccl (= RCCL over xGMI) unless SEPKERN_DIST_BACKEND says otherwise
+
+    from sepkern import _lib
+    _lib.load()
+    env = argparse.Namespace(torch=torch, dist=dist, skdist=skdist, world=world, rank=rank, local=local)
+    res, aux_in = measure(args, env)
     if args.aux and rank == 0:
-        res["aux"] = aux_kernels(torch, ops, pcms, T_mean, B, S)
+        from sepkern import ops
+        res["aux"] = aux_kernels(torch, ops, aux_in[0], aux_in[1], args.batch, args.num_spk)
+    if world == 1 and not args.no_secondary and is_headline(args):
+        res["secondary"] = secondary_workloads(args, env, only=[s for s in args.secondary_only.split(",") if s])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("timing the CPU baseline (bounded sample)")
-        res["cpu_baseline"] = cpu_baseline(H, L, S, B, T)
+        res["cpu_baseline"] = cpu_baseline(args.hidden, args.layers, args.num_spk, args.batch, args.frames)
         log("CPU baseline done: %s frames/s on %d threads" % (res["cpu_baseline"]["value"], res["cpu_baseline"]["cores"]))
     if rank == 0:
         print(json.dumps(res), flush=True)

@@ -10,15 +10,11 @@ not-yet-used-source minimum (archs/RSH.py:225-244, sk_rsh_loss_fwd/bwd); the att
 relu(att - mask) in training and att - mask at test time (archs/RSH.py:254-257, 278-281, sk_att_update).
 Conf keys beyond the reference: hidden_dim (600), num_layers (2).  There is no CPU path.
 """
-import collections.abc
 import os
-import re
-import shutil
 import sys
 
 import numpy as np
 import torch
-from torch.nn.utils.rnn import pack_sequence
 from torch.utils.data import Dataset
 from torch.utils.data.dataloader import default_collate
 
@@ -33,6 +29,7 @@ except ImportError:  # the frozen copy exp/<...>/arch.py is imported from anothe
     import sepkern  # noqa: F401
 from sepkern import dist as skdist
 from sepkern import ops
+from sepkern.collate import collate_sorted, eval_magnitudes, read_scp, stage_copies, train_sample
 from sepkern._lib import SepkernError
 from sepkern.model import SepDNNBase, to_padded as _to_padded
 
@@ -56,23 +53,12 @@ class MultiSpkBatch():
     self.sub_batches.append(elem)
 
 
-# Define collating function (that constructs packed sequences from a batch)
 class Collator():
   """Groups a batch by speaker count ('num_spk' entry at test time, number of source keys otherwise) and
   collates every group as archs/uPIT.py does (reference archs/RSH.py:21-68)."""
 
   def __init__(self, sort_key):
     self.key = sort_key
-
-  def collate_sub_batch(self, batch):
-    if isinstance(batch[0], collections.abc.Mapping):
-      sort_inds = np.argsort(np.array([len(d[self.key]) for d in batch]))[::-1]
-      return {key: self.collate_sub_batch([batch[i][key] for i in sort_inds]) for key in batch[0]}
-    if isinstance(batch[0], np.ndarray):
-      if re.search('[SaUO]', batch[0].dtype.str) is not None:
-        raise TypeError("batch must contain tensors, numbers, dicts or lists; found {}".format(batch[0].dtype))
-      return pack_sequence([(torch.from_numpy(b)).float() for b in batch])
-    return default_collate(batch)
 
   def __call__(self, batch):
     if not self.key:
@@ -86,12 +72,8 @@ class Collator():
     for num_spk in range(max_spk + 1):
       inds = [i for i in range(len(batch)) if counts[i] == num_spk]
       batch_out.sub_batch_lens.append(len(inds))
-      batch_out.append(self.collate_sub_batch([batch[i] for i in inds]) if inds else {})
+      batch_out.append(collate_sorted([batch[i] for i in inds], self.key) if inds else {})
     return batch_out
-
-
-def _read_scp(path):
-  return [line.rstrip('\n').split(' ')[1] for line in open(path)]
 
 
 def _combo(mix_mag_spec):
@@ -99,20 +81,13 @@ def _combo(mix_mag_spec):
   return np.concatenate((mix_mag_spec, np.ones(mix_mag_spec.shape)), axis=1)
 
 
-# Define dataset
 class TrainSet(Dataset):
+  """feats_train.scp -> {'combo': [mixture | attention of ones] (T,2F), 'source1': (T,F), ...} (archs/RSH.py:90-118)."""
 
   def __init__(self, datadir, location=""):
-    self.list = _read_scp(datadir + "/feats_train.scp")
+    self.list = read_scp(datadir + "/feats_train.scp")
     if location:
-      staged = []
-      for path in self.list:
-        dst = location + '/' + path
-        os.makedirs(os.path.dirname(dst), exist_ok=True)
-        if not os.path.exists(dst):
-          shutil.copy2(path, dst)
-        staged.append(dst)
-      self.list = staged
+      self.list = stage_copies(self.list, location)
     self.collator = Collator('combo')
 
   def __len__(self):
@@ -124,30 +99,23 @@ class TrainSet(Dataset):
     return [npz_frames(path) for path in self.list]
 
   def __getitem__(self, idx):
-    feat = np.load(self.list[idx])
-    mix_mag_spec = feat['mix'].transpose()
-    sample = {'combo': _combo(mix_mag_spec)}
-    if len(feat.files) == 1:
-      sample["source1"] = mix_mag_spec
-    else:
-      for src in range(len(feat.files) - 1):
-        sample["source" + str(src + 1)] = feat['s' + str(src + 1)].transpose()
-    return sample
+    return train_sample(self.list[idx], mix_key='combo', mix_map=_combo)
 
 
 class TestSet(Dataset):
+  """feats_test.scp + utt2num_spk -> {'combo', 'name', 'num_spk'} (archs/RSH.py:120-138)."""
 
   def __init__(self, datadir):
-    self.list = _read_scp(datadir + "/feats_test.scp")
-    self.num_spks = [int(line.rstrip('\n').split(' ')[1]) for line in open(datadir + "/utt2num_spk")]
+    self.list = read_scp(datadir + "/feats_test.scp")
+    self.num_spks = [int(v) for v in read_scp(datadir + "/utt2num_spk")]
     self.collator = Collator('combo')
 
   def __len__(self):
     return len(self.list)
 
   def __getitem__(self, idx):
-    mix_mag_spec = np.abs(np.load(self.list[idx])['mix']).transpose()
-    return {'combo': _combo(mix_mag_spec), 'name': os.path.basename(self.list[idx]), 'num_spk': self.num_spks[idx]}
+    mags, name = eval_magnitudes(self.list[idx])
+    return {'combo': _combo(mags), 'name': name, 'num_spk': self.num_spks[idx]}
 
 
 class _PassLossFn(torch.autograd.Function):
@@ -185,7 +153,6 @@ class _AttFn(torch.autograd.Function):
     return dx, dmask, None
 
 
-# define nnet
 class SepDNN(SepDNNBase):
   def __init__(self, gpuid, **kwargs):
     super(SepDNN, self).__init__()
@@ -259,7 +226,6 @@ def compute_loss_padded(model, groups, plotdir=""):
   return loss / norm, norm
 
 
-# define training pass
 def compute_loss(model, epoch, batch_sample, plotdir=""):
   dev = model.lin.weight.device
   groups = []
@@ -272,7 +238,6 @@ def compute_loss(model, epoch, batch_sample, plotdir=""):
   return compute_loss_padded(model, groups, plotdir)
 
 
-# define test pass
 def estimate_masks(model, batch_sample):
   """The arithmetic half of compute_masks: [(file name, {'s1': (257,T_i) float32, ...}), ...] for one batch."""
   dev = model.lin.weight.device

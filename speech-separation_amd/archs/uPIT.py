@@ -22,17 +22,13 @@ Beyond the reference (all optional, defaults reproduce it):
   * under torch.distributed (one process per GPU) gradients are all-reduced over RCCL inside
     backward and the loss is normalised by the GLOBAL frame count.
 """
-import collections.abc
 import itertools
 import os
-import re
-import shutil
 import sys
 
 import numpy as np
 import torch
 import torch.nn as nn
-from torch.nn.utils.rnn import PackedSequence, pack_sequence, pad_packed_sequence
 from torch.utils.data import Dataset
 from torch.utils.data.dataloader import default_collate
 
@@ -47,59 +43,36 @@ except ImportError:  # the frozen copy exp/<...>/arch.py is imported from anothe
     import sepkern  # noqa: F401
 from sepkern import dist as skdist
 from sepkern import ops
-from sepkern.model import SepDNNBase, to_packed as _to_packed
+from sepkern.collate import collate_sorted, eval_magnitudes, read_scp, stage_copies, train_sample
+from sepkern.model import SepDNNBase, UnpackFn, to_packed as _to_packed
 from sepkern.packing import Packing
 from sepkern._lib import SepkernError
 
 
-# Define collating function (that constructs packed sequences from a batch)
 class Collator():
-  """Same contract as the reference Collator (archs/uPIT.py:23-48): dict samples are sorted by
-  the length of `sort_key` (descending, via argsort()[::-1]) and every ndarray entry becomes a
-  float32 PackedSequence; everything else goes through default_collate."""
+  """Same contract as the reference Collator (archs/uPIT.py:23-48): dict samples are sorted by the length of `sort_key`
+  (descending, via argsort()[::-1]) and every ndarray entry becomes a float32 PackedSequence; everything else goes
+  through default_collate (sepkern.collate)."""
 
   def __init__(self, sort_key):
     self.key = sort_key
-    if not self.key:
+    if not sort_key:       # (the text a user of the reference sees)
       print("Warning: you have not provided a sort key.")
       print("  If you are using RNNs with variable-length input, you must")
       print("  provide the key for element in each sample that is the input")
       print("  of variable length.")
 
   def __call__(self, batch):
-    if not self.key:
-      return default_collate(batch)
-    if isinstance(batch[0], collections.abc.Mapping):
-      sort_inds = np.argsort(np.array([len(d[self.key]) for d in batch]))[::-1]
-      return {key: self.__call__([batch[i][key] for i in sort_inds]) for key in batch[0]}
-    if isinstance(batch[0], np.ndarray):
-      if re.search('[SaUO]', batch[0].dtype.str) is not None:
-        raise TypeError("batch must contain tensors, numbers, dicts or lists; found {}".format(batch[0].dtype))
-      return pack_sequence([(torch.from_numpy(b)).float() for b in batch])
-    return default_collate(batch)
+    return collate_sorted(batch, self.key) if self.key else default_collate(batch)
 
 
-def _read_scp(path):
-  return [line.rstrip('\n').split(' ')[1] for line in open(path)]
-
-
-# Define dataset
 class TrainSet(Dataset):
   """feats_train.scp -> {'mix': (T,F), 'source1': (T,F), ...} (reference archs/uPIT.py:51-79)."""
 
   def __init__(self, datadir, location=""):
-    filelist = datadir + "/feats_train.scp"
-    self.list = _read_scp(filelist)
+    self.list = read_scp(datadir + "/feats_train.scp")
     if location:
-      # the reference shells out to tools/copy_scp_data_to_dir.sh (rsync); same effect, in-process
-      staged = []
-      for path in self.list:
-        dst = location + '/' + path
-        os.makedirs(os.path.dirname(dst), exist_ok=True)
-        if not os.path.exists(dst):
-          shutil.copy2(path, dst)
-        staged.append(dst)
-      self.list = staged
+      self.list = stage_copies(self.list, location)
     self.collator = Collator('mix')
 
   def __len__(self):
@@ -111,30 +84,22 @@ class TrainSet(Dataset):
     return [npz_frames(path) for path in self.list]
 
   def __getitem__(self, idx):
-    feat = np.load(self.list[idx])
-    mix_mag_spec = feat['mix'].transpose()
-    sample = {'mix': mix_mag_spec}
-    if len(feat.files) == 1:
-      sample["source1"] = mix_mag_spec
-    else:
-      for src in range(len(feat.files) - 1):
-        sample["source" + str(src + 1)] = feat['s' + str(src + 1)].transpose()
-    return sample
+    return train_sample(self.list[idx])
 
 
 class TestSet(Dataset):
   """feats_test.scp -> {'mix': |complex STFT| (T,F), 'name': '<id>.npz'} (reference archs/uPIT.py:81-94)."""
 
   def __init__(self, datadir):
-    self.list = _read_scp(datadir + "/feats_test.scp")
+    self.list = read_scp(datadir + "/feats_test.scp")
     self.collator = Collator('mix')
 
   def __len__(self):
     return len(self.list)
 
   def __getitem__(self, idx):
-    mix_mag_spec = np.abs(np.load(self.list[idx])['mix']).transpose()
-    return {'mix': mix_mag_spec, 'name': os.path.basename(self.list[idx])}
+    mags, name = eval_magnitudes(self.list[idx])
+    return {'mix': mags, 'name': name}
 
 
 class WavTrainSet(Dataset):
@@ -217,7 +182,6 @@ class _PitFn(torch.autograd.Function):
     return (dmask, None, None, None) + (None,) * len(srcs)
 
 
-# define nnet
 class SepDNN(SepDNNBase):
   def __init__(self, gpuid, **kwargs):
     super(SepDNN, self).__init__()
@@ -248,7 +212,10 @@ class SepDNN(SepDNNBase):
     x2d, pk = _to_packed(x, self.lin.weight.device)
     mask = self.forward_packed(x2d, pk)
     # (padded frames: the constant the reference's BatchNorm / Linear / sigmoid produce there, archs/uPIT.py:135-144)
-    return pk.unpack(mask, fill=None if pk.uniform else self._engine.pad_row()).permute(1, 0, 2)
+    fill = None if pk.uniform else self._engine.pad_row()
+    if mask.requires_grad and not pk.uniform:       # (uniform: unpack is a view, differentiable as it is)
+      return UnpackFn.apply(mask, pk, fill).permute(1, 0, 2)
+    return pk.unpack(mask, fill=fill).permute(1, 0, 2)
 
 
 def compute_cv_loss(model, epoch, batch_sample, plotdir=""):
@@ -312,7 +279,6 @@ def compute_loss_padded(model, mix, sources, lens, plotdir=""):
   return out
 
 
-# define training pass
 def compute_loss(model, epoch, batch_sample, plotdir=""):
   dev = model.lin.weight.device
   if 'pcm' in batch_sample:        # WavTrainSet batches: features are computed on the GPU
@@ -326,7 +292,6 @@ def compute_loss(model, epoch, batch_sample, plotdir=""):
   return compute_loss_packed(model, mix, sources, pk, plotdir)
 
 
-# define test pass
 def estimate_masks(model, batch_sample):
   """The arithmetic half of compute_masks: [(file name, {'s1': (257,T_i) float32, ...}), ...] for one batch, without
   touching the disk (steps/eval_qsub.py overlaps the zlib compression of one batch with the next batch's GPU work)."""

@@ -62,12 +62,22 @@ class Prefetcher:
     import threading
     self.loader, self.device, self.depth = loader, device, max(1, int(depth))
     self._queue_mod, self._threading = queue, threading
+    self._stuck = None          # a staging thread that did not end when its consumer left early
 
   def __len__(self):
     return len(self.loader)
 
   def __iter__(self):
     import torch
+    if self._stuck is not None:
+      if self._stuck.is_alive():
+        raise RuntimeError("Prefetcher: the staging thread of an earlier, abandoned pass is still inside the loader; "
+                           "two threads must not share one loader iterator")
+      self._stuck = None
+    # The loader's iterator is made HERE, in the consumer's thread (with persistent workers: the worker processes are
+    # started -- forked -- from this thread, not from a side thread of a process that holds the GPU, and a new pass
+    # resets the same iterator only after the previous pass's thread is known to have left it).
+    it = iter(self.loader)
     q = self._queue_mod.Queue(maxsize=self.depth)
     stop = self._threading.Event()
     dev = torch.device(self.device)
@@ -89,7 +99,6 @@ class Prefetcher:
       try:
         torch.cuda.set_device(dev)
         with torch.cuda.stream(stream):
-          it = iter(self.loader)
           while True:
             t0 = time.perf_counter()
             try:
@@ -130,8 +139,12 @@ class Prefetcher:
           t.record_stream(cur)             # allocated on the copy stream's pool, consumed on this one
         yield staged
     finally:
+      # (normal end: the thread has put _END and is gone.  Early exit -- an exception in the step, a break: it may be
+      # blocked in next(it); it returns as soon as the loader hands over that batch, finds `stop` set and leaves.)
       stop.set()
-      th.join(timeout=30)
+      th.join(timeout=60)
+      if th.is_alive():
+        self._stuck = th
 
   @staticmethod
   def _tensors(staged):

@@ -2,7 +2,9 @@
 
 The reference is single-GPU (steps/qsub_train.sh:5 `-l gpu=1`); this is new functionality whose
 contract is "same update as one device seeing the global batch" for everything except BatchNorm,
-whose batch statistics stay per-rank (as torch's DistributedDataParallel does by default):
+whose BATCH statistics stay per-rank (as under torch's DistributedDataParallel without SyncBatchNorm; DDP keeps the
+RUNNING statistics consistent by re-broadcasting the buffers from rank 0 at every forward -- here the ranks' running
+statistics are averaged once per epoch, before anything is scored or saved: average_bn_buffers):
   * utterances are sharded by index across ranks (no data-path collective),
   * the PIT loss of every rank is divided by the GLOBAL norm sum(len)*F (one scalar all-reduce,
     known before the forward pass because it depends on lengths only),
@@ -105,8 +107,8 @@ class GradReducer:
 
     Why it is opt-in: the persistent recurrence needs its workgroups co-resident (224 of 256 CUs at 3x896 / batch 32);
     an RCCL kernel that holds more CUs than the grid leaves free would park some of them behind it (bounded spins: a
-    skipped step, never a wrong one).  init_from_env caps NCCL_MAX_NCHANNELS for this mode; the fp32 step hides ~2 ms
-    of a 37 ms step with it, the bf16 step ~2 of 14.6."""
+    skipped step, never a wrong one).  init_from_env caps NCCL_MAX_NCHANNELS for this mode.  What it hides of the exchange
+    has not been measured: RCCL has not run on hardware yet (tools/scale_sweep.py times both modes on a node)."""
 
     def __init__(self):
         self.comm = None
@@ -197,6 +199,42 @@ def broadcast_model(model, src=0):
             dist.broadcast(p.data, src)
     for b in model.buffers():
         dist.broadcast(b, src)
+
+
+def average_bn_buffers(model):
+    """One set of BatchNorm running statistics on every rank.  Without sync_bn each rank's running_mean / running_var are
+    moving averages of ITS OWN batches' statistics, and nothing in a training step exchanges them: a cross-validation pass
+    sharded over the ranks would score every shard with different statistics, and the checkpoint would hold rank 0's --
+    the printed CV loss would not be the loss of the .mdl written beside it.  The reference has one model, hence one set
+    of statistics that scores and is saved (steps/train_qsub.py:124-152).  Called by the training driver after every
+    epoch's last step (before the CV pass, the checkpoint and final.mdl), by all ranks together.
+
+    Rule: running_mean / running_var <- the mean over ranks, weighted by each rank's num_batches_tracked (equal under
+    EpochShards, which gives every rank the same number of steps: then a plain mean); num_batches_tracked <- the maximum.
+    The moving average is linear in the batch statistics, so the averaged running_mean IS the moving average of the
+    mean-over-ranks of the batch means, i.e. of the global batch's mean when the ranks hold equally many frames
+    (balanced_deal), and the averaged running_var is the moving average of the mean within-rank variance -- what each
+    rank's train-mode forward actually normalises with.  Averaging rather than broadcasting rank 0's (DDP's rule) uses
+    every rank's data and is symmetric in the ranks.  One all-reduce of 2 x 2H + 1 floats and one of an int64; no host
+    sync.  A model without such buffers, or a single process: no-op."""
+    if not is_parallel():
+        return
+    named = list(model.named_buffers())
+    stats = [b for n, b in named if n.endswith(("running_mean", "running_var"))]
+    counts = [b for n, b in named if n.endswith("num_batches_tracked")]
+    if not stats:
+        return
+    w = counts[0].detach().to(torch.float32).clamp(min=1.0).reshape(1) if counts else stats[0].new_ones(1)
+    flat = torch.cat([b.detach().reshape(-1).to(torch.float32) * w for b in stats] + [w])
+    dist.all_reduce(flat)
+    flat = flat[:-1] / flat[-1]
+    off = 0
+    with torch.no_grad():
+        for b in stats:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+        for c in counts:
+            dist.all_reduce(c, op=dist.ReduceOp.MAX)
 
 
 # ----------------------------------------------------------------------------- who trains on what, per epoch

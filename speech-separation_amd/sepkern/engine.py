@@ -335,7 +335,11 @@ class Engine:
                 wih_gi, bsum, Ip = ahead[l]
             else:
                 wih_gi, bsum, Ip = weights_of(l, I)
-            if Ip != I or inp.shape[0] < Rp or not inp.is_contiguous():
+            # The weight gradients contract over all Rp rows of `inp` and rely on ZERO tail rows R..Rp.  The layers above
+            # the first read y = pk.rows() (zero tail by construction); the caller's x2d is only known to hold R rows, so
+            # it is taken as it is only when there is no tail (R == Rp) -- whatever lies behind row R of a larger buffer
+            # (another batch, NaN) never enters a product.
+            if Ip != I or inp.shape[0] < Rp or not inp.is_contiguous() or (l == 0 and Rp > R):
                 inp = ops.pad_rows(inp[:R], Ip, rows=Rp)   # one pass, no memset (F = 257 -> 260; tail rows zero)
             gx = pk.rows(8 * H)                              # (Rp, 2, 4H): projections -> saved gates -> dgx, in place
             self._proj(cache, inp, wih_gi, gx, bsum, R)

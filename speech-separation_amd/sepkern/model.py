@@ -68,6 +68,22 @@ class NetFn(torch.autograd.Function):
     return None, None, dx, None, dh0, dc0, None, None
 
 
+class UnpackFn(torch.autograd.Function):
+  """padded (T, B, C) = unpack(packed rows (R, C)) with `fill` at the padded positions; backward is the opposite row mover
+  (sk_pack_rows of the incoming gradient: padded positions carry no gradient into the network -- their value is a constant
+  of the batch as far as this graph goes).  Keeps `model(x)` (reference loop: archs/uPIT.py:175, mask_out = model(mix) ->
+  loss -> backward) differentiable on variable-length batches, where Packing.unpack is a raw kernel launch."""
+
+  @staticmethod
+  def forward(ctx, packed, pk, fill):
+    ctx.pk, ctx.R = pk, packed.shape[0]
+    return pk.unpack(packed, fill=fill)
+
+  @staticmethod
+  def backward(ctx, dpadded):
+    return ctx.pk.pack(dpadded.contiguous())[:ctx.R], None, None
+
+
 class SepDNNBase(nn.Module):
   """BLSTM(in_dim -> H, L layers, bidirectional) -> BatchNorm1d(2H) -> Linear(2H -> out_dim) -> sigmoid."""
 

@@ -11,7 +11,8 @@ What is organised differently here, on the host side only:
   * clip + Adam run fused over the model's flat parameter buffer (sepkern.optim.ClipAdam; --torch-optimizer
     restores the reference's torch calls on the same parameters);
   * under torch.distributed.run (one process per GPU) it trains data-parallel: replicas are made identical by a
-    broadcast from rank 0, every epoch's utterances are dealt to the ranks in length-balanced global batches
+    broadcast from rank 0, their BatchNorm running statistics are averaged after every epoch (sepkern.dist.
+    average_bn_buffers: the CV loss printed is the loss of the model saved), every epoch's utterances are dealt to the ranks in length-balanced global batches
     (sepkern.dist.EpochShards: same step count on every rank), gradients are summed over RCCL inside backward,
     the cross-validation set is sharded too, rank 0 writes the files;
   * checkpoints also carry the optimizer state (NNN.opt), which the reference loses on resume (:107);
@@ -236,7 +237,8 @@ def rank_of():
 def recover_from_timeout(model, optimizer, newly_skipped, epoch):
   """A persistent recurrence launch timed out (its bounded wait gave up: the grid was not co-resident).  The device
   already kept that step away from the weights on EVERY rank (the guard word is all-reduced with the gradients, so the
-  skipped count is the same everywhere and all ranks take this branch together).  Clear the sticky word, continue IN
+  skipped count is the same everywhere; train_epoch reads it at the same steps on every rank, so all ranks take this branch
+  together).  Clear the sticky word, continue IN
   THIS PROCESS with one launch per step (never re-exec a process that holds the GPU), and say so."""
   try:
     model.check_status()                 # reads and clears the workspace's sticky word
@@ -258,11 +260,11 @@ def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
   skipped-step counter is read: the loss terms of a window that contains a skipped step (garbage or NaN forwards) are
   dropped instead of poisoning the epoch's sums, and the run continues in per-step launch mode."""
   dev = next(model.parameters()).device
-  acc = torch.zeros(2, device=dev, dtype=torch.float64)
-  win = torch.zeros(2, device=dev, dtype=torch.float64)
+  # [sum(loss * norm), sum(norm), frames] of the steps that reached the weights; `win` = the same for the open window
+  acc = torch.zeros(3, device=dev, dtype=torch.float64)
+  win = torch.zeros(3, device=dev, dtype=torch.float64)
   fused = hasattr(optimizer, "skipped")
   seen = optimizer.skipped() if fused else 0
-  eng_guard = None
 
   def close_window():
     nonlocal seen, win
@@ -277,13 +279,14 @@ def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
     win = torch.zeros_like(win)
 
   t_epoch = time.perf_counter()
-  frames = torch.zeros(1, device=dev, dtype=torch.float64)
-  for i, batch in enumerate(batches):
+  steps = 0
+  for batch in batches:
+    steps += 1
     loss, norm = m.compute_loss(model, epoch, batch)
-    frames += norm.double() / world
     win[0] += loss.detach().double() * norm.double()
     # under data parallelism `norm` is already the global frame count: every rank adds its 1/world share
     win[1] += norm.double() / world
+    win[2] += norm.double() / world
     loss.backward()
     if torch_clip:
       # torch's optimizer knows nothing of the guard word: look at it here (one host sync per step on this
@@ -295,22 +298,26 @@ def train_epoch(m, model, optimizer, batches, epoch, world, torch_clip):
         continue
       torch.nn.utils.clip_grad_norm_(model.parameters(), CLIP_NORM)
     optimizer.step()
-    # (the counter's asynchronous host copy, one step behind: after a timed-out launch the run switches to per-step
-    # launches within a step or two instead of skipping every step up to the next poll)
-    if (i + 1) % POLL_EVERY == 0 or (fused and optimizer.skipped_nowait() > seen):
+    # One process: the counter's asynchronous host copy, one step behind -- after a timed-out launch the run switches to
+    # per-step launches within a step or two instead of skipping every step up to the next poll.  Several ranks: WHEN that
+    # copy lands differs from rank to rank, so only the poll at a fixed step -- whose count is the same everywhere, the
+    # guard word being all-reduced with the gradients -- may close a window: all ranks then drop the same steps' loss
+    # terms and switch the recurrence mode at the same step.
+    if steps % POLL_EVERY == 0 or (fused and world == 1 and optimizer.skipped_nowait() > seen):
       close_window()
   close_window()
   if world > 1:
     torch.distributed.all_reduce(acc)
-    torch.distributed.all_reduce(frames)
   # wall time and frames/s of the epoch as the user sees it (data loading included): stderr, the reference's stdout
-  # lines stay as they are.  norm = frames x feat_dim (archs/uPIT.py:197).  (One host sync per epoch, here.)
-  n_frames = float(frames.item()) / float(getattr(model, "feat_dim", 257))
+  # lines stay as they are.  norm = frames x feat_dim (archs/uPIT.py:197); frames of windows that were dropped after a
+  # timed-out launch are not counted.  (One host sync per epoch, here.)  An epoch without a batch (an empty shard, a
+  # resume on a tiny set) reports zero steps.
+  n_frames = float(acc[2].item()) / float(getattr(model, "feat_dim", 257))
   dt = time.perf_counter() - t_epoch
   if rank_of() == 0:
-    print("train: epoch %d: %d steps, %.0f frames in %.2f s = %.0f frames/s" % (epoch + 1, i + 1, n_frames, dt, n_frames / dt),
-          file=sys.stderr, flush=True)
-  return acc
+    print("train: epoch %d: %d steps, %.0f frames in %.2f s = %.0f frames/s"
+          % (epoch + 1, steps, n_frames, dt, n_frames / dt if dt > 0 else 0.0), file=sys.stderr, flush=True)
+  return acc[:2]
 
 
 def validation_pass(m, model, batches, epoch, world, plot_dir):
@@ -410,6 +417,9 @@ def main(argv=None):
     number = epoch + 1
     reseed_epoch(args, rank, epoch, shards, model)
     acc = train_epoch(m, model, optimizer, train_batches, epoch, world, args.torch_optimizer)
+    # one set of BatchNorm running statistics on every rank before anything is scored or saved (the reference has one
+    # model: what scores the CV set is what the checkpoint holds, steps/train_qsub.py:124-152)
+    skdist.average_bn_buffers(model)
     checkpoint = epoch % CHECKPOINT_EVERY == CHECKPOINT_EVERY - 1
     if cv_batches is not None and checkpoint:
       cv = validation_pass(m, model, cv_batches, epoch, world,

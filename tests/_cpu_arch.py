@@ -10,12 +10,14 @@ from oracle import upit as OU
 from sepkern import dist as skdist
 
 F, H, L = 33, 12, 2
-_N, _SEED = 8, 0
+_N, _SEED, _BN_TRAIN = 8, 0, False
 
 
-def configure(n, seed):
-    global _N, _SEED
-    _N, _SEED = n, seed
+def configure(n, seed, bn_train=False):
+    """bn_train=True: BatchNorm stays in train mode while training (per-rank batch statistics, per-rank running statistics
+    -- what the product does without sync_bn); the default keeps it in eval mode so that data-parallel == single process."""
+    global _N, _SEED, _BN_TRAIN
+    _N, _SEED, _BN_TRAIN = n, seed, bool(bn_train)
 
 
 class TrainSet(Dataset):
@@ -43,14 +45,16 @@ class TrainSet(Dataset):
 class SepDNN(OU.OracleSepDNN):
     def __init__(self, gpuid, **kwargs):
         super().__init__(feat_dim=F, num_spk=2, hidden_dim=H, num_layers=L)
-        self.bn.eval()
+        if not _BN_TRAIN:
+            self.bn.eval()
 
     def cuda(self):
         return self
 
     def train(self, mode=True):
         super().train(mode)
-        self.bn.eval()
+        if not _BN_TRAIN:
+            self.bn.eval()
         return self
 
 

@@ -134,6 +134,93 @@ def test_dp_training_equals_single_process_on_the_same_global_batches(world, n, 
             np.testing.assert_allclose(losses, one[1], rtol=5e-2)     # same data but for the duplicated utterance
 
 
+def _bn_worker(rank, world, port, tmp, out):
+    for p in (ROOT, PKG, TESTS, os.path.join(PKG, "steps")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    import _cpu_arch as m
+    import train_qsub as drv
+    from sepkern import dist as skdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), SEPKERN_DIST_BACKEND="gloo")
+    skdist.init_from_env()
+    m.configure(12, 3, bn_train=True)
+    torch.manual_seed(1000 + 77 * rank)
+    model = m.SepDNN(0)
+    model.train()
+    skdist.broadcast_model(model)
+    opt = m.SummingAdam(model, 1e-2)
+    ds = m.TrainSet("train")
+    shards = skdist.EpochShards(len(ds), 3, rank, world, lengths=ds.frame_counts(), seed=5)
+    loader = torch.utils.data.DataLoader(ds, batch_sampler=shards, collate_fn=ds.collator)
+    assert len(shards) == 2                                            # two steps on different shards
+    shards.set_epoch(0)
+    drv.train_epoch(m, model, opt, loader, 0, world, False)
+    before = [model.bn.running_mean.clone(), model.bn.running_var.clone(), int(model.bn.num_batches_tracked)]
+    everyone = [torch.zeros_like(before[0]) for _ in range(world)]
+    dist.all_gather(everyone, before[0])
+    every_var = [torch.zeros_like(before[1]) for _ in range(world)]
+    dist.all_gather(every_var, before[1])
+    skdist.average_bn_buffers(model)                                   # what steps/train_qsub.py::main does after the epoch
+    after = [torch.zeros_like(before[0]) for _ in range(world)]
+    dist.all_gather(after, model.bn.running_mean)
+    after_var = [torch.zeros_like(before[1]) for _ in range(world)]
+    dist.all_gather(after_var, model.bn.running_var)
+    # the sharded CV pass, then what rank 0 would write as NNN.mdl
+    cv_ds = m.TrainSet("cv")
+    idx = skdist.shard_indices_contiguous(len(cv_ds), rank, world)
+    cv_batches = torch.utils.data.DataLoader(torch.utils.data.Subset(cv_ds, idx), batch_size=3, collate_fn=cv_ds.collator)
+    cv = drv.validation_pass(m, model, cv_batches, 0, world, "")
+    if rank == 0:
+        torch.save(model.state_dict(), os.path.join(tmp, "005.mdl"))
+    out.put((rank, [t.numpy() for t in everyone], [t.numpy() for t in every_var], [t.numpy() for t in after],
+             [t.numpy() for t in after_var], float(cv[0] / cv[1]), before[2], int(model.bn.num_batches_tracked)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_running_statistics_are_one_set_before_scoring_and_saving(tmp_path):
+    """VERDICT r04 item 2.  Two ranks train two steps on different shards with per-rank BatchNorm (no sync_bn): their running
+    statistics DIFFER after the epoch; after sepkern.dist.average_bn_buffers -- called by the driver before the CV pass and
+    the checkpoint -- they are EQUAL (the mean over ranks), and the CV value the sharded pass prints equals the loss of the
+    saved .mdl re-evaluated on the whole CV set by one process (reference: one model scores and is saved,
+    steps/train_qsub.py:124-152)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bn_worker, args=(r, world, port, str(tmp_path), out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([out.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    _, means, vars_, after, after_var, cv, nbt_before, nbt_after = res[0]
+    assert np.abs(means[0] - means[1]).max() > 1e-4 and np.abs(vars_[0] - vars_[1]).max() > 1e-4     # differ BEFORE
+    np.testing.assert_array_equal(after[0], after[1])                                              # equal AFTER
+    np.testing.assert_array_equal(after_var[0], after_var[1])
+    np.testing.assert_allclose(after[0], 0.5 * (means[0] + means[1]), rtol=1e-6, atol=1e-7)          # equal step counts: the mean
+    np.testing.assert_allclose(after_var[0], 0.5 * (vars_[0] + vars_[1]), rtol=1e-6, atol=1e-7)
+    assert nbt_before == nbt_after == 2
+    assert res[0][5] == res[1][5]                                       # every rank reports the same CV value
+    # ---- one process, the saved model, the whole CV set
+    for p in (ROOT, PKG, TESTS, os.path.join(PKG, "steps")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import _cpu_arch as m
+    import train_qsub as drv
+    m.configure(12, 3, bn_train=True)
+    model = m.SepDNN(0)
+    model.load_state_dict(torch.load(os.path.join(str(tmp_path), "005.mdl")))
+    cv_ds = m.TrainSet("cv")
+    # the same batches the two shards saw (contiguous shards of 6, batch 3): the loss is a sum over utterances either way
+    batches = torch.utils.data.DataLoader(cv_ds, batch_size=3, collate_fn=cv_ds.collator)
+    one = drv.validation_pass(m, model, batches, 0, 1, "")
+    np.testing.assert_allclose(cv, float(one[0] / one[1]), rtol=1e-6)
+
+
 def test_bench_py_launches_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the round driver calls bench.py): the parent
     starts the ranks itself -- before importing torch or touching a GPU -- and relays the worst return code.  There is no

@@ -287,6 +287,40 @@ def test_bench_line_carries_the_contract_fields():
         assert by[k]["us_per_time_step"] > by[k]["mfma_floor_us"] > 0 and by[k]["handoff_us"] > 0
 
 
+def test_bench_default_run_carries_the_secondary_block():
+    """The DEFAULT `python bench.py` (the command the round driver runs; here with fewer headline steps and without the CPU
+    baseline) also times the other one-GPU BASELINE configurations in the same process and reports them under "secondary":
+    the variable-length set (fp32 and bf16), bf16 3-speaker, RSH 4-speaker -- VERDICT r04 item 1.  The headline fields stay
+    what they were; every secondary entry is self-consistent (value = frames per step / time per step) and names its
+    workload; a run with a workload flag does not carry the block."""
+    import json
+    root = os.path.dirname(PKG)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dtype"] == "f32" and d["config"]["frames_per_step"] == 32 * 400 and "uPIT 3x896 BLSTM, 2-spk" in d["config"]["workload"]
+    sec = d["secondary"]
+    assert set(sec) == {"ragged", "bf16_3spk", "bf16_ragged", "rsh_4spk"}
+    for name, s in sec.items():
+        assert "error" not in s, (name, s)
+        for k in ("value", "ms_per_step", "frames_per_step", "dtype", "step_frac_of_mfma_peak", "by_kernel", "workload", "numerics"):
+            assert k in s, (name, k)
+        assert abs(s["value"] - s["frames_per_step"] / (s["ms_per_step"] * 1e-3)) / s["value"] < 1e-3
+        assert 0 < s["step_frac_of_mfma_peak"] <= 1 and "lstm_fallback" not in s
+        assert {"lstm_fwd_kernel", "lstm_bwd_kernel"} <= set(s["by_kernel"])
+    assert sec["ragged"]["dtype"] == "f32" and "U(24000, 64000)" in sec["ragged"]["workload"] and "packed rows" in sec["ragged"]["workload"]
+    assert 32 * 188 <= sec["ragged"]["frames_per_step"] <= 32 * 501
+    assert sec["bf16_3spk"]["dtype"] == "bf16" and "3-spk" in sec["bf16_3spk"]["workload"] and sec["bf16_3spk"]["frames_per_step"] == 12800
+    assert sec["bf16_ragged"]["dtype"] == "bf16" and "U(24000, 64000)" in sec["bf16_ragged"]["workload"]
+    assert sec["bf16_ragged"]["frames_per_step"] == sec["ragged"]["frames_per_step"]      # the same batches
+    assert "RSH 2x600" in sec["rsh_4spk"]["workload"] and "4-spk" in sec["rsh_4spk"]["workload"]
+    # the bf16 configurations are faster than their fp32 counterparts, the ragged step is not slower than the uniform one
+    assert sec["bf16_3spk"]["ms_per_step"] < d["ms_per_step"] and sec["bf16_ragged"]["ms_per_step"] < sec["ragged"]["ms_per_step"]
+
+
 def test_staged_batches_equal_the_plain_loader_and_keep_up_with_the_step(tmp_path):
     """steps/train_qsub.py's loop through sepkern.data.Prefetcher (batches staged on the GPU ahead of their step, as packed
     rows) -- VERDICT r03 item 2:
