@@ -175,3 +175,89 @@ def test_bn_statistics_of_the_global_batch_over_two_ranks():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def _eight_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sepkern import dist as skdist
+    # a ragged corpus (WSJ0-2mix-shaped frame counts), one epoch of global batches of world x 4 utterances
+    n, bs, C = 100, 4, 6
+    lengths = [int(v) for v in np.random.default_rng(11).integers(188, 502, n)]
+    shards = skdist.EpochShards(n, bs, rank, world, lengths=lengths, seed=3)
+    shards.set_epoch(1)
+    mine = list(shards)
+    ok = len(mine) == len(shards) == -(-n // (bs * world))
+    report = []
+    for step, utts in enumerate(mine):
+        # this rank's zero-padded (B, T) grid of C-channel frames: utterance u's valid frames are a function of u alone
+        B, T = len(utts), max(lengths[u] for u in utts)
+        grid = torch.zeros(B, T, C, dtype=torch.float64)
+        for j, u in enumerate(utts):
+            g = torch.Generator().manual_seed(1000 + u)
+            grid[j, :lengths[u]] = torch.randn(lengths[u], C, generator=g, dtype=torch.float64) * (1 + u % 3) + (u % 5)
+        x = grid.view(B * T, C)
+        mean, var, total = skdist.combine_bn_stats(x.mean(0), x.var(0, unbiased=False), B, T)
+        dg, db = skdist.allreduce_bn_sums(x.sum(0), (x * x).sum(0))
+        # who holds what this step: every rank tells every rank (ids padded with -1)
+        ids = torch.full((bs,), -1, dtype=torch.int64)
+        ids[:B] = torch.tensor(utts)
+        every = [torch.zeros_like(ids) for _ in range(world)]
+        dist.all_gather(every, ids)
+        report.append((step, [[int(v) for v in e if v >= 0] for e in every], mean.numpy(), var.numpy(), total, dg.numpy(), db.numpy()))
+    q.put((rank, bool(ok), report if rank in (0, world - 1) else None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_shards_and_global_batchnorm_statistics_on_ragged_lengths():
+    """world_size 8 on CPU (the node's rank count): EpochShards + balanced_deal give every rank the same
+    number of steps, every utterance exactly once (the short last global batch dealt unequally: 100 = 3 x 32 + 4, so four ranks
+    are topped up), near-equal frames per rank; combine_bn_stats / allreduce_bn_sums over the eight ranks' DIFFERENT grids
+    (own batch size, own longest utterance) equal the statistics of the global batch's zero-padded
+    (sum of B) x (longest utterance of any rank) grid computed in one process."""
+    world, n, bs, C = 8, 100, 4, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    lengths = [int(v) for v in np.random.default_rng(11).integers(188, 502, n)]
+    rep0, rep7 = res[0][2], res[-1][2]
+    seen = []
+    for (step, every, mean, var, total, dg, db), other in zip(rep0, rep7):
+        sizes = [len(e) for e in every]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+        if min(sizes) == bs:
+            frames = [sum(lengths[u] for u in e) for e in every]
+            assert max(frames) <= 1.10 * min(frames), frames                  # the slowest rank sets the step
+        seen += [u for e in every for u in e]
+        # one process, the global batch's grid
+        Tg = max(lengths[u] for e in every for u in e)
+        rows = []
+        for e in every:
+            for u in e:
+                g = torch.Generator().manual_seed(1000 + u)
+                grid = torch.zeros(Tg, C, dtype=torch.float64)
+                grid[:lengths[u]] = torch.randn(lengths[u], C, generator=g, dtype=torch.float64) * (1 + u % 3) + (u % 5)
+                rows.append(grid)
+        allx = torch.cat(rows)
+        assert total == float(allx.shape[0]) == float(sum(sizes) * Tg)
+        np.testing.assert_allclose(mean, allx.mean(0).numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(var, allx.var(0, unbiased=False).numpy(), rtol=1e-9)
+        np.testing.assert_allclose(dg, allx.sum(0).numpy(), rtol=1e-10)
+        np.testing.assert_allclose(db, (allx * allx).sum(0).numpy(), rtol=1e-10)
+        # every rank computed the same global statistics
+        np.testing.assert_array_equal(mean, other[2])
+        np.testing.assert_array_equal(var, other[3])
+    assert set(seen) == set(range(n)) and len(seen) == n + 4          # 4 utterances in the last global batch, 8 ranks: 4 top-ups
