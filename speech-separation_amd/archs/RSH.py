@@ -175,7 +175,8 @@ class SepDNN(SepDNNBase):
 
   def forward(self, x):
     xp, lens = _to_padded(x, self.lin.weight.device)
-    return self.forward_padded(xp, lens).permute(1, 0, 2)
+    # (batch-first and contiguous, as the reference's output is: its loss code takes .view(batch, -1), archs/RSH.py:229)
+    return self.forward_padded(xp, lens).permute(1, 0, 2).contiguous()
 
 
 def compute_cv_loss(model, epoch, batch_sample, plotdir=""):

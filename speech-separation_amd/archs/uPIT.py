@@ -214,8 +214,12 @@ class SepDNN(SepDNNBase):
     # (padded frames: the constant the reference's BatchNorm / Linear / sigmoid produce there, archs/uPIT.py:135-144)
     fill = None if pk.uniform else self._engine.pad_row()
     if mask.requires_grad and not pk.uniform:       # (uniform: unpack is a view, differentiable as it is)
-      return UnpackFn.apply(mask, pk, fill).permute(1, 0, 2)
-    return pk.unpack(mask, fill=fill).permute(1, 0, 2)
+      padded = UnpackFn.apply(mask, pk, fill)
+    else:
+      padded = pk.unpack(mask, fill=fill)
+    # batch-first AND contiguous, as the reference's Linear + sigmoid output is: its own loss code takes .view(batch, -1) of an
+    # elementwise result of this tensor (archs/uPIT.py:192), which a permuted view would refuse
+    return padded.permute(1, 0, 2).contiguous()
 
 
 def compute_cv_loss(model, epoch, batch_sample, plotdir=""):

@@ -623,8 +623,14 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       {
         const float* hp = &hs[(kh * NQ) * 256 + lane * 4];
+#ifdef SK_TAIL_HALF
+        const bool tail = PK && B > 16 && s >= a.lens[16];  // see SK_TAIL_HALF at BwdCfg
+#endif
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
+#ifdef SK_TAIL_HALF
+          if (tail && (q & 1)) continue;
+#endif
           if (S3) {
             // nine exact piece products per 32 k, the small ones first; chunks alternate between two accumulators
             // the piece that is needed first is fetched first, and the nine products alternate between the two accumulators (no
@@ -793,13 +799,25 @@ struct BwdW {
   bf16x8 b[BF ? BwdCfg<KS, BF>::NQ : 1];
 };
 
+// TIMING-ONLY diagnostic (-DSK_TAIL_HALF, `make variant NAME=tailhalf DEFS=-DSK_TAIL_HALF`; never shipped, WRONG numerics): an
+// upper bound for re-partitioning the tail of a ragged batch.  Once the short batch group's streams have left the grid (the long
+// group's steps s >= lens[16], B = 32), the long group's workgroups issue only every other MFMA chunk -- what a step's product
+// would cost if the 112 idle CUs took half of it for free (same launches, same hand-off, same pulls).
+#ifdef SK_TAIL_HALF
+#define SK_TAIL_SKIP(j) if (tail && ((j) & 1)) continue;
+#else
+#define SK_TAIL_SKIP(j)
+#endif
+
 template <int KS, bool BF, int SBI>
-__device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* ring, int lane, f32x4& acc0, f32x4& acc1) {
+__device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* ring, int lane, f32x4& acc0, f32x4& acc1,
+                                            bool tail) {
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
   const float* src = ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4;
 #pragma unroll
   for (int j = 0; j < n; ++j) {
+    SK_TAIL_SKIP(j)
     const int q = SBI * C::SB + j;
     if (BF) {
       const bf16x8 db = *reinterpret_cast<const bf16x8*>(src + j * 256);  // dG[b = lane&15][k' = 32 cc + 8 (lane>>4) + 0..7]
@@ -835,12 +853,12 @@ __device__ __forceinline__ void bwd_prologue(const float* xbase, unsigned xoff, 
 // still be in flight), multiply, and refill its slot with sub-block I+DEPTH.
 template <int KS, bool BF, int I>
 __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
-                                         unsigned ring_lds, int w, int lane, f32x4& acc0, f32x4& acc1) {
+                                         unsigned ring_lds, int w, int lane, f32x4& acc0, f32x4& acc1, bool tail) {
   using C = BwdCfg<KS, BF>;
   if constexpr (I < C::NSB) {
     constexpr int younger = bwd_younger<KS, BF>(I);
     wait_vmcnt<younger>();
-    bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1);
+    bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1, tail);
     if constexpr (I + C::DEPTH < C::NSB) {
       if constexpr (C::cnt(I + C::DEPTH) > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this ring slot returned before it is refilled
@@ -848,7 +866,7 @@ __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* 
         bwd_issue<KS, BF, I + C::DEPTH>(xbase, xoff, ring_lds, w, lane);
       }
     }
-    bwd_ring<KS, BF, I + 1>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1);
+    bwd_ring<KS, BF, I + 1>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, tail);
   }
 }
 
@@ -861,7 +879,7 @@ __device__ __forceinline__ int red_slot(int m, int n) { return (m >> 1) * 32 + 1
 // Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
 template <int KS, bool BF>
 __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
-                                            float (*red)[256], int w, int lane) {
+                                            float (*red)[256], int w, int lane, bool tail = false) {
   // xbase: the exchange buffer (kernel argument: scalar), xoff: byte offset of this stream's block of the step (uniform)
   const unsigned ring_lds = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring);
   f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -869,7 +887,7 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
   // nothing may be scheduled into this region (the cell loads of the step were issued before it).
   __builtin_amdgcn_sched_barrier(0);
   bwd_prologue<KS, BF, 0>(xbase, xoff, ring_lds, w, lane);
-  bwd_ring<KS, BF, 0>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1);
+  bwd_ring<KS, BF, 0>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, tail);
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll
@@ -1022,7 +1040,11 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
           break;
         }
         SK_STAMP(0);
+#ifdef SK_TAIL_HALF
+        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane, a.offs && B > 16 && s >= a.lens[16]);
+#else
         dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
+#endif
         SK_STAMP(2);
       }
       // 3. cell backward (owner waves)

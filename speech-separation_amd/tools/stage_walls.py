@@ -29,7 +29,7 @@ def run(tag, cmd, env, out):
     t0 = time.perf_counter()
     r = subprocess.run(cmd, env=env, capture_output=True, text=True)
     dt = time.perf_counter() - t0
-    lines = [l for l in r.stderr.splitlines() if re.search(r"frames/s|skipped|timed out", l)]
+    lines = [l for l in r.stderr.splitlines() if re.search(r"frames/s|skipped|timed out|prefetch:", l)]
     out.append("%-34s %8.2f s   rc %d" % (tag, dt, r.returncode))
     for l in lines:
         out.append("      " + l.strip())
@@ -53,6 +53,8 @@ def main():
     ap.add_argument("--modes", default="ref,npz,wav")
     ap.add_argument("--conf", default="", help="extra conf lines, comma separated (e.g. dtype=bf16)")
     ap.add_argument("--epochs", type=int, default=2, help="training epochs per mode (the last one is the reported rate; > 2: a soak run)")
+    ap.add_argument("--train-args", default="", help="extra arguments for steps/train_qsub.py, space separated (e.g. '--num-workers 6')")
+    ap.add_argument("--skip-eval", action="store_true", help="training stages only")
     ap.add_argument("--keep", action="store_true", help="leave the work directory (tools/loader_probe.py reads its data dirs)")
     a = ap.parse_args()
     from sepkern import synth
@@ -81,7 +83,7 @@ def main():
             if line:
                 f.write(line + "\n")
     base = [py, os.path.join(steps, "train_qsub.py"), "uPIT", "0", d_tr]
-    common = ["--model-config", conf, "--batch-size", str(a.batch), "--num-epochs", str(a.epochs), "--seed", "3"]
+    common = ["--model-config", conf, "--batch-size", str(a.batch), "--num-epochs", str(a.epochs), "--seed", "3"] + a.train_args.split()
     modes = {"ref": ("train_qsub.py reference loop", ["--num-workers", "1", "--prefetch", "0"]),
              "npz": ("train_qsub.py npz, staged", []),
              "wav": ("train_qsub.py wav-input, staged", ["--wav-input"])}
@@ -96,9 +98,10 @@ def main():
                 rates[m] = int(g.group(1))
     exp = os.path.join(work, "exp_" + a.modes.split(",")[-1])
     masks = os.path.join(exp, "output", "masks")
-    run("eval_qsub.py (masks)", [py, os.path.join(steps, "eval_qsub.py"), os.path.join(PKG, "archs", "uPIT.py"), "0",
-                                 os.path.join(exp, "final.mdl"), d_tt, masks, "--model-config", conf, "--batch-size", str(a.batch)], env, out)
-    run("reconstruct_sources.py", [py, os.path.join(steps, "reconstruct_sources.py"), d_tt, os.path.join(exp, "output")], env, out)
+    if not a.skip_eval:
+        run("eval_qsub.py (masks)", [py, os.path.join(steps, "eval_qsub.py"), os.path.join(PKG, "archs", "uPIT.py"), "0",
+                                     os.path.join(exp, "final.mdl"), d_tt, masks, "--model-config", conf, "--batch-size", str(a.batch)], env, out)
+        run("reconstruct_sources.py", [py, os.path.join(steps, "reconstruct_sources.py"), d_tt, os.path.join(exp, "output")], env, out)
     out.append("last-epoch training rates (frames/s): " + ", ".join("%s %d" % kv for kv in rates.items()))
     print(out[-1], flush=True)
     if a.out:

@@ -74,7 +74,7 @@ def test_reference_style_loss_through_model_call_backprops(arch, lens):
     model.next_hidden = hid
     model.hidden = model.init_hidden(B)
     mask_out = model(mix)
-    assert mask_out.requires_grad and tuple(mask_out.shape) == (B, max(lens), F * S)
+    assert mask_out.requires_grad and tuple(mask_out.shape) == (B, max(lens), F * S) and mask_out.is_contiguous()
     mixes, ln = pad_packed_sequence(mix, batch_first=True)
     masked = mask_out * torch.cat([mixes for _ in range(S)], dim=2)
     perms = list(itertools.permutations(range(S)))
