@@ -87,15 +87,15 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * variant (speed only, results agree to fp32 summation order): 0 = choose -- operand tiles DMA'd straight into LDS when
  * every operand row is 16-byte aligned and K is a multiple of 16, the register-staged kernel otherwise; 1 = always
  * the register-staged kernel (the engine's choice for products it runs co-resident with a recurrence: it leaves
- * the recurrence more of the matrix pipe); 2 = exact three-way bf16 split of both operands on the bf16 matrix pipe
- * (nine exact piece products per element pair, fp32 accumulators: an fp32 product in another summation order; power-
- * bound on MI355X, opt-in); 3 = the 128 x 128-tile LDS-DMA kernel wherever it applies, 4 = its 256 x 128-tile, 8-wave form
+ * the recurrence more of the matrix pipe); 3 = the 128 x 128-tile LDS-DMA kernel wherever it applies, 4 = its 256 x 128-tile, 8-wave form
  * wherever that applies (diagnostics; 0 picks among 1, 3 and 4 by shape); 6 = 256 x 256 tiles, one PERSISTENT workgroup
  * per CU with a stream-K cut of the last partial round of tiles (unsplit, unbatched products; splitk = 1 and
  * ws >= sk_gemm_streamk_workspace_bytes(), zero-filled before its first use and left with zeroed counters by every
  * launch; without ws it is variant 4; variant 0 chooses it for the large N/T and N/N products when splitk = 1 and a ws
  * is given, SEPKERN_GEMM_STREAMK=0: never).  Tiles of the cut are summed piece by piece in a fixed order: deterministic,
- * fp32 summation order differs from the other variants.  (5 was the same tile without the stream-K cut: retired in r04.) */
+ * fp32 summation order differs from the other variants.  (2 was the exact three-way bf16 split of both operands, power-bound and neutral on the step: retired in r05; 5 was the
+ * 256 x 256 tile without the stream-K cut: retired in r04.)  Variant 4's 256 x 128 kernel is what variant 0 falls back to for a large
+ * unsplit product whose stream-K preconditions fail (no ws given, a last round too short to cut). */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 size_t sk_gemm_streamk_workspace_bytes(void);
 /* Zero the ticket counters at the head of a split-K workspace (once, before its first use; a buffer that was allocated
@@ -186,10 +186,10 @@ int sk_hprev_rows(const float* y, int ldy, const float* h0, const int32_t* offs,
  * mode bits 8..15: minimum number of 16-row batch groups a workgroup carries (0/1 = as few as fit): a larger
  * value shrinks the persistent grid, leaving CUs free for kernels running concurrently on other streams.
  * Speed-only variants of the persistent kernels (never the arithmetic, except where noted): bit 16 bf16 matrix-core
- * inputs (this one IS arithmetic: BASELINE configs[3]); bit 17 8-unit / 256-thread workgroups, two per CU; bits 18..19
+ * inputs (this one IS arithmetic: BASELINE configs[3]); bit 17 retired in r05 (8-unit / 256-thread workgroups, two per CU: slower at every shape; setting it is SK_EINVAL); bits 18..19
  * block id -> stream map; bit 20 one polling wave per workgroup; bit 21 flags replicated per XCD; bit 22 one flag per
  * 128-byte line; bits 23..27 hold-back of a step's first poll in units of 0.1 us (0 = the library's choice, 31 = none);
- * bit 28 (fp32 forward, 8-wave workgroups, H <= 896): the product h W_hh^T by the EXACT three-way bf16 split of both fp32
+ * bit 28 (fp32 forward, H <= 896): the product h W_hh^T by the EXACT three-way bf16 split of both fp32
  * operands on the bf16 matrix pipe -- x = hi + mid + lo with three bf16 pieces (24 significand bits = 3 x 8), nine exact piece
  * products per element pair added into fp32 accumulators by v_mfma_f32_16x16x32_bf16: an fp32 product in another summation
  * order (results within 2e-6 of the fp32-MFMA kernel's, no operand perturbed), 144 instead of 256 matrix-pipe cycles per 32 k.

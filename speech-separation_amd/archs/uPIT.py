@@ -43,6 +43,7 @@ except ImportError:  # the frozen copy exp/<...>/arch.py is imported from anothe
     import sepkern  # noqa: F401
 from sepkern import dist as skdist
 from sepkern import ops
+from sepkern.data import features_from_pcm as _features_from_pcm
 from sepkern.collate import collate_sorted, eval_magnitudes, read_scp, stage_copies, train_sample
 from sepkern.model import SepDNNBase, UnpackFn, to_packed as _to_packed
 from sepkern.packing import Packing
@@ -137,29 +138,16 @@ class WavTrainSet(Dataset):
 
 
 class WavCollator():
-  """Sorts by frame count (descending, as Collator does) and keeps the PCM as a list per key."""
+  """Sorts by frame count (descending, as Collator does) and hands the batch over as ONE int16 tensor: the signals of all
+  utterances, key-major ('mix', 'source1', ...), longest utterance first -- {'pcm': {'flat', 'keys', 'lens'}}.  One tensor
+  crosses from the loader's worker process to the trainer instead of 32 x (S + 1) (each of which costs a shared-memory
+  hand-over: measured 15-18 ms per batch whatever the worker count, more than a 14 ms bf16 step)."""
 
   def __call__(self, batch):
-    sort_inds = np.argsort(np.array([1 + len(d['mix']) // 128 for d in batch]))[::-1]
-    return {'pcm': {key: [torch.from_numpy(np.ascontiguousarray(batch[i][key])) for i in sort_inds] for key in batch[0]}}
-
-
-def _features_from_pcm(pcm, dev):
-  """{'mix': [int16 (N_b,)], 'source1': ...} (length-sorted, as WavCollator leaves them) -> mix (R,F), sources [(R,F)]
-  packed rows and their Packing: STFT magnitudes on the GPU (sk_stft into the (T,B,F) grid, then the valid rows)."""
-  B = len(pcm['mix'])
-  F = 257
-  Ts = [1 + int(w.numel()) // 128 for w in pcm['mix']]
-  T = max(Ts)
-  pk = Packing.from_lens(Ts, dev)
-  keys = ['mix'] + sorted(k for k in pcm if k != 'mix')
-  feats = {}
-  for k in keys:
-    out = torch.zeros(T, B, F, device=dev)
-    ops.stft_batch([w.to(dev, non_blocking=True) for w in pcm[k]], out=out, out_offs=[b * F for b in range(B)],
-                   stride_t=[B * F] * B, stride_f=[1] * B)
-    feats[k] = pk.pack(out)
-  return feats['mix'], [feats[k] for k in keys[1:]], pk
+    order = np.argsort(np.array([1 + len(d['mix']) // 128 for d in batch]))[::-1]
+    keys = ['mix'] + sorted((k for k in batch[0] if k != 'mix'), key=lambda k: int(k[6:]))
+    flat = np.concatenate([batch[i][k] for k in keys for i in order])
+    return {'pcm': {'flat': torch.from_numpy(flat), 'keys': keys, 'lens': [int(len(batch[i]['mix'])) for i in order]}}
 
 
 class _PitFn(torch.autograd.Function):

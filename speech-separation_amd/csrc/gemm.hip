@@ -776,159 +776,6 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// fp32 product on the bf16 matrix pipe by an EXACT three-way split (variant 2 of sk_gemm_f32_splitk, opt-in).
-// Every fp32 operand element x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits = 3 x 8:
-// hi = the top 8, taken by truncation; x - hi is exact in fp32 and has at most 16 significant bits; again for mid; what
-// is left has at most 8 bits and IS a bf16).  a*b is then the sum of the nine piece products, each of which is exact in
-// fp32 (8 x 8 bits), and the matrix cores add them into the same fp32 accumulators as always -- so this is an fp32 GEMM
-// with another summation order, not a lower-precision one (tests: error against fp64 no larger than the fp32-MFMA
-// kernel's).  Nine v_mfma_f32_32x32x16_bf16 (8 passes each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (16 passes
-// each): 72 passes instead of 128 per 32 x 32 x 16 block, for ~5.5 VALU instructions per operand element to split it
-// (other waves' products run meanwhile).  Operand tiles are DMA'd into LDS as fp32 exactly as in gemm_f32_kernel_dma;
-// the K order is the natural one (lane holds k = 8 (lane>>5) .. +7 of its row, the bf16 MFMA's fragment shape).
-// Non-finite inputs: x = +-inf splits into (inf, nan, nan): such a product is NaN where an fp32 FMA gives +-inf.
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct Split3 {
-  bf16x8_t hi, mid, lo;
-};
-
-__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
-  unsigned h[4], m[4], l[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const f32x2 x = {v[2 * j], v[2 * j + 1]};
-    const f32x2 xh = {__uint_as_float(__float_as_uint(x.x) & 0xffff0000u), __uint_as_float(__float_as_uint(x.y) & 0xffff0000u)};
-    const f32x2 r = x - xh;  // exact
-    const f32x2 rh = {__uint_as_float(__float_as_uint(r.x) & 0xffff0000u), __uint_as_float(__float_as_uint(r.y) & 0xffff0000u)};
-    const f32x2 q = r - rh;  // exact, <= 8 significant bits
-    // upper halves of (odd, even) element -> one register of two bf16
-    h[j] = __builtin_amdgcn_perm(__float_as_uint(x.y), __float_as_uint(x.x), 0x07060302u);
-    m[j] = __builtin_amdgcn_perm(__float_as_uint(r.y), __float_as_uint(r.x), 0x07060302u);
-    l[j] = __builtin_amdgcn_perm(__float_as_uint(q.y), __float_as_uint(q.x), 0x07060302u);
-  }
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  Split3 o;
-  o.hi = __builtin_bit_cast(bf16x8_t, (u32x4){h[0], h[1], h[2], h[3]});
-  o.mid = __builtin_bit_cast(bf16x8_t, (u32x4){m[0], m[1], m[2], m[3]});
-  o.lo = __builtin_bit_cast(bf16x8_t, (u32x4){l[0], l[1], l[2], l[3]});
-  return o;
-}
-
-// this lane's 8 consecutive-k fp32 values of its row of the 32-row fragment starting at d0
-template <bool KMAJOR>
-__device__ __forceinline__ void frag8_load(const char* img, int d0, int lane, float (&v)[8]) {
-  const int l31 = lane & 31, kh = lane >> 5;
-  if (KMAJOR) {
-    const int base = 8 * kh * 512 + ((d0 ^ (kh << 5)) + l31) * 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(img + base + j * 512);
-  } else {
-    const int base = ((d0 + l31) >> 4) * 1024 + 2 * kh * 256 + (((l31 & 15) + 8 * kh) & 15) * 16;
-    const float4 p = *reinterpret_cast<const float4*>(img + base), q = *reinterpret_cast<const float4*>(img + base + 256);
-    v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
-    v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
-  }
-}
-
-__device__ __forceinline__ void mma9(f32x16& acc, const Split3& a, const Split3& b) {
-  // small terms first (it is one fp32 accumulator either way)
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.mid, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
-}
-
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel_split3(GemmArgs g) {
-  constexpr int TILE = BM * BK * 4;  // 8 KB per operand image
-  __shared__ __attribute__((aligned(1024))) char lds[2][2 * TILE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int tile = blockIdx.x;
-  {
-    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
-    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
-  }
-  int m0, n0;
-  {
-    const int tilesM = gridDim.x / g.tilesN, per = GROUP_M * g.tilesN;
-    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GROUP_M;
-    const int gsz = min(GROUP_M, tilesM - first);
-    m0 = (first + rem2 % gsz) * BM;
-    n0 = (rem2 / gsz) * BN;
-  }
-  const int z = blockIdx.z, ks = blockIdx.y;
-  const float* A = g.A + z * g.sA;
-  const float* B = g.B + z * g.sB;
-  const bool partial = g.splitk > 1;
-  float* C = partial ? g.slabs + ((int64_t)z * g.splitk + ks) * g.M * g.N : g.C + z * g.sC;
-  const int ldc = partial ? g.N : g.ldc;
-  const float* bias = (g.bias && !partial) ? g.bias + z * g.sbias : nullptr;
-  const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-  const int nk = (kend - kbeg) / BK;
-
-  const float* srcA[2];
-  const float* srcB[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    srcA[i] = dma_src<TA, 3>(A, g.lda, m0, g.M, kbeg, 2 * wave + i, lane);
-    srcB[i] = dma_src<!TB, 3>(B, g.ldb, n0, g.N, kbeg, 2 * wave + i, lane);
-  }
-  const int64_t stepA = TA ? (int64_t)BK * g.lda : BK, stepB = !TB ? (int64_t)BK * g.ldb : BK;
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
-  const unsigned my_pieces = __builtin_amdgcn_readfirstlane(lds_base + 2 * wave * 1024);
-  auto stage = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      dma_1k(srcA[i], my_pieces + buf * 2 * TILE + i * 1024);
-      dma_1k(srcB[i], my_pieces + buf * 2 * TILE + TILE + i * 1024);
-      srcA[i] += stepA;
-      srcB[i] += stepB;
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  if (nk > 0) stage(0);
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage(cur ^ 1);
-    const char* ai = lds[cur];
-    const char* bi = lds[cur] + TILE;
-    float va0[8], va1[8], vb0[8], vb1[8];
-    frag8_load<TA>(ai, wm * 64, lane, va0);
-    frag8_load<!TB>(bi, wn * 64, lane, vb0);
-    frag8_load<TA>(ai, wm * 64 + 32, lane, va1);
-    frag8_load<!TB>(bi, wn * 64 + 32, lane, vb1);
-    const Split3 a0 = split3(va0), b0 = split3(vb0);
-    mma9(acc[0][0], a0, b0);
-    const Split3 a1 = split3(va1);
-    mma9(acc[1][0], a1, b0);
-    const Split3 b1 = split3(vb1);
-    mma9(acc[0][1], a0, b1);
-    mma9(acc[1][1], a1, b1);
-    cur ^= 1;
-  }
-  store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
-  if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
-}
-
-// ------------------------------------------------------------------------------------------------------
 // bf16-input variant (BASELINE configs[3]: "bf16 MFMA inputs, fp32 accumulate").  Operands stay fp32 in
 // HBM -- no second copy of weights or activations exists -- and are rounded to bf16 (RNE) on their way
 // into LDS; the matrix cores run v_mfma_f32_32x32x16_bf16 with fp32 accumulators, and the epilogue, the
@@ -1733,7 +1580,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                 int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
-  SK_CHECK_ARG(variant >= 0 && variant <= 6 && variant != 5, "sk_gemm: unknown variant %d", variant);
+  SK_CHECK_ARG(variant >= 0 && variant <= 6 && variant != 5 && variant != 2, "sk_gemm: unknown variant %d", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
@@ -1807,13 +1654,6 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((gemm_f32_kernel_dma256<false, true>), grid, dim3(512), 0, st, g);
     else
       hipLaunchKernelGGL((gemm_f32_kernel_dma256<true, false>), grid, dim3(512), 0, st, g);
-  } else if (variant == 2 && dma_ok(g, transA, transB)) {
-    if (!transA && !transB)
-      hipLaunchKernelGGL((gemm_f32_kernel_split3<false, false>), grid, dim3(256), 0, st, g);
-    else if (!transA && transB)
-      hipLaunchKernelGGL((gemm_f32_kernel_split3<false, true>), grid, dim3(256), 0, st, g);
-    else
-      hipLaunchKernelGGL((gemm_f32_kernel_split3<true, false>), grid, dim3(256), 0, st, g);
   } else if (variant != 1 && dma_ok(g, transA, transB, variant == 0)) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_dma<false, false>), grid, dim3(256), 0, st, g);

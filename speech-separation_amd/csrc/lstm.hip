@@ -356,9 +356,9 @@ __device__ __forceinline__ void decode_block(int L, int NUG, int nby, int map, i
   dir = stream / nby;
 }
 
-// NW = waves per workgroup.  8: 16 hidden units per workgroup (4 gate-row tiles x 2 K halves), one workgroup per CU.
-// 4: 8 units per workgroup (2 tiles x 2 K halves), TWO workgroups per CU that belong to different streams: while one
-// waits for its hand-off the other has the matrix pipe, so a step costs the chain plus HALF the MFMA time.
+// NW = waves per workgroup: 8 -- 16 hidden units per workgroup (4 gate-row tiles x 2 K halves), one workgroup per CU.  (A 4-wave
+// form -- 8 units per workgroup, two workgroups of different streams per CU -- measured slower at every shape and was retired in
+// r05; the kernel body stays written in terms of NW.)
 // PK: the sequence tensors are PACKED rows (FwdArgs::offs).  A template parameter, not a run-time test of a.offs: the padded
 // instantiation is then the r03 kernel instruction for instruction (one process measured the run-time form 0.1-0.25 us per
 // step slower on padded batches: the row-base select and the length table in front of the step's gx fetch).
@@ -1186,17 +1186,11 @@ __global__ __launch_bounds__(256) void gate_rows_kernel(const float* __restrict_
 }
 
 template <int KS, bool BF>
-int launch_fwd(const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
-  if (a.offs) {
-    if (half)
-      hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 4, false, true>), dim3((unsigned)nblocks), dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 8, false, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a);
-  } else if (half) {
-    hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 4>), dim3((unsigned)nblocks), dim3(256), 0, st, a);
-  } else {
+int launch_fwd(const FwdArgs& a, int nblocks, hipStream_t st) {
+  if (a.offs)
+    hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 8, false, true>), dim3((unsigned)nblocks), dim3(512), 0, st, a);
+  else
     hipLaunchKernelGGL((lstm_fwd_kernel<KS, BF, 8>), dim3((unsigned)nblocks), dim3(512), 0, st, a);
-  }
   return 0;
 }
 template <int KS>
@@ -1221,18 +1215,18 @@ int dispatch_fwd_s3(int KS, const FwdArgs& a, int nblocks, hipStream_t st) {
   return 0;
 }
 
-int dispatch_fwd(int KS, bool bf, const FwdArgs& a, bool half, int nblocks, hipStream_t st) {
+int dispatch_fwd(int KS, bool bf, const FwdArgs& a, int nblocks, hipStream_t st) {
   if (bf) switch (KS) {
-      case 20: return launch_fwd<20, true>(a, half, nblocks, st);
-      case 40: return launch_fwd<40, true>(a, half, nblocks, st);
-      case 56: return launch_fwd<56, true>(a, half, nblocks, st);
-      default: return launch_fwd<64, true>(a, half, nblocks, st);
+      case 20: return launch_fwd<20, true>(a, nblocks, st);
+      case 40: return launch_fwd<40, true>(a, nblocks, st);
+      case 56: return launch_fwd<56, true>(a, nblocks, st);
+      default: return launch_fwd<64, true>(a, nblocks, st);
     }
   switch (KS) {
-    case 20: return launch_fwd<20, false>(a, half, nblocks, st);
-    case 38: return launch_fwd<38, false>(a, half, nblocks, st);
-    case 56: return launch_fwd<56, false>(a, half, nblocks, st);
-    default: return launch_fwd<64, false>(a, half, nblocks, st);
+    case 20: return launch_fwd<20, false>(a, nblocks, st);
+    case 38: return launch_fwd<38, false>(a, nblocks, st);
+    case 56: return launch_fwd<56, false>(a, nblocks, st);
+    default: return launch_fwd<64, false>(a, nblocks, st);
   }
 }
 int dispatch_bwd(int KS, bool bf, const BwdArgs& a, dim3 grid, hipStream_t st) {
@@ -1298,14 +1292,14 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   if (rc) return rc;
   const int gmin = (mode >> 8) & 0xff;  // bits 8..15: minimum batch groups per workgroup (frees CUs for concurrent kernels)
   const bool bf = (mode >> 16) & 1;     // bit 16: bf16 matrix-core inputs
-  const bool half = (mode >> 17) & 1;   // bit 17: 8-unit, 256-thread workgroups, two per CU
+  SK_CHECK_ARG(!((mode >> 17) & 1), "sk_lstm_fwd: mode bit 17 (8-unit / 256-thread workgroups) was retired in r05");
   const int map = (mode >> 18) & 3;     // bits 18..19: block id -> stream assignment (speed only)
   int opt = (mode >> 20) & 7;     // bit 20: one polling wave per workgroup; bit 21: flags replicated per XCD;
                                         // bit 22: one flag per 128-byte line
   if (opt & 4) opt &= ~2;              // one flag per line: no replicas on top (the flag block is sized for either)
-  // bit 28 (fp32, 8-wave workgroups): the product by the exact three-way bf16 split on the bf16 matrix pipe (S3)
-  const bool s3 = ((mode >> 28) & 1) && !bf && !half && pick_ks(H, true) != 64;  // (KS = 64: 168 + 88 registers do not fit)
-  const bool tagged = ((mode >> 29) & 1) && !((mode >> 16) & 1) && !((mode >> 17) & 1) && !s3;  // bit 29 (fp32, 8-wave workgroups)
+  // bit 28 (fp32): the product by the exact three-way bf16 split on the bf16 matrix pipe (S3)
+  const bool s3 = ((mode >> 28) & 1) && !bf && pick_ks(H, true) != 64;  // (KS = 64: 168 + 88 registers do not fit)
+  const bool tagged = ((mode >> 29) & 1) && !bf && !s3;  // bit 29 (fp32)
   if (tagged) opt |= 8;                // the data is the flag (lstm_fwd_kernel)
   int poll_delay = (mode >> 23) & 31;  // bits 23..27: FwdArgs::poll_delay, units of 0.1 us; 0 = choose, 31 = none
   mode &= 0xff;
@@ -1318,8 +1312,8 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;
-  const int NUG = half ? 2 * L.KS : L.KS;
-  const int G = groups_per_wg(NUG, L.NBG, gmin, half ? 2 : 1);
+  const int NUG = L.KS;
+  const int G = groups_per_wg(NUG, L.NBG, gmin, 1);
   const bool fits = G > 0;
   a.G = fits ? G : 1;
   const int nby = (L.NBG + a.G - 1) / a.G;
@@ -1335,11 +1329,11 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
     SK_CHECK_HIP(hipMemsetAsync(base + L.xbuf, 0, L.state - L.xbuf, st));
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T;
-    s3 ? dispatch_fwd_s3(L.KS, a, nblocks, st) : dispatch_fwd(L.KS, bf, a, half, nblocks, st);
+    s3 ? dispatch_fwd_s3(L.KS, a, nblocks, st) : dispatch_fwd(L.KS, bf, a, nblocks, st);
   } else {  // one launch per step: the state travels through the workspace
     for (int s = 0; s < T; ++s) {
       a.s_begin = s; a.s_end = s + 1;
-      s3 ? dispatch_fwd_s3(L.KS, a, nblocks, st) : dispatch_fwd(L.KS, bf, a, half, nblocks, st);
+      s3 ? dispatch_fwd_s3(L.KS, a, nblocks, st) : dispatch_fwd(L.KS, bf, a, nblocks, st);
     }
   }
   SK_CHECK_LAUNCH("sk_lstm_fwd");

@@ -41,6 +41,31 @@ def wav_frames(path, hop=128):
         return 1 + w.getnframes() // hop
 
 
+def features_from_pcm(pcm, dev):
+  """The on-GPU feature front end of a wav batch.  pcm = the arch's WavCollator batch: {'flat': int16 tensor
+  holding every signal of the batch, key-major ('mix', 'source1', ...), longest utterance first; 'keys'; 'lens': samples per
+  utterance} -> (mix (R,F), [source (R,F)...] packed rows, their Packing): STFT magnitudes by sk_stft into the (T,B,F) grid,
+  then the valid rows.  One H2D copy for the whole batch; everything is enqueued on the CURRENT stream."""
+  import torch
+  from . import ops
+  from .packing import Packing
+  ns = [int(n) for n in pcm['lens']]
+  B, F = len(ns), 257
+  pk = Packing.from_lens([1 + n // 128 for n in ns], dev)
+  flat = pcm['flat']
+  if flat.device != torch.device(dev):
+    flat = (flat if flat.is_pinned() else flat.pin_memory()).to(dev, non_blocking=True)
+  feats, at, total = [], 0, sum(ns)
+  for _ in pcm['keys']:
+    out = torch.zeros(pk.T, B, F, device=dev)
+    ops.stft_batch(flat[at:at + total], lengths=ns, out=out, out_offs=[b * F for b in range(B)],
+                   stride_t=[B * F] * B, stride_f=[1] * B)
+    at += total
+    feats.append(pk.pack(out))
+  flat.record_stream(torch.cuda.current_stream(dev))
+  return feats[0], feats[1:], pk
+
+
 # ----------------------------------------------------------------------------------------------- staging ahead of the step
 class Prefetcher:
   """Iterates a DataLoader of the arch's batches and hands them over ALREADY ON THE GPU, as packed rows.
@@ -164,26 +189,12 @@ class Prefetcher:
     from .packing import Packing
     if not isinstance(batch, dict):
       return batch
-    if 'pcm' in batch:                   # WavCollator: {'pcm': {key: [int16 tensors, longest first]}}
-      from . import ops
+    if 'pcm' in batch:                   # WavCollator: {'pcm': {'flat': int16 tensor, 'keys', 'lens'}}: one pinned copy, STFT here
       pcm = batch['pcm']
-      keys = ['mix'] + sorted(k for k in pcm if k != 'mix')
-      ns = [int(w.numel()) for w in pcm['mix']]
-      B, F = len(ns), 257
-      Ts = [1 + n // 128 for n in ns]
-      pk = Packing.from_lens(Ts, dev)
-      host = torch.cat([w for k in keys for w in pcm[k]]).pin_memory()       # every signal of the batch, one copy
-      flat = host.to(dev, non_blocking=True)
-      feats, at = [], 0
-      for k in keys:
-        out = torch.zeros(pk.T, B, F, device=dev)
-        ops.stft_batch(flat[at:at + sum(ns)], lengths=ns, out=out, out_offs=[b * F for b in range(B)],
-                       stride_t=[B * F] * B, stride_f=[1] * B)
-        at += sum(ns)
-        feats.append(pk.pack(out))
-      flat.record_stream(torch.cuda.current_stream(dev))
+      host = pcm['flat'] if pcm['flat'].is_pinned() else pcm['flat'].pin_memory()
+      mix, sources, pk = features_from_pcm(dict(pcm, flat=host), dev)
       out = {k: v for k, v in batch.items() if k != 'pcm'}
-      out['packed'] = (feats[0], feats[1:], pk)
+      out['packed'] = (mix, sources, pk)
       out['_keepalive'] = host
       return out
     seqs = {k: v for k, v in batch.items() if isinstance(v, PackedSequence)}

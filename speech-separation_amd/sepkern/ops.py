@@ -571,19 +571,20 @@ def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, sprea
     choice, 31 = none); tagged (forward, fp32): the exchanged h carries the step's epoch in its two low mantissa bits and
     nothing else is signalled (mode bit 29); split3 (forward, fp32): the product h W_hh^T by the exact three-way bf16 split
     of both operands on the bf16 matrix pipe (mode bit 28; flags hand-off, the tagged one does not combine with it)."""
-    return ((0x20000 if half else 0) | ((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) |
+    if half:      # (the first field of SEPKERN_LSTM_FWD / _BWD keeps its place so that recorded switch strings stay readable)
+        raise _lib.SepkernError("the 8-unit / 256-thread forward recurrence (field `half`, mode bit 17) was retired in r05: "
+                                "measured slower at every shape (DESIGN_HISTORY.md)")
+    return (((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) |
             (0x200000 if repflags else 0) | (0x400000 if spread else 0) | ((int(poll_delay) & 31) << 23) |
             (0x20000000 if tagged else 0) | (0x10000000 if split3 else 0))
 
 
-def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, half=False, blockmap=0, offs=None,
-             rows=None):
+def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, blockmap=0, offs=None, rows=None):
     """bf16=True: W_hh and h_{t-1} enter the matrix cores rounded to bf16 (fp32 accumulate, fp32 state).
-    half=True: 8-unit / 256-thread workgroups, two per CU (include/sepkern.h, mode bit 17); blockmap 0..2: which
-    workgroups share an XCD / a CU (mode bits 18..19; speed only).  offs (int32, T+1): the sequence tensors are PACKED
+    blockmap 0..2: which workgroups share an XCD / a CU (mode bits 18..19; speed only).  offs (int32, T+1): the sequence tensors are PACKED
     rows (lens sorted descending; `rows` of them: the launch's algorithmic work for the profile); None: zero-padded (T, B, .)."""
     ws = lstm_ws(T, B, H)
-    mode = int(mode) | (0x10000 if bf16 else 0) | (0x20000 if half else 0) | ((int(blockmap) & 3) << 18)
+    mode = int(mode) | (0x10000 if bf16 else 0) | ((int(blockmap) & 3) << 18)
     _chk(offs, torch.int32)
     with _timed("lstm_fwd_kernel", 2.0 * (T * B if rows is None else rows) * 2 * 4 * H * H):
         _lib.call("sk_lstm_fwd", _ptr(gx), _ptr(whh), _ptr(h0), _ptr(c0), _ptr(lens), _ptr(offs), _ptr(y), _ptr(gates), _ptr(cs),

@@ -11,10 +11,10 @@ What is organised differently here, on the host side only:
   * clip + Adam run fused over the model's flat parameter buffer (sepkern.optim.ClipAdam; --torch-optimizer
     restores the reference's torch calls on the same parameters);
   * under torch.distributed.run (one process per GPU) it trains data-parallel: replicas are made identical by a
-    broadcast from rank 0, their BatchNorm running statistics are averaged after every epoch (sepkern.dist.
-    average_bn_buffers: the CV loss printed is the loss of the model saved), every epoch's utterances are dealt to the ranks in length-balanced global batches
+    broadcast from rank 0, every epoch's utterances are dealt to the ranks in length-balanced global batches
     (sepkern.dist.EpochShards: same step count on every rank), gradients are summed over RCCL inside backward,
-    the cross-validation set is sharded too, rank 0 writes the files;
+    the ranks' BatchNorm running statistics are averaged after every epoch (sepkern.dist.average_bn_buffers: the CV
+    loss printed is the loss of the model saved), the cross-validation set is sharded too, rank 0 writes the files;
   * checkpoints also carry the optimizer state (NNN.opt), which the reference loses on resume (:107);
   * a recurrence launch that timed out never reaches the weights (the fused optimizer skips that step on the
     device) and is reported when the epoch ends;
@@ -59,7 +59,8 @@ def get_args(argv=None):
                       help="use torch clip_grad_norm_ + optim.Adam instead of the fused kernel")
   parser.add_argument("--num-workers", type=int, default=None,
                       help="loader processes (default: up to 12 for npz features -- zlib inflate of ~1 MB per utterance is the "
-                           "loader's cost: 8 feed a 35 ms step, the 13 ms bf16 step wants more --, 2 with --wav-input; capped by "
+                           "loader's cost: 8 feed a 35 ms step, the 13 ms bf16 step wants more --, 4 with --wav-input (reading 96 small wav files "
+                           "per batch: ~15 ms per worker); capped by "
                            "the CPUs this process may use)")
   parser.add_argument("--prefetch", type=int, default=2,
                       help="batches staged on the GPU ahead of the step (pinned memory, own copy stream); 0: off")
@@ -161,7 +162,7 @@ def loader_workers(args, world):
     cpus = len(os.sched_getaffinity(0))
   except AttributeError:
     cpus = os.cpu_count() or 1
-  return max(1, min(2 if args.wav_input else 12, cpus // max(1, world) - 3))
+  return max(1, min(4 if args.wav_input else 12, cpus // max(1, world) - 3))
 
 
 def staged(loader, args):
