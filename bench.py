@@ -598,8 +598,9 @@ def numerics_note(model, args):
         return "bf16 matrix-core inputs for every product incl. the recurrences, fp32 accumulate / state / optimizer"
     if eng is not None and eng.split3_fwd:
         return ("fp32 throughout; the forward recurrence forms h W_hh^T by the exact three-way bf16 split of both fp32 operands "
-                "on the bf16 matrix pipe (nine exact piece products per element pair, fp32 accumulators: an fp32 product in "
-                "another summation order, no operand perturbed); SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = plain fp32-MFMA product")
+                "on the bf16 matrix pipe (the six piece products per element pair of relative size >= 2^-16, each exact, fp32 "
+                "accumulators; the three left out are <= half an ulp of the fp32 product: error vs fp64 not above the fp32-MFMA "
+                "kernel's, tests/test_gpu_kernels.py; no operand perturbed); SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = plain fp32-MFMA product")
     if eng is not None and eng.tagged_fwd and eng.lstm_mode != 2:
         return ("fp32 throughout; forward-recurrence hand-off 'tagged': the operand h entering h W_hh^T carries a 2-bit epoch "
                 "in its low mantissa bits (<= 3 ulp), all stored values exact; SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = exact hand-off")

@@ -190,11 +190,13 @@ int sk_hprev_rows(const float* y, int ldy, const float* h0, const int32_t* offs,
  * block id -> stream map; bit 20 one polling wave per workgroup; bit 21 flags replicated per XCD; bit 22 one flag per
  * 128-byte line; bits 23..27 hold-back of a step's first poll in units of 0.1 us (0 = the library's choice, 31 = none);
  * bit 28 (fp32 forward, H <= 896): the product h W_hh^T by the EXACT three-way bf16 split of both fp32
- * operands on the bf16 matrix pipe -- x = hi + mid + lo with three bf16 pieces (24 significand bits = 3 x 8), nine exact piece
- * products per element pair added into fp32 accumulators by v_mfma_f32_16x16x32_bf16: an fp32 product in another summation
- * order (results within 2e-6 of the fp32-MFMA kernel's, no operand perturbed), 144 instead of 256 matrix-pipe cycles per 32 k.
- * W_hh is split once per launch, h by its producer (three bf16 images, flags hand-off).  The engine ships it for the fp32
- * forward recurrence (35.6 vs 36.6 ms per training step at 3 x 896; bench.py's config.numerics names it);
+ * operands on the bf16 matrix pipe -- x = hi + mid + lo with three bf16 pieces (24 significand bits = 3 x 8); of the nine piece
+ * products per element pair (each exact in fp32) the six of relative size >= 2^-16 are added into fp32 accumulators by
+ * v_mfma_f32_16x16x32_bf16, the three of size <= 2^-24 -- at or below half an ulp of the fp32 product -- are not formed: an
+ * fp32 product in another summation order (error against fp64 not above the fp32-MFMA kernel's, results within 2.2e-6 of it,
+ * no operand perturbed), 96 instead of 256 matrix-pipe cycles per 32 k.  W_hh is split once per launch, h by its producer
+ * (three bf16 images, flags hand-off).  The engine ships it for the fp32 forward recurrence (bench.py's config.numerics
+ * names it);
  * bit 29 (fp32 forward; not together with bit 28): "the data is the flag" -- every exchanged h word carries the step's epoch
  * in its two low mantissa bits, producers publish without drain / barrier / flag, consumers hold back, pull, check every word
  * and pull again what was not complete; the next step's product runs on the tagged words (<= 3 ulp = 3.6e-7 relative),

@@ -52,13 +52,19 @@ __device__ __forceinline__ bf16x8 pack8(const float4& a, const float4& b) {
 __device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((((k >> 3) & 3) * 16 + b) << 3) + (k & 7); }
 
 // S3 variant of the forward kernel (mode bit 28): the fp32 product h W_hh^T on the bf16 matrix pipe by an EXACT three-way
-// split.  An fp32 value x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits = 3 x 8: hi = the top
-// 8 by truncation; x - hi is exact and has <= 16 significant bits; again for mid; what is left IS a bf16).  w h is the sum
-// of the nine piece products, each exact in fp32 (8 x 8 bits), added into fp32 accumulators by nine
-// v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32) instead of eight v_mfma_f32_16x16x4_f32 (32 cycles each): an fp32
-// product in another summation order, 144 instead of 256 matrix-pipe cycles per 32 k.  W_hh is split once per launch (three
-// register pieces: 168 instead of 112 VGPRs), h by its producer before it publishes (three bf16 images: 6 instead of 4
-// bytes per cell).  Same arithmetic as gemm.hip's gemm_f32_kernel_split3.
+// split of both operands.  An fp32 value x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits =
+// 3 x 8: hi = the top 8 by truncation; x - hi is exact and has <= 16 significant bits; again for mid; what is left IS a bf16).
+// w h is the sum of nine piece products, each exact in fp32 (8 x 8 bits), of relative sizes 1 (hi hi), 2^-8 (hi mid, mid hi),
+// 2^-16 (hi lo, mid mid, lo hi), 2^-24 (mid lo, lo mid) and 2^-32 (lo lo).  The kernel forms the SIX of size >= 2^-16 and
+// adds them into fp32 accumulators with v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32): 96 matrix-pipe cycles per 32 k
+// instead of the 256 of eight v_mfma_f32_16x16x4_f32.  The three it leaves out lie at or below HALF AN ULP of the fp32 product
+// they belong to -- what an fp32 multiplier rounds away itself -- and far below the rounding of the fp32 accumulation that
+// follows: against an fp64 sum (K = 896, operands of the recurrence's scale) the six-product form has the error of the
+// nine-product form (rms 2.21e-7 vs 2.19e-7) and less than the fp32-MFMA kernel's own (2.50e-7), and differs from the nine-
+// product form by 7x less than that differs from the fp32-MFMA kernel (tests/test_gpu_kernels.py pins this on the device).
+// So this is an fp32 product in another summation order; no operand is perturbed.  W_hh is split once per launch (three
+// register pieces: 168 instead of 112 VGPRs), h by its producer before it publishes (three bf16 images: 6 instead of 4 bytes
+// per cell).  (r04 shipped all nine products: 144 cycles per 32 k.)
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
   const unsigned xu = __builtin_bit_cast(unsigned, x);
   const float r = x - __builtin_bit_cast(float, xu & 0xffff0000u);  // exact
@@ -632,22 +638,19 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
           if (tail && (q & 1)) continue;
 #endif
           if (S3) {
-            // nine exact piece products per 32 k, the small ones first; chunks alternate between two accumulators
-            // the piece that is needed first is fetched first, and the nine products alternate between the two accumulators (no
-            // product waits for the one issued just before it): 5.4 vs 5.7 us per step against fetching hi, mid, lo in that
-            // order and chaining all nine of a chunk on one accumulator (an explicit software pipeline of the fetches on top: no change)
+            // SIX of the nine piece products per 32 k (see split3 above), the small ones first.  The piece that is needed first is
+            // fetched first and the products alternate between the two accumulators (no product waits for the one issued just
+            // before it): 5.4 vs 5.7 us per step against fetching hi, mid, lo in that order and chaining a chunk's products on
+            // one accumulator (an explicit software pipeline of the fetches on top: no change).
             const bf16x8 h3 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + 2 * PIECE);
             const bf16x8 h2 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + PIECE);
             const bf16x8 h1 = *reinterpret_cast<const bf16x8*>(hp + q * 256);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h3, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h3, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h3, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h2, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h2, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h2, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h1, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h1, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h1, acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h3, acc0, 0, 0, 0);  // hi  * lo    ~2^-16
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h2, acc1, 0, 0, 0);  // mid * mid   ~2^-16
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h2, acc0, 0, 0, 0);  // hi  * mid   ~2^-8
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h1, acc1, 0, 0, 0);  // lo  * hi    ~2^-16
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h1, acc0, 0, 0, 0);  // mid * hi    ~2^-8
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h1, acc1, 0, 0, 0);  // hi  * hi
           } else if (BF) {
             const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hp + q * 256);
             if (q & 1)

@@ -120,7 +120,7 @@ class Engine:
         # hand-off geometry / protocol of the persistent recurrences (speed only): "half,map,poll1,repflags,
         # spread,delay,tagged,split3".  Forward: streams dealt to XCD groups, one polling wave, first poll held back (delay 0 =
         # the library's choice); bf16: one flag per 128-byte line on top.  fp32 forward (r04): the product h W_hh^T by the EXACT
-        # three-way bf16 split of both operands on the bf16 matrix pipe (split3 = 1: nine exact piece products per element pair,
+        # three-way bf16 split of both operands on the bf16 matrix pipe (split3 = 1: the six piece products per element pair that reach fp32's resolution, each exact,
         # fp32 accumulators -- an fp32 product in another summation order, no operand is perturbed; 35.6 vs 36.6 ms per
         # training step against the r03 default).  That r03 default, "the data is the flag" (SEPKERN_LSTM_FWD=0,1,1,0,0,8,1,0:
         # the exchanged h carries the step's epoch in its two low mantissa bits, <= 3 ulp on the operand), remains for hidden
