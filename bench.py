@@ -35,6 +35,10 @@ for p in (ROOT, PKG, os.path.join(PKG, "archs")):
 
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide)
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* at 64 FLOP/clk/SIMD, 256 CUs, 2.4 GHz
+# fp32 products formed on the bf16 matrix pipe by the three-way split of both operands, SIX bf16 piece products per fp32 product
+# (gemm_f32_kernel_split3 / the split form of the stream-K kernel; the forward recurrence): the pipe that bounds them is the
+# bf16 one, at a sixth of its rate in fp32-equivalent FLOP
+PEAK_F32_SPLIT_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -399,10 +403,15 @@ def measure(args, env, standalone_pass=True):
     if lstm_fallback:
         res["lstm_fallback"] = lstm_fallback
     if prof:
-        kname = "gemm_f32_kernel"
-        if args.dtype == "bf16":     # bf16 operand copies + the NT kernel (hidden sizes that are no multiple of 8: the r01 kernel)
-            kname = "gemm_bf16_nt_kernel" if any(k.startswith("gemm_bf16_nt_kernel") for k in prof) else "gemm_bf16_kernel"
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS     # the dtype's own dense MFMA peak
+
+        def pipe_peak(cls):
+            """The peak of the matrix pipe a kernel class runs on (fp32-equivalent TFLOP/s)."""
+            if args.dtype == "bf16":
+                return PEAK_BF16_MFMA_TFLOPS
+            if cls.startswith("gemm_f32_split") or (cls.startswith("lstm_fwd") and model._engine is not None and model._engine.split3_fwd):
+                return PEAK_F32_SPLIT_TFLOPS
+            return PEAK_F32_MFMA_TFLOPS
         # launches recorded on the side stream are the weight-gradient GEMMs that the engine co-schedules with the
         # next layer's recurrence on the same CUs (sepkern/engine.py): that shortens the step but lengthens THEIR
         # durations, so the figure over all launches is reported next to the one over the launches that had the
@@ -412,17 +421,29 @@ def measure(args, env, standalone_pass=True):
             b = k.split("@")[0]
             m = merged.setdefault(b, [0, 0.0, 0.0])
             m[0] += v[0]; m[1] += v[1]; m[2] += v[2]
+        # the dominant GEMM class by launch time: fp32 runs split products (bf16 pipe) wherever the operands are aligned and
+        # fp32-MFMA kernels elsewhere; bf16 the NT kernel (hidden sizes that are no multiple of 8: the r01 kernel)
+        if args.dtype == "bf16":
+            kname = "gemm_bf16_nt_kernel" if "gemm_bf16_nt_kernel" in merged else "gemm_bf16_kernel"
+        else:
+            kname = max((k for k in merged if k.startswith("gemm_f32")), key=lambda k: merged[k][1])
         n, ms, fl = merged[kname]
         ach = fl / (ms * 1e-3) / 1e12
+        kpeak = pipe_peak(kname)
         res["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
-                           "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                           "peak": round(kpeak, 1), "unit": "TFLOP/s", "frac": round(ach / kpeak, 4),
                            "traffic": pmc_traffic(kname), "launches_per_step": n // args.steps,
                            "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms / args.steps, 3)}
+        if kname.startswith("gemm_f32_split"):
+            res["roofline"]["peak_note"] = ("fp32 products formed on the bf16 matrix pipe (three-way split of both operands, six bf16 piece "
+                                            "products per fp32 product): peak = the bf16 dense MFMA peak / 6 in fp32-equivalent FLOP; achieved "
+                                            "= 2MNK / time.  The fp32-MFMA pipe (157.3 TFLOP/s) does not bound these launches")
+            res["roofline"]["achieved_over_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
         if prof_alone:
             n1, ms1, fl1 = prof_alone[kname]
             ach1 = fl1 / (ms1 * 1e-3) / 1e12
             res["roofline"]["standalone"] = {
-                "achieved": round(ach1, 2), "frac": round(ach1 / peak, 4), "avg_launch_ms": round(ms1 / n1, 4),
+                "achieved": round(ach1, 2), "frac": round(ach1 / kpeak, 4), "avg_launch_ms": round(ms1 / n1, 4),
                 "note": "same launches in an untimed pass of 2 steps with co-scheduling off: in the timed region the "
                         "weight-gradient launches of every layer but the first run co-resident with the next recurrence "
                         "on its CUs, which shortens the step and lengthens the launches it overlaps"}
@@ -439,11 +460,14 @@ def measure(args, env, standalone_pass=True):
                 continue
             a_ = v[2] / (v[1] * 1e-3) / 1e12
             row = {"launches_per_step": v[0] // args.steps, "avg_launch_ms": round(v[1] / v[0], 4),
-                   "ms_per_step": round(v[1] / args.steps, 3), "achieved": round(a_, 2), "frac": round(a_ / peak, 4)}
+                   "ms_per_step": round(v[1] / args.steps, 3), "achieved": round(a_, 2), "peak": round(pipe_peak(k), 1),
+                   "frac": round(a_ / pipe_peak(k), 4)}
             if k.startswith("lstm_"):
                 us = 1e3 * v[1] / v[0] / T_mean
-                # per workgroup and time step: 16 batch rows x 64 gate columns x H, on 4 SIMDs
-                floor = (2.0 * 16 * 64 * H / 4) / (64.0 if args.dtype != "bf16" else 1024.0) / 2.4e3
+                # per workgroup and time step: 16 batch rows x 64 gate columns x H, on 4 SIMDs, at the rate of the pipe the
+                # products run on (FLOP per clock and SIMD: fp32 MFMA 64, six bf16 piece products 1024 / 6, bf16 1024)
+                rate = 1024.0 if args.dtype == "bf16" else (1024.0 / 6.0 if pipe_peak(k) == PEAK_F32_SPLIT_TFLOPS else 64.0)
+                floor = (2.0 * 16 * 64 * H / 4) / rate / 2.4e3
                 row.update({"us_per_time_step": round(us, 3), "mfma_floor_us": round(floor, 3),
                             "handoff_us": round(us - floor, 3)})
             by[k] = row
@@ -455,7 +479,9 @@ def measure(args, env, standalone_pass=True):
         else:
             P = sum(2 * 4 * H * ((257 if l == 0 else 2 * H) + H) for l in range(L)) + 2 * H * 257 * S
         res["step_tflops"] = round(6.0 * P * frames_per_step / world / (dt / args.steps) / 1e12, 2)
-        res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / peak, 4)   # the compute dtype's dense MFMA peak
+        # against the compute dtype's OWN dense MFMA peak (fp32: 157.3 TFLOP/s -- a yardstick, not a bound, for a step whose
+        # large products run on the bf16 pipe as split products: see roofline.peak_note)
+        res["step_frac_of_mfma_peak"] = round(res["step_tflops"] / peak, 4)
     return res, (pcms, T_mean)
 
 
@@ -596,15 +622,21 @@ def numerics_note(model, args):
     eng = model._engine
     if args.dtype == "bf16":
         return "bf16 matrix-core inputs for every product incl. the recurrences, fp32 accumulate / state / optimizer"
+    gemms = ("products with aligned operands (the large GEMMs: 99 % of the GEMM FLOP) are formed on the bf16 matrix pipe by the three-way "
+             "bf16 split of both fp32 operands -- x = hi + mid + lo exactly, pieces by rounding; the six piece products of relative "
+             "size >= 2^-18, each exact, are added into fp32 accumulators; the three left out are together <= 2^-26 of the product "
+             "(a quarter of an fp32 multiplier's own rounding): error vs fp64 not above the fp32-MFMA kernels' "
+             "(tests/test_gpu_kernels.py); SEPKERN_GEMM_SPLIT=0 = fp32-MFMA kernels throughout")
+    if os.environ.get("SEPKERN_GEMM_SPLIT", "1") == "0" or (eng is not None and eng.var_main not in (0, 2, 7)):
+        gemms = "GEMMs on the fp32-MFMA kernels"
     if eng is not None and eng.split3_fwd:
-        return ("fp32 throughout; the forward recurrence forms h W_hh^T by the exact three-way bf16 split of both fp32 operands "
-                "on the bf16 matrix pipe (the six piece products per element pair of relative size >= 2^-16, each exact, fp32 "
-                "accumulators; the three left out are <= half an ulp of the fp32 product: error vs fp64 not above the fp32-MFMA "
-                "kernel's, tests/test_gpu_kernels.py; no operand perturbed); SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = plain fp32-MFMA product")
+        return ("fp32 storage, fp32 accumulation, no operand perturbed; " + gemms + "; the forward recurrence forms h W_hh^T the same way "
+                "(SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = plain fp32-MFMA product); backward recurrence: fp32-MFMA products")
     if eng is not None and eng.tagged_fwd and eng.lstm_mode != 2:
-        return ("fp32 throughout; forward-recurrence hand-off 'tagged': the operand h entering h W_hh^T carries a 2-bit epoch "
-                "in its low mantissa bits (<= 3 ulp), all stored values exact; SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = exact hand-off")
-    return "fp32 throughout, fp32-MFMA products, exact hand-off (flags)"
+        return ("fp32 storage and accumulation; " + gemms + "; forward-recurrence hand-off 'tagged': the operand h entering h W_hh^T "
+                "carries a 2-bit epoch in its low mantissa bits (<= 3 ulp), all stored values exact; SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = "
+                "exact hand-off")
+    return "fp32 storage and accumulation; " + gemms + "; recurrences: fp32-MFMA products, exact hand-off (flags)"
 
 
 def aux_kernels(torch, ops, pcms, T, B, S):

@@ -97,6 +97,11 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * 256 x 256 tile without the stream-K cut: retired in r04.)  Variant 4's 256 x 128 kernel is what variant 0 falls back to for a large
  * unsplit product whose stream-K preconditions fail (no ws given, a last round too short to cut). */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
+/* Which kernel the calling thread's LAST sk_gemm_f32[_splitk] / sk_gemm_bf16_splitk launch took (profiling: bench.py prices a
+ * launch against the peak of the matrix pipe it ran on): 1 register-staged fp32 MFMA, 3 / 4 / 6 the 128 x 128 / 256 x 128 /
+ * stream-K fp32-MFMA LDS-DMA kernels, 2 / 7 the 128 x 128 / stream-K SPLIT kernels (bf16 pipe, six piece products), 9 bf16 inputs;
+ * 0 before the first launch. */
+int sk_gemm_last_kernel(void);
 size_t sk_gemm_streamk_workspace_bytes(void);
 /* Zero the ticket counters at the head of a split-K workspace (once, before its first use; a buffer that was allocated
  * zero-filled needs no call). */

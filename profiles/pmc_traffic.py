@@ -14,7 +14,13 @@ import json
 import os
 import sys
 
-KEYS = ("gemm_f32_kernel", "gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "hprev_rows_kernel", "lstm_fwd_kernel",
+def is_split(name):
+    """fp32 products on the bf16 pipe: gemm_f32_kernel_split3<..> and the S6 form gemm_f32_kernel_streamk<.., .., true>."""
+    import re
+    return "gemm_f32_kernel_split3" in name or re.search(r"gemm_f32_kernel_streamk<\w+, \w+, true>", name) is not None
+
+
+KEYS = ("gemm_f32_split_kernel", "gemm_f32_kernel", "gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "hprev_rows_kernel", "lstm_fwd_kernel",
         "lstm_bwd_kernel", "clip_adam", "pit_pair", "pit_bwd", "bn_apply", "bn_bwd", "splitk_reduce", "colred", "sumsq")
 BF16_ONLY = ("gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel")
 
@@ -44,7 +50,9 @@ def main():
                               recursive=True)
             for r in csv.DictReader(open(files[0])):
                 for k in KEYS:
-                    if k in r["Kernel_Name"] and (dt == "f32" or k in BF16_ONLY):
+                    name = r["Kernel_Name"]
+                    hit = is_split(name) if k == "gemm_f32_split_kernel" else (k in name and not (k == "gemm_f32_kernel" and is_split(name)))
+                    if hit and (dt == "f32" or k in BF16_ONLY):
                         acc[k][c].append(float(r["Counter_Value"]))
     res = {}
     for k, e in acc.items():

@@ -15,6 +15,10 @@
 #include "sk_common.h"
 
 namespace {
+thread_local int t_last_kernel = 0;  // which kernel this thread's last launch took: sk_gemm_last_kernel()
+}
+
+namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int GROUP_M = 8;  // tile rows per L2 working-set group (see the kernels' tile order)
@@ -568,6 +572,58 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_dma256(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
+// The three-way bf16 split of an fp32 operand (used by the S6 form of the stream-K kernel and by gemm_f32_kernel_split3 below;
+// the arithmetic is described there): x = hi + mid + lo exactly, three bf16 pieces.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Split3 {
+  bf16x8_t hi, mid, lo;
+};
+
+// Pieces by ROUND-TO-NEAREST (v_cvt_pk_bf16_f32): hi = bf16(x), r = x - hi (exact: a multiple of ulp(x), |r| <= 2^-9 |x|),
+// mid = bf16(r), lo = r - mid (exact, |lo| <= 2^-9 |r| <= 2^-18 |x|, at most 8 significant bits: IS a bf16).  (r04 cut by
+// truncation: one instruction fewer per pair, but then |mid| < 2^-7 |x|, |lo| < 2^-15 |x| and all pieces share x's sign -- the
+// products left out below were up to 2^-21 of a b and a systematic shrink; rounded pieces make them <= 2^-26 and signless.)
+// Operands beyond bf16's finite range (|x| > 3.39e38) round to inf.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Split3 split3(const float (&v)[8]) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const f32x2 x = {v[2 * j], v[2 * j + 1]};
+    h[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));  // element 2j in the low half
+    const f32x2 xh = {__uint_as_float(h[j] << 16), __uint_as_float(h[j] & 0xffff0000u)};
+    const f32x2 r = x - xh;  // exact
+    m[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+    const f32x2 rh = {__uint_as_float(m[j] << 16), __uint_as_float(m[j] & 0xffff0000u)};
+    const f32x2 q = r - rh;  // exact, <= 8 significant bits
+    l[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2_t));
+  }
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  Split3 o;
+  o.hi = __builtin_bit_cast(bf16x8_t, (u32x4){h[0], h[1], h[2], h[3]});
+  o.mid = __builtin_bit_cast(bf16x8_t, (u32x4){m[0], m[1], m[2], m[3]});
+  o.lo = __builtin_bit_cast(bf16x8_t, (u32x4){l[0], l[1], l[2], l[3]});
+  return o;
+}
+
+__device__ __forceinline__ void mma9(f32x16& acc, const Split3& a, const Split3& b) {
+  // small terms first (it is one fp32 accumulator either way); SK_SPLIT_NINE: all nine piece products (diagnostic build)
+#ifdef SK_SPLIT_NINE
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.lo, acc, 0, 0, 0);
+#endif
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.mid, b.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
+}
+
+
+// ------------------------------------------------------------------------------------------------------
 // 256 x 256 block tiles (eight waves of 64 x 128: per flop HALF the bytes global -> LDS of the 128 x 128 kernels and 3/4 of
 // their fragment bytes) as a PERSISTENT stream-K kernel (r03, variant 6; unsplit, unbatched products): one workgroup per
 // CU, P = gridDim.x of them.  With one workgroup per CU a partial last round of tiles costs a whole round (1400 tiles on
@@ -579,7 +635,13 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_dma256(GemmArgs g) {
 // the tile's pieces in workgroup order (deterministic), applies bias / accumulate / act and stores: nobody ever waits for
 // anybody, so the grid need not be co-resident.  The K steps of consecutive segments form ONE software pipeline: the
 // next segment's first two stages are in flight while a tile is stored.
-template <bool TA, bool TB>
+// S6 (variant 7): the same kernel with its products formed on the bf16 matrix pipe by the three-way split of both operands, six
+// piece products per element pair (gemm_f32_kernel_split3 below describes the arithmetic).  The fp32 images in LDS and the
+// fragment reads are the fp32 form's: a lane's two half-step reads of a fragment are 8 values of its row, k = 4 (kh + 2 cp) + i,
+// and since A and B fragments use the same k <-> slot map, they are a valid operand pair of v_mfma_f32_32x32x16_bf16 as they
+// are.  Per K step and wave: 6 fragments split once (216 VALU instructions) feed 48 MFMAs of 32 cycles -- each split fragment
+// is used by 2 (B) or 4 (A) products, twice the reuse of the 128 x 128 kernel's 64 x 64 wave tiles.
+template <bool TA, bool TB, bool S6 = false>
 __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
   constexpr int BMW = 256, BNW = 256;
   constexpr int TILE = BMW * BK * 4, STAGE = 2 * TILE;
@@ -694,19 +756,41 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
     fetch((cur + 2) % NST);
     const char* ai = lds[cur];
     const char* bi = lds[cur] + TILE;
+    if constexpr (S6) {
+      Split3 sa[2], sb[4];
 #pragma unroll
-    for (int cp = 0; cp < 2; ++cp) {
-      float a[2][4], bb[4][4];
+      for (int i = 0; i < 2; ++i) {
+        float lo4[4], hi4[4];
+        frag_load_w<TA, BMW>(ai, fa[i], 0, lo4);
+        frag_load_w<TA, BMW>(ai, fa[i], 1, hi4);
+        const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        sa[i] = split3(v);
+      }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) frag_load_w<TA, BMW>(ai, fa[i], cp, a[i]);
+      for (int j = 0; j < 4; ++j) {
+        float lo4[4], hi4[4];
+        frag_load_w<!TB, BNW>(bi, fb[j], 0, lo4);
+        frag_load_w<!TB, BNW>(bi, fb[j], 1, hi4);
+        const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        sb[j] = split3(v);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) frag_load_w<!TB, BNW>(bi, fb[j], cp, bb[j]);
+        for (int i = 0; i < 2; ++i) mma9(acc[i][j], sa[i], sb[j]);
+      }
+    } else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int cp = 0; cp < 2; ++cp) {
+        float a[2][4], bb[4][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) frag_load_w<TA, BMW>(ai, fa[i], cp, a[i]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], bb[j][k], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) frag_load_w<!TB, BNW>(bi, fb[j], cp, bb[j]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][k], bb[j][k], acc[i][j], 0, 0, 0);
+      }
     }
     cur = (cur + 1) % NST;
     if (++ck < cke) continue;
@@ -773,6 +857,118 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
     clear();
     if (++ci < nseg) segment(ci, cv, ck, cke);
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fp32 product on the bf16 matrix pipe by an EXACT three-way split (variant 2 of sk_gemm_f32_splitk, opt-in).
+// Every fp32 operand element x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits = 3 x 8:
+// hi = the top 8, taken by truncation; x - hi is exact in fp32 and has at most 16 significant bits; again for mid; what
+// is left has at most 8 bits and IS a bf16).  a*b is then the sum of the nine piece products, each of which is exact in
+// fp32 (8 x 8 bits), and the matrix cores add them into the same fp32 accumulators as always -- so this is an fp32 GEMM
+// with another summation order, not a lower-precision one (tests: error against fp64 no larger than the fp32-MFMA
+// kernel's).  Nine v_mfma_f32_32x32x16_bf16 (8 passes each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (16 passes
+// each): 72 passes instead of 128 per 32 x 32 x 16 block, for ~5.5 VALU instructions per operand element to split it
+// (other waves' products run meanwhile).  Operand tiles are DMA'd into LDS as fp32 exactly as in gemm_f32_kernel_dma;
+// the K order is the natural one (lane holds k = 8 (lane>>5) .. +7 of its row, the bf16 MFMA's fragment shape).
+// Non-finite inputs: x = +-inf splits into (inf, nan, nan): such a product is NaN where an fp32 FMA gives +-inf.
+// this lane's 8 consecutive-k fp32 values of its row of the 32-row fragment starting at d0
+template <bool KMAJOR>
+__device__ __forceinline__ void frag8_load(const char* img, int d0, int lane, float (&v)[8]) {
+  const int l31 = lane & 31, kh = lane >> 5;
+  if (KMAJOR) {
+    const int base = 8 * kh * 512 + ((d0 ^ (kh << 5)) + l31) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float*>(img + base + j * 512);
+  } else {
+    const int base = ((d0 + l31) >> 4) * 1024 + 2 * kh * 256 + (((l31 & 15) + 8 * kh) & 15) * 16;
+    const float4 p = *reinterpret_cast<const float4*>(img + base), q = *reinterpret_cast<const float4*>(img + base + 256);
+    v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w;
+    v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+  }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel_split3(GemmArgs g) {
+  constexpr int TILE = BM * BK * 4;  // 8 KB per operand image
+  __shared__ __attribute__((aligned(1024))) char lds[2][2 * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
+    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+  }
+  int m0, n0;
+  {
+    const int tilesM = gridDim.x / g.tilesN, per = GROUP_M * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GROUP_M;
+    const int gsz = min(GROUP_M, tilesM - first);
+    m0 = (first + rem2 % gsz) * BM;
+    n0 = (rem2 / gsz) * BN;
+  }
+  const int z = blockIdx.z, ks = blockIdx.y;
+  const float* A = g.A + z * g.sA;
+  const float* B = g.B + z * g.sB;
+  const bool partial = g.splitk > 1;
+  float* C = partial ? g.slabs + ((int64_t)z * g.splitk + ks) * g.M * g.N : g.C + z * g.sC;
+  const int ldc = partial ? g.N : g.ldc;
+  const float* bias = (g.bias && !partial) ? g.bias + z * g.sbias : nullptr;
+  const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / BK;
+
+  const float* srcA[2];
+  const float* srcB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    srcA[i] = dma_src<TA, 3>(A, g.lda, m0, g.M, kbeg, 2 * wave + i, lane);
+    srcB[i] = dma_src<!TB, 3>(B, g.ldb, n0, g.N, kbeg, 2 * wave + i, lane);
+  }
+  const int64_t stepA = TA ? (int64_t)BK * g.lda : BK, stepB = !TB ? (int64_t)BK * g.ldb : BK;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
+  const unsigned my_pieces = __builtin_amdgcn_readfirstlane(lds_base + 2 * wave * 1024);
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dma_1k(srcA[i], my_pieces + buf * 2 * TILE + i * 1024);
+      dma_1k(srcB[i], my_pieces + buf * 2 * TILE + TILE + i * 1024);
+      srcA[i] += stepA;
+      srcB[i] += stepB;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) stage(0);
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage(cur ^ 1);
+    const char* ai = lds[cur];
+    const char* bi = lds[cur] + TILE;
+    float va0[8], va1[8], vb0[8], vb1[8];
+    frag8_load<TA>(ai, wm * 64, lane, va0);
+    frag8_load<!TB>(bi, wn * 64, lane, vb0);
+    frag8_load<TA>(ai, wm * 64 + 32, lane, va1);
+    frag8_load<!TB>(bi, wn * 64 + 32, lane, vb1);
+    const Split3 a0 = split3(va0), b0 = split3(vb0);
+    mma9(acc[0][0], a0, b0);
+    const Split3 a1 = split3(va1);
+    mma9(acc[1][0], a1, b0);
+    const Split3 b1 = split3(vb1);
+    mma9(acc[0][1], a0, b1);
+    mma9(acc[1][1], a1, b1);
+    cur ^= 1;
+  }
+  store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
+  if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1580,7 +1776,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                 int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
-  SK_CHECK_ARG(variant >= 0 && variant <= 6 && variant != 5 && variant != 2, "sk_gemm: unknown variant %d", variant);
+  SK_CHECK_ARG(variant >= 0 && variant <= 8 && variant != 5, "sk_gemm: unknown variant %d", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
@@ -1598,19 +1794,31 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), bk) * bk);
   splitk = (int)sk_cdiv(K, g.kchunk);  // slices that actually hold work
   g.splitk = splitk;
-  // 256 x 128 block tiles, 8 waves: variant 4, or chosen (variant 0) for the large unsplit N/T and N/N products -- measured
-  // +2 % / +5 % on them stand-alone and 37.50 / 37.61 / 37.65 vs 37.73 / 37.98 / 37.85 ms on the training step (one call);
-  // with split-K launches included the step does not move.  SEPKERN_GEMM_WIDE=0 (diagnostics): never chosen.
+  // ---- which kernel.  fp32 products run by default (variant 0) on the bf16 matrix pipe by the three-way split of both operands
+  // with six piece products (gemm_f32_kernel_split3 / the S6 form of the stream-K kernel) wherever the LDS-DMA conditions
+  // hold: 160-173 TFLOP/s fp32-equivalent on the training step's large products against 124-135 of the fp32-MFMA kernels
+  // (stand-alone, one MI355X), 30.1 vs 34.7 ms per training step.  Variant 8 = the r04 choice among the fp32-MFMA kernels
+  // (SEPKERN_GEMM_SPLIT=0 makes variant 0 that); operands with unaligned rows or K % 16 != 0 take the fp32-MFMA kernels always.
+  static const bool split_on = [] { const char* e = getenv("SEPKERN_GEMM_SPLIT"); return !(e && e[0] == '0'); }();
+  // the stream-K form of the split kernel: 0 never, 1 (default) the large unsplit N/N and T/N products with a long K (data
+  // gradients: 172.8 vs 164.0 TFLOP/s, the unsplit T/N weight gradient 172.0 vs 141.3), 2 also the N/T projections
+  static const int split_sk = [] { const char* e = getenv("SEPKERN_GEMM_SPLIT_SK"); return e ? atoi(e) : 1; }();
+  if (variant == 0 && !split_on) variant = 8;
+  const bool split = !bf16 && (variant == 0 || variant == 2 || variant == 7) && dma_ok(g, transA, transB);
+  const bool mfma_choose = variant == 8 || (variant == 0 && !split);  // the r04 policy among the fp32-MFMA kernels
+  // 256 x 128 block tiles, 8 waves (fp32 MFMA): variant 4, or chosen for the large unsplit N/T and N/N products -- measured
+  // +2 % / +5 % on them stand-alone.  SEPKERN_GEMM_WIDE=0 (diagnostics): never chosen.
   static const bool wide_ok = [] { const char* e = getenv("SEPKERN_GEMM_WIDE"); return !(e && e[0] == '0'); }();
-  const bool wide = !bf16 && M >= 256 && dma_ok(g, transA, transB) &&
-                    (variant == 4 || variant == 6 || (variant == 0 && wide_ok && !transA && M >= 4096 && N >= 1024 && splitk == 1));
-  // 256 x 256 tiles, persistent, with a stream-K cut of the last partial round: variant 6, or chosen (variant 0) for the large
-  // unsplit N/T and N/N products when the caller passes the workspace of sk_gemm_streamk_workspace_bytes() -- measured
-  // 124.4 vs 121.5 TFLOP/s on the input projections, 134.6 vs 125.5 on the data gradients, 36.05 vs 36.63 ms on the training
-  // step (three alternations).  SEPKERN_GEMM_STREAMK=0 (diagnostics): never chosen.
+  const bool wide = !bf16 && !split && M >= 256 && dma_ok(g, transA, transB) &&
+                    (variant == 4 || variant == 6 || (mfma_choose && wide_ok && !transA && M >= 4096 && N >= 1024 && splitk == 1));
+  // 256 x 256 tiles, persistent, with a stream-K cut of the last partial round: variant 6 (fp32 MFMA) / 7 (split products), or
+  // chosen for large unsplit products when the caller passes the workspace of sk_gemm_streamk_workspace_bytes().
+  // SEPKERN_GEMM_STREAMK=0 (diagnostics): never chosen.
   static const bool streamk_ok = [] { const char* e = getenv("SEPKERN_GEMM_STREAMK"); return !(e && e[0] == '0'); }();
-  bool streamk = !bf16 && ws && batch == 1 && M >= 256 && N >= 256 && splitk == 1 && dma_ok(g, transA, transB) &&
-                 (variant == 6 || (variant == 0 && streamk_ok && !transA && M >= 4096 && N >= 1024));
+  const bool sk_shape = ws && batch == 1 && M >= 256 && N >= 256 && splitk == 1 && dma_ok(g, transA, transB);
+  const bool sk_split = split && sk_shape && (variant == 7 || (variant == 0 && streamk_ok && M >= 4096 && N >= 1024 &&
+                                                               ((split_sk >= 1 && !transB && K >= 4096) || (split_sk >= 2 && !transA))));
+  bool streamk = !bf16 && sk_shape && (sk_split || (!split && (variant == 6 || (mfma_choose && streamk_ok && !transA && M >= 4096 && N >= 1024))));
   if (streamk) {
     const int P = streamk_wgs();
     const int64_t nt = sk_cdiv(M, 256) * sk_cdiv(N, 256), nk = K / BK;
@@ -1629,6 +1837,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.counters = inkernel ? (unsigned*)ws : nullptr;
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
+  t_last_kernel = bf16 ? 9 : streamk ? (split ? 7 : 6) : wide ? 4 : split ? 2 : (variant != 1 && dma_ok(g, transA, transB, mfma_choose)) ? 3 : 1;
   if (bf16) {
     if (!transA && !transB)
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, g);
@@ -1641,7 +1850,14 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   } else if (streamk) {
     g.counters = (unsigned*)ws;
     const dim3 pgrid((unsigned)streamk_wgs());
-    if (!transA && !transB)
+    if (split) {
+      if (!transA && !transB)
+        hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, false, true>), pgrid, dim3(512), 0, st, g);
+      else if (!transA && transB)
+        hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, true, true>), pgrid, dim3(512), 0, st, g);
+      else
+        hipLaunchKernelGGL((gemm_f32_kernel_streamk<true, false, true>), pgrid, dim3(512), 0, st, g);
+    } else if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, false>), pgrid, dim3(512), 0, st, g);
     else if (!transA && transB)
       hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, true>), pgrid, dim3(512), 0, st, g);
@@ -1654,7 +1870,14 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((gemm_f32_kernel_dma256<false, true>), grid, dim3(512), 0, st, g);
     else
       hipLaunchKernelGGL((gemm_f32_kernel_dma256<true, false>), grid, dim3(512), 0, st, g);
-  } else if (variant != 1 && dma_ok(g, transA, transB, variant == 0)) {
+  } else if (split) {
+    if (!transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_kernel_split3<false, false>), grid, dim3(256), 0, st, g);
+    else if (!transA && transB)
+      hipLaunchKernelGGL((gemm_f32_kernel_split3<false, true>), grid, dim3(256), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel_split3<true, false>), grid, dim3(256), 0, st, g);
+  } else if (variant != 1 && dma_ok(g, transA, transB, mfma_choose)) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_dma<false, false>), grid, dim3(256), 0, st, g);
     else if (!transA && transB)
@@ -1805,3 +2028,5 @@ extern "C" int sk_cast_bf16_rows(const float* src, int R, int C, int ld_src, voi
   SK_CHECK_LAUNCH("sk_cast_bf16");
   return SK_OK;
 }
+
+extern "C" int sk_gemm_last_kernel(void) { return t_last_kernel; }

@@ -53,25 +53,27 @@ __device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((
 
 // S3 variant of the forward kernel (mode bit 28): the fp32 product h W_hh^T on the bf16 matrix pipe by an EXACT three-way
 // split of both operands.  An fp32 value x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits =
-// 3 x 8: hi = the top 8 by truncation; x - hi is exact and has <= 16 significant bits; again for mid; what is left IS a bf16).
-// w h is the sum of nine piece products, each exact in fp32 (8 x 8 bits), of relative sizes 1 (hi hi), 2^-8 (hi mid, mid hi),
-// 2^-16 (hi lo, mid mid, lo hi), 2^-24 (mid lo, lo mid) and 2^-32 (lo lo).  The kernel forms the SIX of size >= 2^-16 and
+// 3 x 8; by rounding to nearest: hi = bf16(x), x - hi is exact and <= 2^-9 |x|; again for mid; what is left IS a bf16, <= 2^-18 |x|).
+// w h is the sum of nine piece products, each exact in fp32 (8 x 8 bits), of relative sizes 1 (hi hi), 2^-9 (hi mid, mid hi),
+// 2^-18 (hi lo, mid mid, lo hi), 2^-27 (mid lo, lo mid) and 2^-36 (lo lo).  The kernel forms the SIX of size >= 2^-18 and
 // adds them into fp32 accumulators with v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32): 96 matrix-pipe cycles per 32 k
-// instead of the 256 of eight v_mfma_f32_16x16x4_f32.  The three it leaves out lie at or below HALF AN ULP of the fp32 product
-// they belong to -- what an fp32 multiplier rounds away itself -- and far below the rounding of the fp32 accumulation that
-// follows: against an fp64 sum (K = 896, operands of the recurrence's scale) the six-product form has the error of the
+// instead of the 256 of eight v_mfma_f32_16x16x4_f32.  The three it leaves out are together <= 2^-26 of the product they
+// belong to, a QUARTER of the half ulp an fp32 multiplier rounds away itself, and far below the rounding of the fp32
+// accumulation that follows: against an fp64 sum (K = 896, operands of the recurrence's scale) the six-product form has the error of the
 // nine-product form (rms 2.21e-7 vs 2.19e-7) and less than the fp32-MFMA kernel's own (2.50e-7), and differs from the nine-
 // product form by 7x less than that differs from the fp32-MFMA kernel (tests/test_gpu_kernels.py pins this on the device).
 // So this is an fp32 product in another summation order; no operand is perturbed.  W_hh is split once per launch (three
 // register pieces: 168 instead of 112 VGPRs), h by its producer before it publishes (three bf16 images: 6 instead of 4 bytes
 // per cell).  (r04 shipped all nine products: 144 cycles per 32 k.)
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  const unsigned xu = __builtin_bit_cast(unsigned, x);
-  const float r = x - __builtin_bit_cast(float, xu & 0xffff0000u);  // exact
-  const unsigned ru = __builtin_bit_cast(unsigned, r);
-  const float q = r - __builtin_bit_cast(float, ru & 0xffff0000u);  // exact, <= 8 significant bits
-  hi = xu >> 16;
-  mid = ru >> 16;
+  // pieces by round-to-nearest: hi = bf16(x); r = x - hi is exact, |r| <= 2^-9 |x|; mid = bf16(r); lo = r - mid is exact, has
+  // at most 8 significant bits (IS a bf16) and |lo| <= 2^-18 |x|
+  const __bf16 h = (__bf16)x;
+  const float r = x - (float)h;
+  const __bf16 m = (__bf16)r;
+  const float q = r - (float)m;
+  hi = (unsigned)__builtin_bit_cast(unsigned short, h);
+  mid = (unsigned)__builtin_bit_cast(unsigned short, m);
   lo = __builtin_bit_cast(unsigned, q) >> 16;
 }
 // 8 consecutive-k fp32 values -> the three bf16x8 piece vectors

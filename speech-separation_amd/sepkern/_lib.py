@@ -27,6 +27,7 @@ PROTOTYPES = {
     "sk_gemm_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _p]),
     "sk_gemm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sk_gemm_streamk_workspace_bytes": (_sz, []),
+    "sk_gemm_last_kernel": (_i, []),
     "sk_gemm_workspace_init": (_i, [_p, _p]),
     "sk_gemm_f32_splitk": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _i, _p]),
     "sk_gemm_bf16_splitk": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),

@@ -118,9 +118,11 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     first element of the operand (views are fine: leading dimensions are explicit).  splitk > 1 (or 0 =
     choose) splits K into deterministic partial slabs -- for weight gradients.  bf16=True rounds A and B to
     bf16 on the way into the matrix cores (fp32 accumulate; everything in memory stays fp32).  variant (fp32 only,
-    sk_gemm_f32_splitk's `variant`): 0 choose, 1 the register-staged kernel even where the LDS-DMA one applies,
-    2 exact three-way bf16 split of both operands on the bf16 matrix pipe (fp32 products, another summation order),
-    3 / 4 / 5 the 128 x 128 / 256 x 128 / 256 x 256-tile LDS-DMA kernels, 6 the persistent stream-K form of 5."""
+    sk_gemm_f32_splitk's `variant`): 0 choose -- the three-way bf16 split of both operands on the bf16 matrix pipe (six piece
+    products per element pair: fp32 products in another summation order) wherever the operands are aligned, else the
+    fp32-MFMA kernels; 1 the register-staged fp32-MFMA kernel; 2 / 7 the 128 x 128 / persistent 256 x 256 stream-K split
+    kernels; 3 / 4 / 6 the 128 x 128 / 256 x 128 / stream-K 256 x 256 fp32-MFMA LDS-DMA kernels; 8 choose among the
+    fp32-MFMA kernels only (the r04 default; SEPKERN_GEMM_SPLIT=0 makes 0 mean this)."""
     for t in (A, B, Cout, bias):
         _chk(t)
     if splitk == 0:
@@ -128,15 +130,19 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     ws = None
     if splitk > 1:
         ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
-    elif not bf16 and batch == 1 and (variant == 6 or (variant == 0 and _STREAMK and not transA and M >= 4096 and N >= 1024)):
+    elif not bf16 and batch == 1 and (variant in (6, 7) or (_STREAMK and M >= 4096 and N >= 1024 and
+                                                (variant == 0 or (variant == 8 and not transA)))):
         ws = _streamk_ws()                                                              # pieces of the stream-K cut
-    with _timed("gemm_bf16_kernel" if bf16 else "gemm_f32_kernel", 2.0 * M * N * K * batch):
+    with _timed("gemm_bf16_kernel" if bf16 else "gemm_f32_kernel", 2.0 * M * N * K * batch) as rec:
         args = (_ptr(A), _ptr(B), _ptr(Cout), _ptr(bias), M, N, K, lda, ldb, ldc, int(transA), int(transB), int(accumulate),
                 int(act), batch, sA, sB, sC, sbias, int(splitk), _ptr(ws))
         if bf16:
             _lib.call("sk_gemm_bf16_splitk", *args, _stream())
         else:
             _lib.call("sk_gemm_f32_splitk", *args, int(variant), _stream())
+            if PROF is not None and _lib.load().sk_gemm_last_kernel() in (2, 7):
+                # the launch ran on the bf16 matrix pipe (split products): its own class -- another pipe, another peak
+                rec.cls = "gemm_f32_split_kernel"
 
 
 def _streamk_ws():

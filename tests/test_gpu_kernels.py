@@ -49,6 +49,60 @@ def test_gemm_matches_fp64(ops, M, N, K, tA, tB):
     np.testing.assert_allclose(C.cpu().numpy(), ref.numpy(), atol=2e-5 * np.sqrt(K) * 4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,tA,tB", [(300, 260, 512, False, True), (300, 260, 528, False, False), (132, 516, 1024, True, False),
+                                         (1000, 772, 1792, False, True), (517, 1792, 3584, False, False), (1028, 132, 2048, True, False),
+                                         (4, 4, 16, True, False)])
+def test_gemm_exact_bf16_split_is_an_fp32_product(ops, M, N, K, tA, tB):
+    """variant 2 of sk_gemm_f32_splitk: both fp32 operands cut exactly into three bf16 pieces; the six piece products per
+    element pair of relative size >= 2^-16 (each exact) are added on the bf16 matrix pipe into fp32 accumulators, the three
+    of size <= 2^-24 -- at or below half an ulp of the fp32 product -- are not formed.  That is an fp32 GEMM in another
+    summation order: it meets the fp32 kernel's tolerance against fp64, and its error is not larger than the fp32-MFMA
+    kernel's on the same operands (wide dynamic range: elements scaled by 2^-20 .. 2^20, so every piece carries weight)."""
+    g = torch.Generator().manual_seed(M * 13 + N)
+    scale = lambda shape: torch.exp2(torch.randint(-20, 21, shape, generator=g).float())
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    A = A * scale(A.shape)                     # element-wise: terms of very different size meet in every sum
+    B = B * scale(B.shape)
+    bias = torch.randn(N, generator=g)
+    ref = (A.double().t() if tA else A.double()) @ (B.double().t() if tB else B.double()) + bias.double()
+    mag = (A.double().abs().t() if tA else A.double().abs()) @ (B.double().abs().t() if tB else B.double().abs())
+    outs = []
+    for variant in (2, 0):
+        C = torch.full((M, N), float("nan")).cuda()
+        ops.gemm(dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N, transA=tA, transB=tB, bias=dev(bias), variant=variant)
+        torch.cuda.synchronize()
+        outs.append(C.cpu().double())
+    err_split = ((outs[0] - ref).abs() / mag.clamp_min(1e-30)).max().item()
+    err_f32 = ((outs[1] - ref).abs() / mag.clamp_min(1e-30)).max().item()
+    # a K-term fp32 sum: errors of a few ulp relative to sum |a||b|
+    assert err_split <= 2.0 ** -23 * 4 * np.sqrt(K), (err_split, err_f32)
+    assert err_split <= max(2.0 * err_f32, 2.0 ** -22), (err_split, err_f32)
+
+
+def test_gemm_exact_bf16_split_pieces_reassemble_single_products(ops):
+    """K = 16 with ONE non-zero term per output: C[m, n] = a[m] * b[n] must then be the fp32 product to within 2 ulp (the six
+    piece products formed miss the exact 48-bit product by the three smallest, <= 2^-23 of it together, and are rounded once
+    at each accumulation), and exact whenever both factors have <= 16 significant bits (nothing is left out then)."""
+    g = torch.Generator().manual_seed(99)
+    M, N, K = 128, 128, 16
+    a = torch.randn(M, generator=g) * torch.exp2(torch.randint(-30, 31, (M,), generator=g).float())
+    b = torch.randn(N, generator=g) * torch.exp2(torch.randint(-30, 31, (N,), generator=g).float())
+    A, B = torch.zeros(M, K), torch.zeros(N, K)
+    A[:, 5], B[:, 5] = a, b
+    C = torch.empty(M, N).cuda()
+    ops.gemm(dev(A), dev(B), C, M, N, K, K, K, N, transB=True, variant=2)
+    exact = a.double()[:, None] * b.double()[None, :]
+    rel = ((C.cpu().double() - exact).abs() / exact.abs()).max().item()
+    assert rel <= 2.0 ** -22, rel
+    # powers of two times small integers: representable products must come out exact
+    ai = torch.randint(-255, 256, (M,), generator=g).float() * 2.0 ** 7
+    bi = torch.randint(-255, 256, (N,), generator=g).float() * 2.0 ** -9
+    A[:, 5], B[:, 5] = ai, bi
+    ops.gemm(dev(A), dev(B), C, M, N, K, K, K, N, transB=True, variant=2)
+    assert torch.equal(C.cpu(), ai[:, None] * bi[None, :])
+
+
 @pytest.mark.parametrize("M,N,K,tA,tB", [
     (300, 200, 257, False, True), (256, 256, 64, False, False), (256, 256, 64, True, False), (256, 256, 64, False, True),
     (256, 256, 64, True, True), (130, 514, 96, False, True), (1000, 72, 1, False, False), (129, 131, 300, True, False),
