@@ -69,7 +69,7 @@ int sk_mask_istft(const void* mix_c64, const int64_t* mix_offs, const int64_t* m
                   float* wav_out, int16_t* pcm_out, const int64_t* out_offs, int max_frames,
                   sk_stream_t stream);
 
-/* ---------------------------------------------------------------- fp32 MFMA GEMM
+/* ---------------------------------------------------------------- fp32 GEMM (matrix cores)
  * C[M,N] (ldc) = act( opA(A) * opB(B) + bias[n] + (accumulate ? C : 0) ).
  * transA == 0: A is M x K row-major (lda); transA != 0: A is stored K x M row-major (lda).
  * transB == 0: B is K x N row-major (ldb); transB != 0: B is stored N x K row-major (ldb).
@@ -84,18 +84,28 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * (a ticket counter per tile at the head of ws) adds the slabs in fixed slice order and applies bias / accumulate /
  * act -- deterministic, no floating-point atomics, no second launch (the bf16 kernels use a second kernel for the same
  * sums).  ws must be ZERO-FILLED before its first use; every launch leaves its head (the counters) zeroed again.
- * variant (speed only, results agree to fp32 summation order): 0 = choose -- operand tiles DMA'd straight into LDS when
- * every operand row is 16-byte aligned and K is a multiple of 16, the register-staged kernel otherwise; 1 = always
- * the register-staged kernel (the engine's choice for products it runs co-resident with a recurrence: it leaves
- * the recurrence more of the matrix pipe); 3 = the 128 x 128-tile LDS-DMA kernel wherever it applies, 4 = its 256 x 128-tile, 8-wave form
- * wherever that applies (diagnostics; 0 picks among 1, 3 and 4 by shape); 6 = 256 x 256 tiles, one PERSISTENT workgroup
- * per CU with a stream-K cut of the last partial round of tiles (unsplit, unbatched products; splitk = 1 and
- * ws >= sk_gemm_streamk_workspace_bytes(), zero-filled before its first use and left with zeroed counters by every
- * launch; without ws it is variant 4; variant 0 chooses it for the large N/T and N/N products when splitk = 1 and a ws
- * is given, SEPKERN_GEMM_STREAMK=0: never).  Tiles of the cut are summed piece by piece in a fixed order: deterministic,
- * fp32 summation order differs from the other variants.  (2 was the exact three-way bf16 split of both operands, power-bound and neutral on the step: retired in r05; 5 was the
- * 256 x 256 tile without the stream-K cut: retired in r04.)  Variant 4's 256 x 128 kernel is what variant 0 falls back to for a large
- * unsplit product whose stream-K preconditions fail (no ws given, a last round too short to cut). */
+ * variant (which kernel; results agree to fp32 summation order -- every variant is an fp32 product with fp32 accumulation):
+ *   0  choose (the default everywhere).  Products whose operands allow LDS-DMA staging (every operand row 16-byte aligned, K a
+ *      multiple of 16, not the T/T form) run on the BF16 MATRIX PIPE by the three-way split of both fp32 operands: x = hi + mid + lo
+ *      exactly, three bf16 pieces made by rounding to nearest (|mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|); of the nine piece products
+ *      per element pair, each exact in fp32, the six of relative size >= 2^-18 are added into fp32 accumulators by
+ *      v_mfma_f32_32x32x16_bf16; the three of size <= 2^-27 -- together <= 2^-26 of the product, a quarter of the half ulp an
+ *      fp32 multiplier rounds away itself -- are not formed.  Error against fp64 is not above the fp32-MFMA kernels' (tests);
+ *      160-173 TFLOP/s fp32-equivalent on the training step's large products against 124-135 (one MI355X, stand-alone; the
+ *      fp32-MFMA pipe's own peak is 157).  Kernels: 2 (128 x 128 tiles; any splitk / batch) and, for large unsplit N/N and
+ *      T/N products with K >= 4096 when ws >= sk_gemm_streamk_workspace_bytes() is given, 7.  Other operands (F = 257 columns,
+ *      K = 514): the fp32-MFMA kernels as under 8.  Operands beyond bf16's finite range (|x| > 3.39e38) round to inf.
+ *      SEPKERN_GEMM_SPLIT=0 (diagnostics) makes 0 mean 8.
+ *   1  the register-staged fp32-MFMA kernel (v_mfma_f32_32x32x2_f32), any alignment
+ *   2  the 128 x 128-tile split kernel wherever the LDS-DMA conditions hold (else as 8)
+ *   3 / 4  the 128 x 128 / 256 x 128-tile fp32-MFMA LDS-DMA kernels wherever they apply (diagnostics)
+ *   6 / 7  256 x 256 tiles, one PERSISTENT workgroup per CU with a stream-K cut of the last partial round of tiles, fp32-MFMA (6) or
+ *      split products (7): unsplit, unbatched products; splitk = 1 and ws >= sk_gemm_streamk_workspace_bytes(), zero-filled
+ *      before its first use and left with zeroed counters by every launch (without ws: 4 / 2).  Tiles of the cut are summed
+ *      piece by piece in a fixed order: deterministic.
+ *   8  choose among the fp32-MFMA kernels only (the r04 default): LDS-DMA where the operands allow, stream-K (6) for the large
+ *      unsplit N/T and N/N products when a ws is given, the register-staged kernel otherwise.
+ *   (5 was the 256 x 256 tile without the stream-K cut: retired in r04.) */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 /* Which kernel the calling thread's LAST sk_gemm_f32[_splitk] / sk_gemm_bf16_splitk launch took (profiling: bench.py prices a
  * launch against the peak of the matrix pipe it ran on): 1 register-staged fp32 MFMA, 3 / 4 / 6 the 128 x 128 / 256 x 128 /

@@ -1,10 +1,16 @@
-// gemm.hip -- fp32-in / fp32-accumulate MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32).
+// gemm.hip -- fp32-in / fp32-accumulate matrix-core GEMM for gfx950.
 //
 // C[M,N] = act(opA(A) * opB(B) + bias + (accumulate ? C : 0)).  Used for everything on the uPIT
 // path that is a plain matrix product: the LSTM input projections for all T*B rows at once,
 // nn.Linear, and their dgrad / wgrad passes (reference archs/uPIT.py:132,141 via torch).
-// fp32 MFMA is bit-for-bit a k-ordered fmaf chain, so results match an fp32 reference to
-// rounding-order differences only.
+// Two families of kernels, both fp32 products with fp32 accumulation (results match an fp32 reference to
+// rounding-order differences only):
+//   * fp32 MFMA (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain): gemm_f32_kernel (register-staged, any
+//     alignment), _dma / _dma256 / _streamk (LDS-DMA staging);
+//   * SPLIT products on the bf16 matrix pipe (r05, the default wherever operands are aligned): both operands cut exactly into
+//     three bf16 pieces, six exact piece products per element pair -- gemm_f32_kernel_split3, gemm_f32_kernel_streamk<.., S6>;
+//     the bf16 pipe is 16x the fp32 one, so six products still leave 2.7x its rate.
+// The fp32-MFMA kernel's design notes follow.
 //
 // Tiling: 128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 MFMA tiles of 32x32
 // (64 accumulator VGPRs); K step 16, LDS double-buffered, operands kept k-major in LDS so the
@@ -860,17 +866,24 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// fp32 product on the bf16 matrix pipe by an EXACT three-way split (variant 2 of sk_gemm_f32_splitk, opt-in).
-// Every fp32 operand element x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits = 3 x 8:
-// hi = the top 8, taken by truncation; x - hi is exact in fp32 and has at most 16 significant bits; again for mid; what
-// is left has at most 8 bits and IS a bf16).  a*b is then the sum of the nine piece products, each of which is exact in
-// fp32 (8 x 8 bits), and the matrix cores add them into the same fp32 accumulators as always -- so this is an fp32 GEMM
-// with another summation order, not a lower-precision one (tests: error against fp64 no larger than the fp32-MFMA
-// kernel's).  Nine v_mfma_f32_32x32x16_bf16 (8 passes each, K = 16) replace eight v_mfma_f32_32x32x2_f32 (16 passes
-// each): 72 passes instead of 128 per 32 x 32 x 16 block, for ~5.5 VALU instructions per operand element to split it
-// (other waves' products run meanwhile).  Operand tiles are DMA'd into LDS as fp32 exactly as in gemm_f32_kernel_dma;
-// the K order is the natural one (lane holds k = 8 (lane>>5) .. +7 of its row, the bf16 MFMA's fragment shape).
-// Non-finite inputs: x = +-inf splits into (inf, nan, nan): such a product is NaN where an fp32 FMA gives +-inf.
+// fp32 product on the bf16 matrix pipe by an EXACT three-way split of both operands (variant 2 of sk_gemm_f32_splitk; what
+// variant 0 chooses for every product with aligned operands -- r05).
+// Every fp32 operand element x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits = 3 x 8; pieces by
+// rounding to nearest, see split3() above: |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|).  a*b is the sum of the nine piece products,
+// each exact in fp32 (8 x 8 bits), of relative sizes 1, 2^-9 (two), 2^-18 (three), 2^-27 (two), 2^-36.  The kernel forms the
+// SIX of size >= 2^-18 and the matrix cores add them into the same fp32 accumulators as always; the three it leaves out are
+// together <= 2^-26 of a*b -- a quarter of the half ulp an fp32 multiplier rounds away itself, and far below the rounding of
+// the fp32 accumulation that follows.  So this is an fp32 GEMM in another summation order, not a lower-precision one (tests:
+// error against fp64 not above the fp32-MFMA kernel's on operands spanning 2^+-20; single products within 1 ulp, exact when
+// both factors have <= 16 significant bits).  Six v_mfma_f32_32x32x16_bf16 (8 passes each, K = 16) replace eight
+// v_mfma_f32_32x32x2_f32 (16 passes each): 48 passes instead of 128 per 32 x 32 x 16 block, for 4.5 VALU instructions per
+// operand element to split it (other waves' products run meanwhile).  Measured (one MI355X, stand-alone): 160-168 TFLOP/s
+// fp32-equivalent on the training step's large products against 124-135 of the fp32-MFMA kernels (whose pipe peaks at 157);
+// sustained it is POWER-bound: 181 TFLOP/s at 1.9 GHz and 1375 W of the 1400 W cap (the fp32-MFMA kernels: 126-130 at 2.39 GHz,
+// 1140-1260 W).  (-DSK_SPLIT_NINE builds all nine products: 130 TFLOP/s, the r03 form.)  Operand tiles are DMA'd into LDS as
+// fp32 exactly as in gemm_f32_kernel_dma; the K order is the natural one (lane holds k = 8 (lane>>5) .. +7 of its row, the
+// bf16 MFMA's fragment shape).  Non-finite inputs: x = +-inf splits into (inf, nan, nan): such a product is NaN where an fp32
+// FMA gives +-inf; |x| > 3.39e38 rounds to inf.
 // this lane's 8 consecutive-k fp32 values of its row of the 32-row fragment starting at d0
 template <bool KMAJOR>
 __device__ __forceinline__ void frag8_load(const char* img, int d0, int lane, float (&v)[8]) {
