@@ -1,0 +1,22 @@
+#!/bin/bash
+# tuning of the 128 x 128 split kernel: LDS stages (DMA depth) and resident blocks per CU; stand-alone on the step's shapes, then the step
+R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r05_gemm_split_tuning.txt
+T=$R/speech-separation_amd/tools; L=$R/speech-separation_amd/sepkern
+: > $O
+S="--shape 12800,7168,1792,0,1 --shape 12800,1792,7168,0,0 --shape 7168,1792,12800,1,0,4 --shape 3584,896,12800,1,0,5 --shape 12800,514,1792,0,1"
+for v in default nst3 nst4 occ3 nst3occ3; do
+  if [ $v = default ]; then unset SEPKERN_LIB; else export SEPKERN_LIB=$L/libsepkern_$v.so; fi
+  echo "== $v (variant 2)" >> $O; python3 $T/gemm_bench.py --variant 2 $S >> $O 2>/dev/null || exit 1
+done
+for i in 1 2; do
+  for v in default nst3 nst4 occ3 nst3occ3; do
+    if [ $v = default ]; then unset SEPKERN_LIB; else export SEPKERN_LIB=$L/libsepkern_$v.so; fi
+    python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary 2> /dev/null |
+      python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels']
+print('%-9s run $i: %.3f ms/step  %.0f frames/s  ' % ('$v', d['ms_per_step'], d['value']) + '  '.join('%s %.2f' % (n, v['ms_per_step']) for n, v in sorted(k.items()) if v['ms_per_step'] > 1.0))" >> $O || exit 1
+  done
+done
+unset SEPKERN_LIB
+cat $O

@@ -900,10 +900,25 @@ __device__ __forceinline__ void frag8_load(const char* img, int d0, int lane, fl
   }
 }
 
+// LDS stages (the DMA runs NST - 1 K steps ahead of the products) and resident blocks per CU: tuning constants.  Measured (r05,
+// profiles/r05_gemm_split_tuning.txt): stand-alone 160-167 TFLOP/s whatever the stages (2, 3, 4) or the minimum occupancy (2, 3)
+// -- at 122 VGPRs and 32 KB of LDS four blocks are resident per CU and the waves of different blocks fill each other's VALU /
+// MFMA phases; in the training step more stages LOSE (48-64 KB of LDS per block: fewer blocks fit beside a recurrence workgroup,
+// 30.6-32.0 vs 29.7 ms).  A form software-pipelined across K steps (next step's fragment reads and splits in the shadow of this
+// step's MFMAs; 170 VGPRs, 3-4 stages) was built, passed the tests and was removed: 157-165 TFLOP/s, 30.6-32.0 ms in the step
+// (profiles/r05_gemm_split_pipe.txt) -- the kernel is bound by the work it issues (sustained: power), not by latency.
+#ifndef SK_SPLIT_NST
+#define SK_SPLIT_NST 2
+#endif
+#ifndef SK_SPLIT_OCC
+#define SK_SPLIT_OCC 2
+#endif
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel_split3(GemmArgs g) {
+__global__ __launch_bounds__(256, SK_SPLIT_OCC) void gemm_f32_kernel_split3(GemmArgs g) {
   constexpr int TILE = BM * BK * 4;  // 8 KB per operand image
-  __shared__ __attribute__((aligned(1024))) char lds[2][2 * TILE];
+  constexpr int NST = SK_SPLIT_NST;
+  static_assert(NST >= 2 && NST <= 4, "2..4 LDS stages");
+  __shared__ __attribute__((aligned(1024))) char lds[NST][2 * TILE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -958,12 +973,21 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel_split3(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nk > 0) stage(0);
+#pragma unroll
+  for (int i = 0; i < NST - 1; ++i)
+    if (i < nk) stage(i);
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage(cur ^ 1);
+    // step kt has landed when only the DMAs of the (up to NST - 2) stages issued after it may still fly: 4 instructions each
+    const int later = min(NST - 2, nk - 1 - kt);
+    if (later >= 2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // everybody's pieces of step kt have landed; all reads of the buffer refilled next are done
+    if (kt + NST - 1 < nk) stage((cur + NST - 1) % NST);
     const char* ai = lds[cur];
     const char* bi = lds[cur] + TILE;
     float va0[8], va1[8], vb0[8], vb1[8];
@@ -978,7 +1002,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel_split3(GemmArgs g) {
     const Split3 b1 = split3(vb1);
     mma9(acc[0][1], a0, b1);
     mma9(acc[1][1], a1, b1);
-    cur ^= 1;
+    cur = (cur + 1) % NST;
   }
   store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
   if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
