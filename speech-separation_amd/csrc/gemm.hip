@@ -593,6 +593,14 @@ struct Split3 {
 // Operands beyond bf16's finite range (|x| > 3.39e38) round to inf.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Split3 split3(const float (&v)[8]) {
+#ifdef SK_SPLIT_FREE  // TIMING-ONLY diagnostic (wrong numerics): the pieces cost nothing -- an upper bound for a kernel that finds them ready in LDS
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+  Split3 f;
+  f.hi = __builtin_bit_cast(bf16x8_t, (u32x4_){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
+  f.mid = __builtin_bit_cast(bf16x8_t, (u32x4_){__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])});
+  f.lo = __builtin_bit_cast(bf16x8_t, (u32x4_){__float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[5]), __float_as_uint(v[6])});
+  return f;
+#endif
   unsigned h[4], m[4], l[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
