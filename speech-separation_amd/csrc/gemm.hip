@@ -19,6 +19,7 @@
 // each other's barrier / staging gaps: measured 115 / 111 / 117 TFLOP/s on the large NT / NN / TN shapes
 // against 110 / 107 / 111 with BK = 32 (two blocks per CU).
 #include "sk_common.h"
+#include <type_traits>
 
 namespace {
 thread_local int t_last_kernel = 0;  // which kernel this thread's last launch took: sk_gemm_last_kernel()
@@ -1017,6 +1018,210 @@ __global__ __launch_bounds__(256, SK_SPLIT_OCC) void gemm_f32_kernel_split3(Gemm
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Split products with the split done ONCE per element (variant 9; N/T products: both operands stored with K contiguous).
+// gemm_f32_kernel_split3 / the S6 stream-K form stage fp32 tiles by LDS-DMA and every WAVE splits the fragments it reads -- 2 to 4
+// waves split the same element, and the split (4.5 VALU instructions per element) is ~22 % of those kernels' time and energy
+// (profiles/r05_gemm_split_free_upper_bound.txt).  Here a 256 x 256 x 16 tile is staged through registers: every thread fetches
+// 16 operand values (four float4: 4 consecutive k of a row), splits them once and writes the three bf16 PLANES of the tile to
+// LDS; the waves read ready-made bf16 fragments (ds_read_b128: 8 consecutive k of a row per lane and plane) and issue the six
+// MFMAs per fragment pair.  Per wave and K step: 72 VALU + 12 ds_write_b64 + 18 ds_read_b128 + 48 MFMAs.
+// LDS image of one plane of one operand: [256 rows][16 k] bf16 = 32 B per row; the two 16-byte k-halves of a row are swapped
+// where bit 3 of the row is set, so that the 16 rows a fragment read serves together hit 16 different 16-byte bank groups, and
+// the four 8-byte pieces of a row written by neighbouring lanes stay contiguous.  Two stages (96 KB), one workgroup per CU.
+// The global loads of step k + 2 are issued before the products of step k and land during them.
+struct Pl4 {
+  unsigned h[2], m[2], l[2];  // hi / mid / lo pieces of 4 consecutive-k values (two packed pairs each)
+};
+__device__ __forceinline__ Pl4 split4(const float4& x4) {
+  Pl4 o;
+  const float v[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x2 x = {v[2 * j], v[2 * j + 1]};
+    o.h[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+    const f32x2 xh = {__uint_as_float(o.h[j] << 16), __uint_as_float(o.h[j] & 0xffff0000u)};
+    const f32x2 r = x - xh;
+    o.m[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+    const f32x2 rh = {__uint_as_float(o.m[j] << 16), __uint_as_float(o.m[j] & 0xffff0000u)};
+    const f32x2 q = r - rh;
+    o.l[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2_t));
+  }
+  return o;
+}
+
+// NJ = 32-column fragments per wave: 4 -> 256 x 256 tile, waves of 64 x 128 (128 accumulator registers: ONE set of staging registers,
+// the fetch one K step ahead); 2 -> 256 x 128 tile, waves of 64 x 64 (TWO sets, the fetch two steps ahead, the split of the next
+// step interleaved with this step's MFMA groups).
+template <int NJ>
+__global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes_nt(GemmArgs g) {
+  constexpr int BMW = 256, BNW = 64 * NJ;
+  constexpr int NB = NJ / 2;               // float4 of the B tile per thread and K step
+  constexpr int NL = 2 + NB;               // float4 per thread and K step
+  constexpr bool TWO = NJ == 2;
+  constexpr int PLANE_A = BMW * 32, PLANE_B = BNW * 32;  // bytes of one plane of an operand tile
+  constexpr int OPER_A = 3 * PLANE_A, OPER_B = 3 * PLANE_B;
+  constexpr int STAGE = OPER_A + OPER_B;
+  __shared__ __attribute__((aligned(1024))) char lds[2][STAGE];
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
+    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+  }
+  int m0, n0;
+  {
+    constexpr int GM = GROUP_M / 2;
+    const int tilesM = gridDim.x / g.tilesN, per = GM * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GM;
+    const int gsz = min(GM, tilesM - first);
+    m0 = (first + rem2 % gsz) * BMW;
+    n0 = (rem2 / gsz) * BNW;
+  }
+  // unsplit, unbatched products only (the launcher sees to it)
+  const float* A = g.A;
+  const float* B = g.B;
+  const int nk = g.K / BK;
+
+  // staging: thread (r = tid >> 2, q = tid & 3) fetches float4 q of rows r and r + 128 of the A tile and of the B tile (NJ = 2: row r only)
+  const int sr = tid >> 2, sq = tid & 3;
+  const float* src[NL];
+  src[0] = A + (int64_t)min(m0 + sr, g.M - 1) * g.lda + 4 * sq;
+  src[1] = A + (int64_t)min(m0 + sr + 128, g.M - 1) * g.lda + 4 * sq;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) src[2 + i] = B + (int64_t)min(n0 + sr + 128 * i, g.N - 1) * g.ldb + 4 * sq;
+  auto woff = [&](int row) { return row * 32 + (((sq >> 1) ^ ((row >> 3) & 1)) << 4) + ((sq & 1) << 3); };
+  const int w0 = woff(sr), w1 = woff(sr + 128);
+  float4 X[NL], Y[TWO ? NL : 1];
+  auto load = [&](float4* ld) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      ld[i] = *reinterpret_cast<const float4*>(src[i]);
+      src[i] += BK;
+    }
+  };
+  auto put = [&](char* base, int plane, int off, const Pl4& p) {
+    *reinterpret_cast<u32x2_*>(base + off) = (u32x2_){p.h[0], p.h[1]};
+    *reinterpret_cast<u32x2_*>(base + plane + off) = (u32x2_){p.m[0], p.m[1]};
+    *reinterpret_cast<u32x2_*>(base + 2 * plane + off) = (u32x2_){p.l[0], p.l[1]};
+  };
+  auto put_piece = [&](int buf, int j, const float4* ld) {  // j = 0, 1: A rows r, r + 128; 2 (, 3): B rows r (, r + 128)
+    if (j < 2)
+      put(lds[buf], PLANE_A, j ? w1 : w0, split4(ld[j]));
+    else
+      put(lds[buf] + OPER_A, PLANE_B, (j - 2) ? w1 : w0, split4(ld[j]));
+  };
+  // fragments: lane (l31 = row of the 32-row fragment, kh = k half)
+  const int l31 = lane & 31, kh = lane >> 5;
+  auto roff = [&](int row) { return row * 32 + ((kh ^ ((row >> 3) & 1)) << 4); };
+  int fa[2], fb[NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) fa[i] = roff(wm * 64 + 32 * i + l31);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) fb[j] = roff(wn * (32 * NJ) + 32 * j + l31);
+  auto frag = [&](const char* oper, int plane, int off) {
+    Split3 f;
+    f.hi = *reinterpret_cast<const bf16x8_t*>(oper + off);
+    f.mid = *reinterpret_cast<const bf16x8_t*>(oper + plane + off);
+    f.lo = *reinterpret_cast<const bf16x8_t*>(oper + 2 * plane + off);
+    return f;
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // the products of the step in stage `buf`; STORE: the next step's values (in nx) are split and written to the other stage
+  // BETWEEN the groups of twelve MFMAs -- no dependence between the two, one basic block
+  auto step = [&](int buf, const float4* nx, auto store) {
+    const char* ai = lds[buf];
+    const char* bi = lds[buf] + OPER_A;
+    if constexpr (decltype(store)::value && NJ == 4) {  // (128 accumulator registers: no room to interleave -- split first)
+#pragma unroll
+      for (int j = 0; j < NL; ++j) put_piece(buf ^ 1, j, nx);
+    }
+    Split3 sa[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) sa[i] = frag(ai, PLANE_A, fa[i]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const Split3 sb = frag(bi, PLANE_B, fb[j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) mma9(acc[i][j], sa[i], sb);
+      if constexpr (decltype(store)::value && NJ == 2) {  // three pieces over two groups
+        put_piece(buf ^ 1, j, nx);
+        if (j == 1) put_piece(buf ^ 1, 2, nx);
+      }
+    }
+  };
+  using Yes = std::integral_constant<bool, true>;
+  using No = std::integral_constant<bool, false>;
+
+  if (nk > 0) {
+    load(X);  // step 0
+#pragma unroll
+    for (int j = 0; j < NL; ++j) put_piece(0, j, X);
+    if (nk > 1) load(X);  // step 1
+    if (TWO && nk > 2) load(Y);  // step 2
+    __syncthreads();
+    int cur = 0, kt = 0;
+    if constexpr (TWO) {
+      // invariant at the top: stage cur holds step kt, X step kt + 1, Y step kt + 2
+      while (kt + 4 < nk) {
+        step(cur, X, Yes());
+        load(X);  // step kt + 3
+        __syncthreads();
+        cur ^= 1;
+        step(cur, Y, Yes());
+        load(Y);  // step kt + 4
+        __syncthreads();
+        cur ^= 1;
+        kt += 2;
+      }
+      for (; kt < nk; ++kt) {  // the last (up to four) steps
+        if (kt + 1 < nk) {
+          step(cur, X, Yes());
+#pragma unroll
+          for (int j = 0; j < NL; ++j) X[j] = Y[j];
+          if (kt + 3 < nk) load(Y);
+        } else {
+          step(cur, X, No());
+        }
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+      // invariant at the top: stage cur holds step kt, X step kt + 1
+      for (; kt + 2 < nk; ++kt) {
+        step(cur, X, Yes());
+        load(X);  // step kt + 2: lands during the next step's first MFMA groups
+        __syncthreads();
+        cur ^= 1;
+      }
+      for (; kt < nk; ++kt) {
+        if (kt + 1 < nk)
+          step(cur, X, Yes());
+        else
+          step(cur, X, No());
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < NJ / 2; ++h) {
+    const f32x16 part[2][2] = {{acc[0][2 * h], acc[0][2 * h + 1]}, {acc[1][2 * h], acc[1][2 * h + 1]}};
+    store_tile(g, part, g.C, g.ldc, g.bias, false, m0 + wm * 64, n0 + wn * (32 * NJ) + 64 * h, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // bf16-input variant (BASELINE configs[3]: "bf16 MFMA inputs, fp32 accumulate").  Operands stay fp32 in
 // HBM -- no second copy of weights or activations exists -- and are rounded to bf16 (RNE) on their way
 // into LDS; the matrix cores run v_mfma_f32_32x32x16_bf16 with fp32 accumulators, and the epilogue, the
@@ -1821,7 +2026,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                 int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
-  SK_CHECK_ARG(variant >= 0 && variant <= 8 && variant != 5, "sk_gemm: unknown variant %d", variant);
+  SK_CHECK_ARG(variant >= 0 && variant <= 9 && variant != 5, "sk_gemm: unknown variant %d", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
@@ -1849,7 +2054,9 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   // gradients: 172.8 vs 164.0 TFLOP/s, the unsplit T/N weight gradient 172.0 vs 141.3), 2 also the N/T projections
   static const int split_sk = [] { const char* e = getenv("SEPKERN_GEMM_SPLIT_SK"); return e ? atoi(e) : 1; }();
   if (variant == 0 && !split_on) variant = 8;
-  const bool split = !bf16 && (variant == 0 || variant == 2 || variant == 7) && dma_ok(g, transA, transB);
+  const bool split = !bf16 && (variant == 0 || variant == 2 || variant == 7 || variant == 9) && dma_ok(g, transA, transB);
+  // split ONCE per element while staging (gemm_f32_kernel_planes_nt): unsplit, unbatched N/T products
+  const bool planes = split && variant == 9 && !transA && transB && splitk == 1 && batch == 1 && M >= 256 && N >= 256;
   const bool mfma_choose = variant == 8 || (variant == 0 && !split);  // the r04 policy among the fp32-MFMA kernels
   // 256 x 128 block tiles, 8 waves (fp32 MFMA): variant 4, or chosen for the large unsplit N/T and N/N products -- measured
   // +2 % / +5 % on them stand-alone.  SEPKERN_GEMM_WIDE=0 (diagnostics): never chosen.
@@ -1874,7 +2081,8 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
     if (P < 8 || nt >= (1 << 24) || nk < 8 || (R > 0 && R < P) || nt - (int64_t)g.sk_full * P > 16384) streamk = false;
   }
   if (streamk) g.tilesN = (int)sk_cdiv(N, 256);
-  const int64_t tiles = sk_cdiv(M, (wide || streamk) ? 256 : BM) * g.tilesN;
+  if (planes) g.tilesN = (int)sk_cdiv(N, 128);
+  const int64_t tiles = sk_cdiv(M, (wide || streamk || planes) ? 256 : BM) * g.tilesN;
   SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm: too many tiles");
   // workspace = [ticket counters | slabs]; the fp32 kernels reduce in-kernel when the counters cover every (batch, tile)
   g.slabs = ws ? (float*)((char*)ws + COUNTER_BYTES) : nullptr;
@@ -1882,7 +2090,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.counters = inkernel ? (unsigned*)ws : nullptr;
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
-  t_last_kernel = bf16 ? 9 : streamk ? (split ? 7 : 6) : wide ? 4 : split ? 2 : (variant != 1 && dma_ok(g, transA, transB, mfma_choose)) ? 3 : 1;
+  t_last_kernel = bf16 ? 9 : streamk ? (split ? 7 : 6) : wide ? 4 : planes ? 7 : split ? 2 : (variant != 1 && dma_ok(g, transA, transB, mfma_choose)) ? 3 : 1;
   if (bf16) {
     if (!transA && !transB)
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, g);
@@ -1915,6 +2123,8 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
       hipLaunchKernelGGL((gemm_f32_kernel_dma256<false, true>), grid, dim3(512), 0, st, g);
     else
       hipLaunchKernelGGL((gemm_f32_kernel_dma256<true, false>), grid, dim3(512), 0, st, g);
+  } else if (planes) {
+    hipLaunchKernelGGL(gemm_f32_kernel_planes_nt<2>, grid, dim3(512), 0, st, g);
   } else if (split) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_split3<false, false>), grid, dim3(256), 0, st, g);
