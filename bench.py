@@ -627,7 +627,7 @@ def numerics_note(model, args):
              "size >= 2^-18, each exact, are added into fp32 accumulators; the three left out are together <= 2^-26 of the product "
              "(a quarter of an fp32 multiplier's own rounding): error vs fp64 not above the fp32-MFMA kernels' "
              "(tests/test_gpu_kernels.py); SEPKERN_GEMM_SPLIT=0 = fp32-MFMA kernels throughout")
-    if os.environ.get("SEPKERN_GEMM_SPLIT", "1") == "0" or (eng is not None and eng.var_main not in (0, 2, 7)):
+    if os.environ.get("SEPKERN_GEMM_SPLIT", "1") == "0" or (eng is not None and eng.var_main not in (0, 2, 7, 9)):
         gemms = "GEMMs on the fp32-MFMA kernels"
     if eng is not None and eng.split3_fwd:
         return ("fp32 storage, fp32 accumulation, no operand perturbed; " + gemms + "; the forward recurrence forms h W_hh^T the same way "

@@ -92,13 +92,16 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  *      v_mfma_f32_32x32x16_bf16; the three of size <= 2^-27 -- together <= 2^-26 of the product, a quarter of the half ulp an
  *      fp32 multiplier rounds away itself -- are not formed.  Error against fp64 is not above the fp32-MFMA kernels' (tests);
  *      160-173 TFLOP/s fp32-equivalent on the training step's large products against 124-135 (one MI355X, stand-alone; the
- *      fp32-MFMA pipe's own peak is 157).  Kernels: 2 (128 x 128 tiles; any splitk / batch) and, for large unsplit N/N and
- *      T/N products with K >= 4096 when ws >= sk_gemm_streamk_workspace_bytes() is given, 7.  Other operands (F = 257 columns,
+ *      fp32-MFMA pipe's own peak is 157).  Kernels: 9 for unsplit, unbatched products of at least 192 tiles of 256 x 128 (the split
+ *      is done once per element while the tile is staged: 180-193 TFLOP/s; 72 KB of LDS, 200 VGPRs -- a caller that runs a product
+ *      beside a persistent recurrence passes 2), else 2 (128 x 128 tiles; any splitk / batch).  SEPKERN_GEMM_PLANES=0: never 9,
+ *      then 7 for large unsplit N/N and T/N products with K >= 4096 when ws >= sk_gemm_streamk_workspace_bytes() is given.  Other operands (F = 257 columns,
  *      K = 514): the fp32-MFMA kernels as under 8.  Operands beyond bf16's finite range (|x| > 3.39e38) round to inf.
  *      SEPKERN_GEMM_SPLIT=0 (diagnostics) makes 0 mean 8.
  *   1  the register-staged fp32-MFMA kernel (v_mfma_f32_32x32x2_f32), any alignment
  *   2  the 128 x 128-tile split kernel wherever the LDS-DMA conditions hold (else as 8)
  *   3 / 4  the 128 x 128 / 256 x 128-tile fp32-MFMA LDS-DMA kernels wherever they apply (diagnostics)
+ *   9  256 x 128 tiles, split once per element while staging (unsplit, unbatched products; else as 2)
  *   6 / 7  256 x 256 tiles, one PERSISTENT workgroup per CU with a stream-K cut of the last partial round of tiles, fp32-MFMA (6) or
  *      split products (7): unsplit, unbatched products; splitk = 1 and ws >= sk_gemm_streamk_workspace_bytes(), zero-filled
  *      before its first use and left with zeroed counters by every launch (without ws: 4 / 2).  Tiles of the cut are summed
@@ -109,7 +112,8 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 /* Which kernel the calling thread's LAST sk_gemm_f32[_splitk] / sk_gemm_bf16_splitk launch took (profiling: bench.py prices a
  * launch against the peak of the matrix pipe it ran on): 1 register-staged fp32 MFMA, 3 / 4 / 6 the 128 x 128 / 256 x 128 /
- * stream-K fp32-MFMA LDS-DMA kernels, 2 / 7 the 128 x 128 / stream-K SPLIT kernels (bf16 pipe, six piece products), 9 bf16 inputs;
+ * stream-K fp32-MFMA LDS-DMA kernels, 2 / 7 / 10 the 128 x 128 / stream-K / 256 x 128 split-while-staging SPLIT kernels (bf16 pipe, six piece
+ * products), 9 bf16 inputs;
  * 0 before the first launch. */
 int sk_gemm_last_kernel(void);
 size_t sk_gemm_streamk_workspace_bytes(void);

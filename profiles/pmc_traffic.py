@@ -15,9 +15,10 @@ import os
 import sys
 
 def is_split(name):
-    """fp32 products on the bf16 pipe: gemm_f32_kernel_split3<..> and the S6 form gemm_f32_kernel_streamk<.., .., true>."""
+    """fp32 products on the bf16 pipe: gemm_f32_kernel_split3<..>, gemm_f32_kernel_planes<..> and the S6 form
+    gemm_f32_kernel_streamk<.., .., true>."""
     import re
-    return "gemm_f32_kernel_split3" in name or re.search(r"gemm_f32_kernel_streamk<\w+, \w+, true>", name) is not None
+    return "gemm_f32_kernel_split3" in name or "gemm_f32_kernel_planes" in name or re.search(r"gemm_f32_kernel_streamk<\w+, \w+, true>", name) is not None
 
 
 KEYS = ("gemm_f32_split_kernel", "gemm_f32_kernel", "gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "hprev_rows_kernel", "lstm_fwd_kernel",

@@ -1018,7 +1018,7 @@ __global__ __launch_bounds__(256, SK_SPLIT_OCC) void gemm_f32_kernel_split3(Gemm
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Split products with the split done ONCE per element (variant 9; N/T products: both operands stored with K contiguous).
+// Split products with the split done ONCE per element (variant 9; unsplit, unbatched N/T, N/N and T/N products).
 // gemm_f32_kernel_split3 / the S6 stream-K form stage fp32 tiles by LDS-DMA and every WAVE splits the fragments it reads -- 2 to 4
 // waves split the same element, and the split (4.5 VALU instructions per element) is ~22 % of those kernels' time and energy
 // (profiles/r05_gemm_split_free_upper_bound.txt).  Here a 256 x 256 x 16 tile is staged through registers: every thread fetches
@@ -1049,16 +1049,17 @@ __device__ __forceinline__ Pl4 split4(const float4& x4) {
   return o;
 }
 
-// NJ = 32-column fragments per wave: 4 -> 256 x 256 tile, waves of 64 x 128 (128 accumulator registers: ONE set of staging registers,
-// the fetch one K step ahead); 2 -> 256 x 128 tile, waves of 64 x 64 (TWO sets, the fetch two steps ahead, the split of the next
-// step interleaved with this step's MFMA groups).
-template <int NJ>
-__global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes_nt(GemmArgs g) {
-  constexpr int BMW = 256, BNW = 64 * NJ;
-  constexpr int NB = NJ / 2;               // float4 of the B tile per thread and K step
-  constexpr int NL = 2 + NB;               // float4 per thread and K step
-  constexpr bool TWO = NJ == 2;
-  constexpr int PLANE_A = BMW * 32, PLANE_B = BNW * 32;  // bytes of one plane of an operand tile
+// 256 x 128 tile, 8 waves (4 x 2) of 64 x 64; TWO sets of staging registers: the fetch runs two K steps ahead of the split, and the
+// split of the next step is interleaved with this step's MFMA groups.  AKM / BKM: the operand is K-major in memory (A stored
+// [K][M] = transA; B stored [K][N] = !transB): its planes are then kept K-major in LDS too ([16 k][DIM] bf16 per plane; a thread
+// stages 4 consecutive DIMS of one k row) and the fragments are gathered by ds_read_b64_tr_b16 (see kmaj_frag below): within a k
+// row the 32-byte chunk c (16 dims) sits at chunk c ^ 2 (k & 3), so that the 8 segments a half-wave reads in one instruction (two
+// adjacent 16-dim blocks x 4 k rows) fall on 8 different 32-byte bank groups.
+template <bool AKM, bool BKM>
+__global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
+  constexpr int BMW = 256, BNW = 128, NJ = 2;
+  constexpr int NL = 3;                    // float4 per thread and K step: 2 of the A tile, 1 of the B tile
+  constexpr int PLANE_A = BMW * 32, PLANE_B = BNW * 32;  // bytes of one plane of an operand tile (16 k x DIM bf16)
   constexpr int OPER_A = 3 * PLANE_A, OPER_B = 3 * PLANE_B;
   constexpr int STAGE = OPER_A + OPER_B;
   __shared__ __attribute__((aligned(1024))) char lds[2][STAGE];
@@ -1081,25 +1082,49 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes_nt(GemmArgs g) 
     n0 = (rem2 / gsz) * BNW;
   }
   // unsplit, unbatched products only (the launcher sees to it)
-  const float* A = g.A;
-  const float* B = g.B;
   const int nk = g.K / BK;
 
-  // staging: thread (r = tid >> 2, q = tid & 3) fetches float4 q of rows r and r + 128 of the A tile and of the B tile (NJ = 2: row r only)
-  const int sr = tid >> 2, sq = tid & 3;
+  // ---- staging.  dim-major operand: thread (r = tid >> 2, q = tid & 3) fetches float4 q (4 consecutive k) of row r (A: and r + 128).
+  // K-major operand: thread fetches 4 consecutive dims of k row tid >> 6 (A: and + 8) / tid >> 5 (B).
   const float* src[NL];
-  src[0] = A + (int64_t)min(m0 + sr, g.M - 1) * g.lda + 4 * sq;
-  src[1] = A + (int64_t)min(m0 + sr + 128, g.M - 1) * g.lda + 4 * sq;
-#pragma unroll
-  for (int i = 0; i < NB; ++i) src[2 + i] = B + (int64_t)min(n0 + sr + 128 * i, g.N - 1) * g.ldb + 4 * sq;
-  auto woff = [&](int row) { return row * 32 + (((sq >> 1) ^ ((row >> 3) & 1)) << 4) + ((sq & 1) << 3); };
-  const int w0 = woff(sr), w1 = woff(sr + 128);
-  float4 X[NL], Y[TWO ? NL : 1];
+  int64_t adv[NL];
+  int wo[NL];  // byte offset of the thread's 8-byte piece inside a plane
+  {
+    const int sr = tid >> 2, sq = tid & 3;
+    auto dm_off = [&](int row) { return row * 32 + (((sq >> 1) ^ ((row >> 3) & 1)) << 4) + ((sq & 1) << 3); };
+    auto km_off = [&](int k, int d, int rowb) { return k * rowb + ((((d >> 4) ^ (2 * (k & 3)))) << 5) + (((d >> 2) & 3) << 3); };
+    if (AKM) {
+      const int k = tid >> 6, d = 4 * (tid & 63);
+      const int dc = min(m0 + d, g.M - 4);
+      src[0] = g.A + (int64_t)k * g.lda + dc;
+      src[1] = g.A + (int64_t)(k + 8) * g.lda + dc;
+      adv[0] = adv[1] = (int64_t)BK * g.lda;
+      wo[0] = km_off(k, d, 2 * BMW);
+      wo[1] = km_off(k + 8, d, 2 * BMW);
+    } else {
+      src[0] = g.A + (int64_t)min(m0 + sr, g.M - 1) * g.lda + 4 * sq;
+      src[1] = g.A + (int64_t)min(m0 + sr + 128, g.M - 1) * g.lda + 4 * sq;
+      adv[0] = adv[1] = BK;
+      wo[0] = dm_off(sr);
+      wo[1] = dm_off(sr + 128);
+    }
+    if (BKM) {
+      const int k = tid >> 5, d = 4 * (tid & 31);
+      src[2] = g.B + (int64_t)k * g.ldb + min(n0 + d, g.N - 4);
+      adv[2] = (int64_t)BK * g.ldb;
+      wo[2] = km_off(k, d, 2 * BNW);
+    } else {
+      src[2] = g.B + (int64_t)min(n0 + sr, g.N - 1) * g.ldb + 4 * sq;
+      adv[2] = BK;
+      wo[2] = dm_off(sr);
+    }
+  }
+  float4 X[NL], Y[NL];
   auto load = [&](float4* ld) {
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       ld[i] = *reinterpret_cast<const float4*>(src[i]);
-      src[i] += BK;
+      src[i] += adv[i];
     }
   };
   auto put = [&](char* base, int plane, int off, const Pl4& p) {
@@ -1107,25 +1132,40 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes_nt(GemmArgs g) 
     *reinterpret_cast<u32x2_*>(base + plane + off) = (u32x2_){p.m[0], p.m[1]};
     *reinterpret_cast<u32x2_*>(base + 2 * plane + off) = (u32x2_){p.l[0], p.l[1]};
   };
-  auto put_piece = [&](int buf, int j, const float4* ld) {  // j = 0, 1: A rows r, r + 128; 2 (, 3): B rows r (, r + 128)
+  auto put_piece = [&](int buf, int j, const float4* ld) {  // j = 0, 1: the A tile's two pieces; 2: the B tile's
     if (j < 2)
-      put(lds[buf], PLANE_A, j ? w1 : w0, split4(ld[j]));
+      put(lds[buf], PLANE_A, wo[j], split4(ld[j]));
     else
-      put(lds[buf] + OPER_A, PLANE_B, (j - 2) ? w1 : w0, split4(ld[j]));
+      put(lds[buf] + OPER_A, PLANE_B, wo[2], split4(ld[2]));
   };
-  // fragments: lane (l31 = row of the 32-row fragment, kh = k half)
+  // ---- fragments of 32 dims starting at d0: lane (l31 = dim, kh = k half)
   const int l31 = lane & 31, kh = lane >> 5;
-  auto roff = [&](int row) { return row * 32 + ((kh ^ ((row >> 3) & 1)) << 4); };
+  auto dm_frag = [&](int row) { return row * 32 + ((kh ^ ((row >> 3) & 1)) << 4); };
+  auto km_frag = [&](int d0, int rowb) {  // address of this lane's transposed read: k row 8 kh + q, piece p of 16-dim block b
+    const int bq = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+    return (8 * kh + q) * rowb + ((((d0 >> 4) + bq) ^ (2 * q)) << 5) + 8 * pp;
+  };
   int fa[2], fb[NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) fa[i] = roff(wm * 64 + 32 * i + l31);
+  for (int i = 0; i < 2; ++i) fa[i] = AKM ? km_frag(wm * 64 + 32 * i, 2 * BMW) : dm_frag(wm * 64 + 32 * i + l31);
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) fb[j] = roff(wn * (32 * NJ) + 32 * j + l31);
-  auto frag = [&](const char* oper, int plane, int off) {
+  for (int j = 0; j < NJ; ++j) fb[j] = BKM ? km_frag(wn * 64 + 32 * j, 2 * BNW) : dm_frag(wn * 64 + 32 * j + l31);
+  auto rd = [&](const char* pl, int off, bool km, int rowb) -> bf16x8_t {
+    if (km) {
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pl + off));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pl + off + 4 * rowb));
+      const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8_t, v);
+    }
+    return *reinterpret_cast<const bf16x8_t*>(pl + off);
+  };
+  auto frag = [&](const char* oper, int plane, int off, bool km, int rowb) {
     Split3 f;
-    f.hi = *reinterpret_cast<const bf16x8_t*>(oper + off);
-    f.mid = *reinterpret_cast<const bf16x8_t*>(oper + plane + off);
-    f.lo = *reinterpret_cast<const bf16x8_t*>(oper + 2 * plane + off);
+    f.hi = rd(oper, off, km, rowb);
+    f.mid = rd(oper + plane, off, km, rowb);
+    f.lo = rd(oper + 2 * plane, off, km, rowb);
     return f;
   };
 
@@ -1142,19 +1182,15 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes_nt(GemmArgs g) 
   auto step = [&](int buf, const float4* nx, auto store) {
     const char* ai = lds[buf];
     const char* bi = lds[buf] + OPER_A;
-    if constexpr (decltype(store)::value && NJ == 4) {  // (128 accumulator registers: no room to interleave -- split first)
-#pragma unroll
-      for (int j = 0; j < NL; ++j) put_piece(buf ^ 1, j, nx);
-    }
     Split3 sa[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) sa[i] = frag(ai, PLANE_A, fa[i]);
+    for (int i = 0; i < 2; ++i) sa[i] = frag(ai, PLANE_A, fa[i], AKM, 2 * BMW);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const Split3 sb = frag(bi, PLANE_B, fb[j]);
+      const Split3 sb = frag(bi, PLANE_B, fb[j], BKM, 2 * BNW);
 #pragma unroll
       for (int i = 0; i < 2; ++i) mma9(acc[i][j], sa[i], sb);
-      if constexpr (decltype(store)::value && NJ == 2) {  // three pieces over two groups
+      if constexpr (decltype(store)::value) {  // three pieces over two groups
         put_piece(buf ^ 1, j, nx);
         if (j == 1) put_piece(buf ^ 1, 2, nx);
       }
@@ -1168,57 +1204,35 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes_nt(GemmArgs g) 
 #pragma unroll
     for (int j = 0; j < NL; ++j) put_piece(0, j, X);
     if (nk > 1) load(X);  // step 1
-    if (TWO && nk > 2) load(Y);  // step 2
+    if (nk > 2) load(Y);  // step 2
     __syncthreads();
     int cur = 0, kt = 0;
-    if constexpr (TWO) {
-      // invariant at the top: stage cur holds step kt, X step kt + 1, Y step kt + 2
-      while (kt + 4 < nk) {
+    // invariant at the top: stage cur holds step kt, X step kt + 1, Y step kt + 2
+    while (kt + 4 < nk) {
+      step(cur, X, Yes());
+      load(X);  // step kt + 3
+      __syncthreads();
+      cur ^= 1;
+      step(cur, Y, Yes());
+      load(Y);  // step kt + 4
+      __syncthreads();
+      cur ^= 1;
+      kt += 2;
+    }
+    for (; kt < nk; ++kt) {  // the last (up to four) steps
+      if (kt + 1 < nk) {
         step(cur, X, Yes());
-        load(X);  // step kt + 3
-        __syncthreads();
-        cur ^= 1;
-        step(cur, Y, Yes());
-        load(Y);  // step kt + 4
-        __syncthreads();
-        cur ^= 1;
-        kt += 2;
-      }
-      for (; kt < nk; ++kt) {  // the last (up to four) steps
-        if (kt + 1 < nk) {
-          step(cur, X, Yes());
 #pragma unroll
-          for (int j = 0; j < NL; ++j) X[j] = Y[j];
-          if (kt + 3 < nk) load(Y);
-        } else {
-          step(cur, X, No());
-        }
-        __syncthreads();
-        cur ^= 1;
+        for (int j = 0; j < NL; ++j) X[j] = Y[j];
+        if (kt + 3 < nk) load(Y);
+      } else {
+        step(cur, X, No());
       }
-    } else {
-      // invariant at the top: stage cur holds step kt, X step kt + 1
-      for (; kt + 2 < nk; ++kt) {
-        step(cur, X, Yes());
-        load(X);  // step kt + 2: lands during the next step's first MFMA groups
-        __syncthreads();
-        cur ^= 1;
-      }
-      for (; kt < nk; ++kt) {
-        if (kt + 1 < nk)
-          step(cur, X, Yes());
-        else
-          step(cur, X, No());
-        __syncthreads();
-        cur ^= 1;
-      }
+      __syncthreads();
+      cur ^= 1;
     }
   }
-#pragma unroll
-  for (int h = 0; h < NJ / 2; ++h) {
-    const f32x16 part[2][2] = {{acc[0][2 * h], acc[0][2 * h + 1]}, {acc[1][2 * h], acc[1][2 * h + 1]}};
-    store_tile(g, part, g.C, g.ldc, g.bias, false, m0 + wm * 64, n0 + wn * (32 * NJ) + 64 * h, lane);
-  }
+  store_tile(g, acc, g.C, g.ldc, g.bias, false, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2056,7 +2070,13 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   if (variant == 0 && !split_on) variant = 8;
   const bool split = !bf16 && (variant == 0 || variant == 2 || variant == 7 || variant == 9) && dma_ok(g, transA, transB);
   // split ONCE per element while staging (gemm_f32_kernel_planes_nt): unsplit, unbatched N/T products
-  const bool planes = split && variant == 9 && !transA && transB && splitk == 1 && batch == 1 && M >= 256 && N >= 256;
+  // For unsplit, unbatched products with enough 256 x 128 tiles to fill the chip it is what variant 0 takes (SEPKERN_GEMM_PLANES=0:
+  // never): 180 / 193 / 179 TFLOP/s on the projection / data-gradient / unsplit weight-gradient shapes against 165 / 179 / 169
+  // of the stream-K split kernel and 163 / 165 of the 128 x 128 one; 158 vs 100-124 on the N = 514 Linear product.  It needs 72 KB of
+  // LDS and 200 VGPRs: callers that run a product BESIDE a persistent recurrence pass variant 2 (sepkern/engine.py).
+  static const bool planes_on = [] { const char* e = getenv("SEPKERN_GEMM_PLANES"); return !(e && e[0] == '0'); }();
+  const bool planes = split && splitk == 1 && batch == 1 && M >= 256 && N >= 128 &&
+                      (variant == 9 || (variant == 0 && planes_on && sk_cdiv(M, 256) * sk_cdiv(N, 128) >= 192));
   const bool mfma_choose = variant == 8 || (variant == 0 && !split);  // the r04 policy among the fp32-MFMA kernels
   // 256 x 128 block tiles, 8 waves (fp32 MFMA): variant 4, or chosen for the large unsplit N/T and N/N products -- measured
   // +2 % / +5 % on them stand-alone.  SEPKERN_GEMM_WIDE=0 (diagnostics): never chosen.
@@ -2070,7 +2090,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   const bool sk_shape = ws && batch == 1 && M >= 256 && N >= 256 && splitk == 1 && dma_ok(g, transA, transB);
   const bool sk_split = split && sk_shape && (variant == 7 || (variant == 0 && streamk_ok && M >= 4096 && N >= 1024 &&
                                                                ((split_sk >= 1 && !transB && K >= 4096) || (split_sk >= 2 && !transA))));
-  bool streamk = !bf16 && sk_shape && (sk_split || (!split && (variant == 6 || (mfma_choose && streamk_ok && !transA && M >= 4096 && N >= 1024))));
+  bool streamk = !bf16 && !planes && sk_shape && (sk_split || (!split && (variant == 6 || (mfma_choose && streamk_ok && !transA && M >= 4096 && N >= 1024))));
   if (streamk) {
     const int P = streamk_wgs();
     const int64_t nt = sk_cdiv(M, 256) * sk_cdiv(N, 256), nk = K / BK;
@@ -2090,7 +2110,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.counters = inkernel ? (unsigned*)ws : nullptr;
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
-  t_last_kernel = bf16 ? 9 : streamk ? (split ? 7 : 6) : wide ? 4 : planes ? 7 : split ? 2 : (variant != 1 && dma_ok(g, transA, transB, mfma_choose)) ? 3 : 1;
+  t_last_kernel = bf16 ? 9 : planes ? 10 : streamk ? (split ? 7 : 6) : wide ? 4 : split ? 2 : (variant != 1 && dma_ok(g, transA, transB, mfma_choose)) ? 3 : 1;
   if (bf16) {
     if (!transA && !transB)
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, g);
@@ -2124,7 +2144,12 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
     else
       hipLaunchKernelGGL((gemm_f32_kernel_dma256<true, false>), grid, dim3(512), 0, st, g);
   } else if (planes) {
-    hipLaunchKernelGGL(gemm_f32_kernel_planes_nt<2>, grid, dim3(512), 0, st, g);
+    if (!transA && transB)
+      hipLaunchKernelGGL((gemm_f32_kernel_planes<false, false>), grid, dim3(512), 0, st, g);
+    else if (!transA && !transB)
+      hipLaunchKernelGGL((gemm_f32_kernel_planes<false, true>), grid, dim3(512), 0, st, g);
+    else
+      hipLaunchKernelGGL((gemm_f32_kernel_planes<true, true>), grid, dim3(512), 0, st, g);
   } else if (split) {
     if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_split3<false, false>), grid, dim3(256), 0, st, g);

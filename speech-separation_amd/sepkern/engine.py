@@ -143,12 +143,13 @@ class Engine:
         # BatchNorm folded into the Linear layer (fp32 path; the bf16 arithmetic is DEFINED with bn(y) and W rounded
         # separately, oracle/upit_bf16.py, so that path keeps the explicit normalisation)
         self.bn_fold = os.environ.get("SEPKERN_BN_FOLD", "1") == "1" and not self.bf16
-        # fp32 GEMM kernel per stream (sk_gemm_f32_splitk's variant): "main,side".  Default 0,0: the library chooses -- the
-        # split-product kernels (three-way bf16 split, six piece products) wherever the operands allow, on the main stream and
-        # beside the recurrences alike (r05: 30.1 vs 34.7 ms per step; beside a recurrence the split kernel finishes its products
-        # sooner than the register-staged fp32-MFMA kernel slowed the recurrence less: 12.2 vs 12.8 ms of backward recurrences).
-        # "8,1" = the r04 arrangement (fp32-MFMA kernels; the register-staged one beside a recurrence).
-        self.var_main, self.var_side = (int(v) for v in os.environ.get("SEPKERN_GEMM_VARIANTS", "0,0").split(","))
+        # fp32 GEMM kernel per stream (sk_gemm_f32_splitk's variant): "main,side".  Default 0,2.  Main stream: the library chooses --
+        # split products on the bf16 matrix pipe (three-way bf16 split, six piece products) wherever the operands allow: the
+        # kernel that splits once per element while staging a 256 x 128 tile for the large unsplit products, the 128 x 128 split
+        # kernel otherwise.  Beside a recurrence: the 128 x 128 split kernel always (122 VGPRs, 32 KB of LDS: it fits on a CU next
+        # to a persistent workgroup, the 256 x 128 one does not), which finishes its products sooner than r04's register-staged
+        # fp32-MFMA kernel (12.2 vs 12.8 ms of backward recurrences).  r05: 34.7 -> 30.0 ms per step.  "8,1" = the r04 arrangement.
+        self.var_main, self.var_side = (int(v) for v in os.environ.get("SEPKERN_GEMM_VARIANTS", "0,2").split(","))
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
         self.version = 0               # bumped by whoever writes the parameters (ClipAdam, load_state_dict): see backward()

@@ -120,8 +120,8 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     bf16 on the way into the matrix cores (fp32 accumulate; everything in memory stays fp32).  variant (fp32 only,
     sk_gemm_f32_splitk's `variant`): 0 choose -- the three-way bf16 split of both operands on the bf16 matrix pipe (six piece
     products per element pair: fp32 products in another summation order) wherever the operands are aligned, else the
-    fp32-MFMA kernels; 1 the register-staged fp32-MFMA kernel; 2 / 7 the 128 x 128 / persistent 256 x 256 stream-K split
-    kernels; 3 / 4 / 6 the 128 x 128 / 256 x 128 / stream-K 256 x 256 fp32-MFMA LDS-DMA kernels; 8 choose among the
+    fp32-MFMA kernels; 1 the register-staged fp32-MFMA kernel; 2 / 7 / 9 the 128 x 128 / persistent 256 x 256 stream-K /
+    256 x 128 split-once-while-staging split kernels; 3 / 4 / 6 the 128 x 128 / 256 x 128 / stream-K 256 x 256 fp32-MFMA LDS-DMA kernels; 8 choose among the
     fp32-MFMA kernels only (the r04 default; SEPKERN_GEMM_SPLIT=0 makes 0 mean this)."""
     for t in (A, B, Cout, bias):
         _chk(t)
@@ -140,7 +140,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
             _lib.call("sk_gemm_bf16_splitk", *args, _stream())
         else:
             _lib.call("sk_gemm_f32_splitk", *args, int(variant), _stream())
-            if PROF is not None and _lib.load().sk_gemm_last_kernel() in (2, 7):
+            if PROF is not None and _lib.load().sk_gemm_last_kernel() in (2, 7, 10):
                 # the launch ran on the bf16 matrix pipe (split products): its own class -- another pipe, another peak
                 rec.cls = "gemm_f32_split_kernel"
 

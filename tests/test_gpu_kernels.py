@@ -236,6 +236,44 @@ def test_gemm_stream_k_kernel(ops, M, N, K, tA, tB):
         assert bool((Cw[:, N:] == 7).all())
 
 
+@pytest.mark.parametrize("variant", [7, 9])
+@pytest.mark.parametrize("M,N,K,tA,tB", [(1400, 1300, 1792, False, True), (1030, 772, 3584, False, False), (1028, 516, 2048, True, False),
+                                         (256, 128, 16, False, True), (4352, 4096, 256, False, False), (300, 260, 64, True, False)])
+def test_gemm_split_kernels_of_the_large_products(ops, variant, M, N, K, tA, tB):
+    """sk_gemm_f32_splitk variants 7 (stream-K 256 x 256 with split products) and 9 (256 x 128, the split done once per element
+    while the tile is staged; K-major operands read back by ds_read_b64_tr_b16) in the N/T, N/N and T/N forms with ragged
+    tile edges: against fp64 with bias, accumulate and the sigmoid epilogue; run-to-run identical; error not above the fp32-MFMA
+    kernels' (variant 8); variant 9 is bit for bit the 128 x 128 split kernel (2): same pieces, same products, same K order."""
+    g = torch.Generator().manual_seed(M + 3 * N + variant)
+    A = torch.randn((K, M) if tA else (M, K), generator=g)
+    B = torch.randn((N, K) if tB else (K, N), generator=g)
+    bias, C0 = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    a64 = A.double().t() if tA else A.double()
+    b64 = B.double().t() if tB else B.double()
+    ref = a64 @ b64 + bias.double() + C0.double()
+    mag = a64.abs() @ b64.abs()
+
+    def run(v, **kw):
+        C = dev(C0.clone())
+        ops.gemm(dev(A), dev(B), C, M, N, K, A.shape[1], B.shape[1], N, transA=tA, transB=tB, bias=dev(bias), accumulate=True,
+                 variant=v, ws_tag="t_sp", **kw)
+        torch.cuda.synchronize()
+        return C.cpu()
+    out, again, mfma = run(variant), run(variant), run(8)
+    assert torch.equal(out, again)
+    err = float(((out.double() - ref).abs() / mag).max())
+    err_mfma = float(((mfma.double() - ref).abs() / mag).max())
+    assert err <= max(1.25 * err_mfma, 2.0 ** -22), (err, err_mfma)
+    if variant == 9:
+        assert torch.equal(out, run(2))
+    Cw = torch.full((M, N + 8), 7.0).cuda()
+    ops.gemm(dev(A), dev(B), Cw, M, N, K, A.shape[1], B.shape[1], N + 8, transA=tA, transB=tB, bias=dev(bias), act=1, variant=variant,
+             ws_tag="t_sp")
+    want = torch.sigmoid(ref - C0.double())
+    assert float((Cw[:, :N].cpu().double() - want).abs().max()) < 1e-4
+    assert bool((Cw[:, N:] == 7).all())
+
+
 def test_gemm_splitk_workspace_from_a_c_caller(ops):
     """A split-K workspace that did NOT come zero-filled (a C caller's own allocation): sk_gemm_workspace_init zeroes the
     ticket counters at its head once; launches then leave them zeroed (two launches in a row give the same, right result)."""
