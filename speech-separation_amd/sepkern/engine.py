@@ -150,6 +150,7 @@ class Engine:
         # to a persistent workgroup, the 256 x 128 one does not), which finishes its products sooner than r04's register-staged
         # fp32-MFMA kernel (12.2 vs 12.8 ms of backward recurrences).  r05: 34.7 -> 30.0 ms per step.  "8,1" = the r04 arrangement.
         self.var_main, self.var_side = (int(v) for v in os.environ.get("SEPKERN_GEMM_VARIANTS", "0,2").split(","))
+        self.pad_in = int(os.environ.get("SEPKERN_PAD_IN", "16"))   # diagnostics: 4 = the r04 padding of the input width
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
         self.version = 0               # bumped by whoever writes the parameters (ClipAdam, load_state_dict): see backward()
@@ -307,9 +308,12 @@ class Engine:
             ops.colsum(self.flat[off_ih:], 2, 8 * H, 8 * H, bsum, ws_tag=ws_tag)
             # the recurrence keeps i,f,g,o of a cell adjacent (one 16-byte access per cell and step instead of four
             # H-strided ones): reorder the rows of W_ih and of the bias once, the GEMM then writes gx in that order
-            # ... and in the same pass pads an input width that is no multiple of 4 (F = 257 -> 260) with zero columns,
-            # so that the rows of both operands of the layer-0 products are 16-byte aligned (float4 fetches)
-            Ip = ops.pad_to(I, 4)
+            # ... and in the same pass pads an input width that is no multiple of 16 (F = 257 -> 272; RSH 514 -> 528) with zero
+            # columns: the rows of both operands of the layer-0 products are then 16-byte aligned AND K is a whole number of
+            # 16-deep K steps, so that the layer-0 projection and weight gradient take the split-product kernels too
+            # (r04 padded to 260: float4 fetches, fp32-MFMA kernels).  Layer 0 only: the layers above read y (2H columns, a
+            # multiple of 4 by construction) as it lies, and their data gradient IS the next recurrence's dy (2H columns)
+            Ip = ops.pad_to(I, self.pad_in if l == 0 else 4)
             wih_gi = ops.gate_rows(wih.view(8 * H, I), H, out=torch.empty(8 * H, Ip, device=dev), cols=I)
             return wih_gi, ops.gate_rows(bsum, H), Ip
 
