@@ -13,15 +13,15 @@ for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES" "SQ_ACTIVE_INST_L
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" \
            "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  for v in 8 2 7; do
+  for v in 8 2 7 9; do
     rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/prof_${tag}_gsp_${v}_$i -- python3 $R/speech-separation_amd/tools/gemm_bench.py --variant $v $S > /dev/null 2> $O/prof_${tag}_gsp_${v}_$i.err || echo "pass $i variant $v failed"
   done
 done
 python3 - <<PY
 import csv, glob, collections, re
 print("# rocprofv3 PMC over tools/gemm_bench.py (12 launches per shape), per launch averages; shapes: NT 12800 x 7168 x 1792 (projection), NN 12800 x 1792 x 7168 (data gradient)")
-print("# variant 8 = fp32-MFMA kernels (stream-K 256 x 256), 2 = split 128 x 128, 7 = split stream-K 256 x 256")
-for v in (8, 2, 7):
+print("# variant 8 = fp32-MFMA kernels (stream-K 256 x 256), 2 = split 128 x 128, 7 = split stream-K 256 x 256, 9 = split once while staging 256 x 128")
+for v in (8, 2, 7, 9):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob("$O/prof_${tag}_gsp_%d_*/**/*counter_collection.csv" % v, recursive=True)):
         for row in csv.DictReader(open(f)):
