@@ -384,16 +384,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   constexpr int PIECE = 256 * NCH;        // floats per bf16 piece image (NCH KB)
   constexpr int NPC = NP * NCH;           // 1 KB pieces a workgroup pulls per step
   static_assert(NCH % 2 == 0, "image chunks must split into two K halves");
-  // P2 (the split product, r05): a wave multiplies TWO gate-row tiles over a QUARTER of K instead of one tile over half of it --
-  // every h fragment it reads from LDS feeds twelve MFMAs instead of six.  With six products per fragment the product phase had
-  // become bound by those reads (42 KB per wave and step, 336 KB per workgroup: 2 700 LDS cycles beside 2 700 matrix-pipe
-  // cycles); this halves them.  Wave w: tile pair w & 1 (tiles 2 (w & 1), + 1), K quarter w >> 1; same registers of W pieces (2 x NCH / 4
-  // chunks).  The four partial tiles of a gate-row tile meet in LDS; the owner waves (w < 4, tile w) are who they were.
-  constexpr bool P2 = S3 && NW == 8 && NCH % 4 == 0;
-  constexpr int NQ4 = NCH / 4;
   __shared__ __attribute__((aligned(16))) float hs[S3 ? 3 * PIECE : 16 * HP];  // B-operand image(s) of h_{s-1}
   __shared__ __attribute__((aligned(16))) float red[MT][64][4];
-  __shared__ __attribute__((aligned(16))) float red2[P2 ? 4 : 1][P2 ? 4 : 1][64][4];  // P2: [tile][K quarter][lane]
   __shared__ float st_c[GMAX][64 * MT], st_h[GMAX][64 * MT];  // per-group cell state of the owner lanes
   __shared__ long long st_tpub[GMAX];                         // wave 0: when this workgroup raised the group's flag
   __shared__ int s_abort;
@@ -418,16 +410,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
     const float* wrow = a.whh + ((size_t)dir * 4 * H + (size_t)g_i * H + unit_i) * H;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      if (P2) {
-        // register q: tile 2 (w & 1) + q / NQ4, chunk (w >> 1) NQ4 + q % NQ4
-        const int unit_p = ug * (4 * MT) + 4 * (2 * (w & 1) + q / NQ4) + (i >> 2);
-        const float* wr = a.whh + ((size_t)dir * 4 * H + (size_t)g_i * H + unit_p) * H;
-        const int k = 32 * ((w >> 1) * NQ4 + q % NQ4) + 8 * kq;
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        if (unit_p < H && k < H) v0 = *reinterpret_cast<const float4*>(wr + k);
-        if (unit_p < H && k + 4 < H) v1 = *reinterpret_cast<const float4*>(wr + k + 4);
-        split3x8(v0, v1, w1[q], w2[q], w3[q]);
-      } else if (B16) {
+      if (B16) {
         const int k = 32 * (kh * NQ + q) + 8 * kq;
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
         if (rowok && k < H) v0 = *reinterpret_cast<const float4*>(wrow + k);
@@ -646,31 +629,6 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       SK_STAMP(1);
       // 4. gates^T (64 gate rows x 16 batch) = W_slice (64 x HP) * h^T (HP x 16); this wave: 16 rows, half of K
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (P2) {
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-        const float* hp = &hs[((w >> 1) * NQ4) * 256 + lane * 4];
-#pragma unroll
-        for (int q = 0; q < NQ4; ++q) {
-          const bf16x8 h3 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + 2 * PIECE);
-          const bf16x8 h2 = *reinterpret_cast<const bf16x8*>(hp + q * 256 + PIECE);
-          const bf16x8 h1 = *reinterpret_cast<const bf16x8*>(hp + q * 256);
-          // the six products of each of the two tiles, small ones first, four accumulators in turn
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h3, acc0, 0, 0, 0);
-          b0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[NQ4 + q], h3, b0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h2, acc1, 0, 0, 0);
-          b1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[NQ4 + q], h2, b1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h2, acc0, 0, 0, 0);
-          b0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[NQ4 + q], h2, b0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], h1, acc1, 0, 0, 0);
-          b1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[NQ4 + q], h1, b1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], h1, acc0, 0, 0, 0);
-          b0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[NQ4 + q], h1, b0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], h1, acc1, 0, 0, 0);
-          b1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[NQ4 + q], h1, b1, 0, 0, 0);
-        }
-        *reinterpret_cast<f32x4*>(&red2[2 * (w & 1)][w >> 1][lane][0]) = acc0 + acc1;
-        *reinterpret_cast<f32x4*>(&red2[2 * (w & 1) + 1][w >> 1][lane][0]) = b0 + b1;
-      } else
       {
         const float* hp = &hs[(kh * NQ) * 256 + lane * 4];
 #ifdef SK_TAIL_HALF
@@ -712,20 +670,13 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       }
       f32x4 acc = acc0 + acc1;
       SK_STAMP(2);
-      if (!P2 && !owner) *reinterpret_cast<f32x4*>(&red[mt][lane][0]) = acc;
+      if (!owner) *reinterpret_cast<f32x4*>(&red[mt][lane][0]) = acc;
       __syncthreads();
       SK_STAMP(3);
       float y_out = 0.f, c_out = 0.f;
       bool valid = false;
       if (owner) {
-        if constexpr (P2) {  // the four K quarters of this wave's tile, in a fixed order
-          acc = *reinterpret_cast<const f32x4*>(&red2[mt][0][lane][0]);
-          acc += *reinterpret_cast<const f32x4*>(&red2[mt][1][lane][0]);
-          acc += *reinterpret_cast<const f32x4*>(&red2[mt][2][lane][0]);
-          acc += *reinterpret_cast<const f32x4*>(&red2[mt][3][lane][0]);
-        } else {
-          acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
-        }
+        acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
         // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
         float c_reg = st_c[gi][oi], h_reg = st_h[gi][oi];
         const float gi_ = fast_sigmoid(acc[0] + gxv.x);
