@@ -20,14 +20,19 @@ from sepkern.optim import ClipAdam  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    every = int(sys.argv[2]) if len(sys.argv) > 2 else 20          # print the loss of every `every`-th step
+    hseed = int(sys.argv[3]) if len(sys.argv) > 3 else 1234        # seed of the per-step h0 / c0 draws
+    only = sys.argv[4] if len(sys.argv) > 4 else ""               # 'fp32' / 'bf16': that arithmetic only
     for dtype in ("fp32", "bf16"):
+        if only and dtype != only:
+            continue
         torch.manual_seed(0)
         with contextlib.redirect_stdout(sys.stderr):
             model = uPIT.SepDNN(0, num_spk="2", hidden_dim="896", num_layers="3", dtype=dtype)
         model.cuda()
         model.train()
         model.hidden_generator = torch.Generator(device="cuda")
-        model.hidden_generator.manual_seed(1234)
+        model.hidden_generator.manual_seed(hseed)
         opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
         mix, srcs, pk, _, _ = bench.make_batch(torch, ops, synth, 32, 400, 2, 0)
         out = []
@@ -38,7 +43,7 @@ def main():
             loss, norm = uPIT.compute_loss_packed(model, mix, srcs, pk)
             loss.backward()
             opt.step()
-            if i % 20 == 0 or i == steps - 1:
+            if i % every == 0 or i == steps - 1:
                 out.append((i, loss.detach().clone()))          # no host sync inside the timed loop
         torch.cuda.synchronize()
         secs = time.perf_counter() - t0
