@@ -238,7 +238,8 @@ def test_gemm_stream_k_kernel(ops, M, N, K, tA, tB):
 
 @pytest.mark.parametrize("variant", [7, 9])
 @pytest.mark.parametrize("M,N,K,tA,tB", [(1400, 1300, 1792, False, True), (1030, 772, 3584, False, False), (1028, 516, 2048, True, False),
-                                         (256, 128, 16, False, True), (4352, 4096, 256, False, False), (300, 260, 64, True, False)])
+                                         (256, 128, 16, False, True), (4352, 4096, 256, False, False), (300, 260, 64, True, False),
+                                         (260, 132, 80, False, False), (260, 132, 112, True, False), (516, 260, 96, False, True)])
 def test_gemm_split_kernels_of_the_large_products(ops, variant, M, N, K, tA, tB):
     """sk_gemm_f32_splitk variants 7 (stream-K 256 x 256 with split products) and 9 (256 x 128, the split done once per element
     while the tile is staged; K-major operands read back by ds_read_b64_tr_b16) in the N/T, N/N and T/N forms with ragged
