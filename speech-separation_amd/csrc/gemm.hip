@@ -1055,7 +1055,13 @@ __device__ __forceinline__ Pl4 split4(const float4& x4) {
 // stages 4 consecutive DIMS of one k row) and the fragments are gathered by ds_read_b64_tr_b16 (see kmaj_frag below): within a k
 // row the 32-byte chunk c (16 dims) sits at chunk c ^ 2 (k & 3), so that the 8 segments a half-wave reads in one instruction (two
 // adjacent 16-dim blocks x 4 k rows) fall on 8 different 32-byte bank groups.
-template <bool AKM, bool BKM>
+#ifndef SK_PLANES_FLIP
+#define SK_PLANES_FLIP 32  // phase length in K steps of the N/N instantiation (0: none -- `make gemm_variant DEFS=-DSK_PLANES_FLIP=0`)
+#endif
+#ifndef SK_PLANES_SCHED
+#define SK_PLANES_SCHED 4  // VALU instructions stated behind every MFMA of a K step (0: the scheduler's own choice)
+#endif
+template <bool AKM, bool BKM, int FL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
   constexpr int BMW = 256, BNW = 128, NJ = 2;
   constexpr int NL = 3;                    // float4 per thread and K step: 2 of the A tile, 1 of the B tile
@@ -1132,12 +1138,37 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
     *reinterpret_cast<u32x2_*>(base + plane + off) = (u32x2_){p.m[0], p.m[1]};
     *reinterpret_cast<u32x2_*>(base + 2 * plane + off) = (u32x2_){p.l[0], p.l[1]};
   };
-  auto put_piece = [&](int buf, int j, const float4* ld) {  // j = 0, 1: the A tile's two pieces; 2: the B tile's
-    if (j < 2)
+  // sm: the sign mask (0 or the sign bit) of the step the pieces belong to (see FL below): applied to the B tile's four values
+  // before they are split -- the pieces of -x are the negated pieces of x (rounding to nearest is symmetric)
+  auto put_piece = [&](int buf, int j, const float4* ld, unsigned sm) {  // j = 0, 1: the A tile's two pieces; 2: the B tile's
+    if (j < 2) {
       put(lds[buf], PLANE_A, wo[j], split4(ld[j]));
-    else
-      put(lds[buf] + OPER_A, PLANE_B, wo[2], split4(ld[2]));
+    } else {
+      float4 b = ld[2];
+      if (FL > 0) {
+        b.x = __uint_as_float(__float_as_uint(b.x) ^ sm);
+        b.y = __uint_as_float(__float_as_uint(b.y) ^ sm);
+        b.z = __uint_as_float(__float_as_uint(b.z) ^ sm);
+        b.w = __uint_as_float(__float_as_uint(b.w) ^ sm);
+      }
+      put(lds[buf] + OPER_A, PLANE_B, wo[2], split4(b));
+    }
   };
+  // FL > 0 (the data-gradient form N/N, see sk_gemm's launcher): sign-alternating accumulation.  The bf16 MFMA does not round
+  // the alignment of its addends to nearest: it TRUNCATES TOWARDS MINUS INFINITY (measured, profiles/r05_planes_flip.txt: on
+  // all-positive operands the fp32-MFMA kernels' mean signed error is 1e-10 of the result, this kernel's -3.7e-8 at K = 1792,
+  // -1.5e-7 at K = 7168, -2.7e-7 at K = 12800 -- a DC offset, the same in every element, far below the kernel's own rel-L2 error
+  // against fp64 (7e-7, SMALLER than the fp32-MFMA kernels' 1.2e-6) but COHERENT: the backward recurrence of the layer below
+  // integrates the offset of the top layer's data gradient (K = 7168) over 400 time steps, which left that layer's parameter
+  // gradients 8 x further from a float64 step than with fp32-MFMA products: 5.9e-6 against 6e-7, gate 2e-4).  Cure without a
+  // second accumulator: every FL K steps the accumulators change sign (acc = -acc) and the B values are negated while they are
+  // staged, so that the registers hold +sum in even phases and -sum in odd ones: truncation pulls the sum down, then up -- the
+  // offsets of neighbouring phases cancel (all-positive bias at K = 7168: -1.5e-7 -> +1.6e-9; layer-0 / 1 gradients of the
+  // full-size step against float64: 5.9e-6 -> 6.2e-7 = the fp32-MFMA arrangement's).  Cost: 4 v_xor per thread and K step + 64
+  // per phase change -- nothing once the loop's interleave is stated (SK_PLANES_SCHED below; left to itself the compiler
+  // scheduled THIS instantiation's loop 6 % slower than the unflipped one).  Only where it matters: the forward projections
+  // (K <= 1792) and the weight gradients (integrated by nothing) measured no effect of their offsets.
+  auto mask_of = [&](int kt) -> unsigned { return FL > 0 ? ((unsigned)((kt / (FL > 0 ? FL : 1)) & 1) << 31) : 0u; };
   // ---- fragments of 32 dims starting at d0: lane (l31 = dim, kh = k half)
   const int l31 = lane & 31, kh = lane >> 5;
   auto dm_frag = [&](int row) { return row * 32 + ((kh ^ ((row >> 3) & 1)) << 4); };
@@ -1179,9 +1210,16 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
 
   // the products of the step in stage `buf`; STORE: the next step's values (in nx) are split and written to the other stage
   // BETWEEN the groups of twelve MFMAs -- no dependence between the two, one basic block
-  auto step = [&](int buf, const float4* nx, auto store) {
+  auto step = [&](int buf, int kt, const float4* nx, auto store) {
     const char* ai = lds[buf];
     const char* bi = lds[buf] + OPER_A;
+    if (FL > 0 && kt > 0 && kt % (FL > 0 ? FL : 1) == 0) {  // a new phase: the accumulators change sign with the products
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = -acc[i][j];
+    }
+    const unsigned sg_next = mask_of(kt + 1);
     Split3 sa[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) sa[i] = frag(ai, PLANE_A, fa[i], AKM, 2 * BMW);
@@ -1191,8 +1229,21 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) mma9(acc[i][j], sa[i], sb);
       if constexpr (decltype(store)::value) {  // three pieces over two groups
-        put_piece(buf ^ 1, j, nx);
-        if (j == 1) put_piece(buf ^ 1, 2, nx);
+        put_piece(buf ^ 1, j, nx, sg_next);
+        if (j == 1) put_piece(buf ^ 1, 2, nx, sg_next);
+      }
+    }
+    // The interleaving is STATED, not left to the scheduler: one MFMA, then SK_PLANES_SCHED VALU instructions of the next step's
+    // split, 24 times (a step has 24 MFMAs and ~70 VALU instructions; LDS reads / writes and the fetches go where the scheduler
+    // likes).  Left to itself the compiler found a good interleave for some instantiations and long VALU runs with the MFMA pipe
+    // idle for others (the FL form lost 6 % to that, not to its 4 extra instructions).  Measured, one device
+    // (profiles/r05_planes_sched.txt): N/N 181 -> 186-188 TFLOP/s WITH the sign phases (172 without the statement), N/T 204.5 ->
+    // 210-212, T/N 187 -> 195, 8192^3 215 -> 222; 3 and 4 are equal within the run-to-run spread, 2 loses.
+    if constexpr (SK_PLANES_SCHED > 0 && decltype(store)::value) {
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, SK_PLANES_SCHED, 0);
       }
     }
   };
@@ -1202,18 +1253,18 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
   if (nk > 0) {
     load(X);  // step 0
 #pragma unroll
-    for (int j = 0; j < NL; ++j) put_piece(0, j, X);
+    for (int j = 0; j < NL; ++j) put_piece(0, j, X, 0u);
     if (nk > 1) load(X);  // step 1
     if (nk > 2) load(Y);  // step 2
     __syncthreads();
     int cur = 0, kt = 0;
     // invariant at the top: stage cur holds step kt, X step kt + 1, Y step kt + 2
     while (kt + 4 < nk) {
-      step(cur, X, Yes());
+      step(cur, kt, X, Yes());
       load(X);  // step kt + 3
       __syncthreads();
       cur ^= 1;
-      step(cur, Y, Yes());
+      step(cur, kt + 1, Y, Yes());
       load(Y);  // step kt + 4
       __syncthreads();
       cur ^= 1;
@@ -1221,15 +1272,21 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
     }
     for (; kt < nk; ++kt) {  // the last (up to four) steps
       if (kt + 1 < nk) {
-        step(cur, X, Yes());
+        step(cur, kt, X, Yes());
 #pragma unroll
         for (int j = 0; j < NL; ++j) X[j] = Y[j];
         if (kt + 3 < nk) load(Y);
       } else {
-        step(cur, X, No());
+        step(cur, kt, X, No());
       }
       __syncthreads();
       cur ^= 1;
+    }
+    if (mask_of(nk - 1) != 0u) {  // the last phase held -sum
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = -acc[i][j];
     }
   }
   store_tile(g, acc, g.C, g.ldc, g.bias, false, m0 + wm * 64, n0 + wn * 64, lane);
@@ -2147,7 +2204,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
     if (!transA && transB)
       hipLaunchKernelGGL((gemm_f32_kernel_planes<false, false>), grid, dim3(512), 0, st, g);
     else if (!transA && !transB)
-      hipLaunchKernelGGL((gemm_f32_kernel_planes<false, true>), grid, dim3(512), 0, st, g);
+      hipLaunchKernelGGL((gemm_f32_kernel_planes<false, true, SK_PLANES_FLIP>), grid, dim3(512), 0, st, g);  // (data gradients)
     else
       hipLaunchKernelGGL((gemm_f32_kernel_planes<true, true>), grid, dim3(512), 0, st, g);
   } else if (split) {

@@ -149,7 +149,11 @@ class Engine:
         # kernel otherwise.  Beside a recurrence: the 128 x 128 split kernel always (122 VGPRs, 32 KB of LDS: it fits on a CU next
         # to a persistent workgroup, the 256 x 128 one does not), which finishes its products sooner than r04's register-staged
         # fp32-MFMA kernel (12.2 vs 12.8 ms of backward recurrences).  r05: 34.7 -> 30.0 ms per step.  "8,1" = the r04 arrangement.
-        self.var_main, self.var_side = (int(v) for v in os.environ.get("SEPKERN_GEMM_VARIANTS", "0,2").split(","))
+        v = [int(x) for x in os.environ.get("SEPKERN_GEMM_VARIANTS", "0,2").split(",")]
+        self.var_main, self.var_side = v[0], v[1]
+        # (diagnostics: optional third / fourth field = the variant of the forward projections / of the data gradients alone)
+        self.var_proj = v[2] if len(v) > 2 else None
+        self.var_dgrad = v[3] if len(v) > 3 else None
         self.pad_in = int(os.environ.get("SEPKERN_PAD_IN", "16"))   # diagnostics: 4 = the r04 padding of the input width
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
@@ -227,7 +231,7 @@ class Engine:
         N = w.shape[0]
         if not self.nt:
             ops.gemm(inp2d, w, out2d, R, N, K, inp2d.stride(0), K, N, transB=True, bias=bias, act=act, bf16=self.bf16,
-                     variant=self.var_main)
+                     variant=self.var_main if self.var_proj is None else self.var_proj)
             return
         a, b = self._copy(cache, inp2d), self._copy(cache, w)
         # (not the stream-K kernel: with 1400 tiles of 28 K steps its fix-up costs more than the sixth partial round it saves --
@@ -241,7 +245,8 @@ class Engine:
         if not self.nt:
             # large data gradients unsplit (stream-K / 256 x 128 tiles: 125.5-134.6 TFLOP/s against 119-120 for two K slices)
             sk = 1 if (not self.bf16 and R >= 4096 and K >= 1024 and N % 16 == 0) else 0
-            ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=sk, ws_tag=ws_tag, bf16=self.bf16, variant=self.var_main)
+            ops.gemm(dout2d, w, out2d, R, K, N, N, K, K, splitk=sk, ws_tag=ws_tag, bf16=self.bf16,
+                     variant=self.var_main if self.var_dgrad is None else self.var_dgrad)
             return
         # w (N, K) is the K-major B of the product as it lies (contraction over its rows, padded with zero rows up to
         # dout's zero-padded width)

@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-parameter relative error of one training step's gradients against the CPU oracle (test infrastructure: run
-by hand on a GPU box).  usage: grad_check.py H L S B T"""
+"""Diagnostic (test infrastructure, not collected by pytest: run by hand on a GPU box): per-parameter relative error and
+systematic scale factor of one training step's gradients against the CPU oracle -- GRAD_CHECK_F64=1: against the oracle's
+step in float64.  usage: python tests/grad_check.py H L S B T   (3x896 at 32 x 400: 896 3 2 32 400)"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "speech-separation_amd"), os.path.join(ROOT, "speech-separation_amd", "archs")):
     sys.path.insert(0, p)
 import uPIT  # noqa: E402
@@ -24,6 +25,9 @@ def main():
     orc = OU.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
     orc.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
     orc.train()
+    f64 = os.environ.get("GRAD_CHECK_F64") == "1"          # the oracle's step in float64: the reference is then the TRUTH to ~1e-15
+    if f64:
+        orc = orc.double()
     lens = sorted([int(v) for v in rng.integers(max(2, T // 2), T + 1, B)])
     lens[-1] = T
     samples = []
@@ -33,7 +37,12 @@ def main():
             d["source%d" % (s + 1)] = np.abs(rng.standard_normal((n, 257))).astype(np.float32) * 0.6
         samples.append(d)
     h0, c0 = torch.randn(2 * L, B, H), torch.randn(2 * L, B, H)
-    lo, no, aux = OU.compute_loss(orc, OU.collate(samples), (h0, c0))
+    osamples = [{k: v.astype(np.float64) for k, v in d.items()} for d in samples] if f64 else samples
+    ocoll = OU.collate(osamples)
+    if f64:
+        from torch.nn.utils.rnn import PackedSequence
+        ocoll = {k: (PackedSequence(v.data.double(), v.batch_sizes) if isinstance(v, PackedSequence) else v) for k, v in ocoll.items()}
+    lo, no, aux = OU.compute_loss(orc, ocoll, (h0.double(), c0.double()) if f64 else (h0, c0))
     lo.backward()
     model.next_hidden = (h0.cuda(), c0.cuda())
     loss, norm = uPIT.compute_loss(model, 0, uPIT.Collator("mix")(samples))
@@ -41,9 +50,11 @@ def main():
     print("R = %d  loss %.7f oracle %.7f" % (sum(lens), float(loss), float(lo)))
     og = dict(orc.named_parameters())
     for k, p in model.named_parameters():
-        ref = og[k].grad
-        err = float((p.grad.cpu().double() - ref.double()).norm() / (ref.double().norm() + 1e-30))
-        print("  %-28s rel err %.3e%s" % (k, err, "   <<<" if err > 2e-4 else ""))
+        ref = og[k].grad.double()
+        got = p.grad.cpu().double()
+        err = float((got - ref).norm() / (ref.norm() + 1e-30))
+        scale = float((got * ref).sum() / (ref * ref).sum()) - 1.0      # systematic scale factor of the gradient against the oracle's
+        print("  %-28s rel err %.3e  scale-1 %+.3e%s" % (k, err, scale, "   <<<" if err > 2e-4 else ""))
 
 
 if __name__ == "__main__":

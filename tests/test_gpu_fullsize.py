@@ -49,7 +49,9 @@ def _batch(S, seed):
 
 def _run_pair(S, dtype, oracle_mod, seed, handoffs=(None,)):
     """One training step of the HIP path per entry of `handoffs` (None: the engine's default forward-recurrence hand-off;
-    else a SEPKERN_LSTM_FWD value) and ONE of the oracle (a minute of host time): a list of result dicts."""
+    else a SEPKERN_LSTM_FWD value; a value ending in "|mfma" also runs every GEMM on the fp32-MFMA kernels -- variants 8 / 1,
+    the r04 arrangement -- instead of the split-product kernels) and ONE of the oracle (a minute of host time): a list of
+    result dicts."""
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need an MI355X")
     import uPIT
@@ -59,6 +61,9 @@ def _run_pair(S, dtype, oracle_mod, seed, handoffs=(None,)):
     batch = uPIT.Collator("mix")(samples)
     runs, state = [], None
     for spec in handoffs:
+        mfma_gemms = spec is not None and spec.endswith("|mfma")
+        if mfma_gemms:
+            spec = spec[:-len("|mfma")]
         old = os.environ.get("SEPKERN_LSTM_FWD")
         if spec is not None:
             os.environ["SEPKERN_LSTM_FWD"] = spec                 # read when the engine is built (first use of the model)
@@ -72,6 +77,9 @@ def _run_pair(S, dtype, oracle_mod, seed, handoffs=(None,)):
                 h0, c0 = torch.randn(2 * L, B, H), torch.randn(2 * L, B, H)
             # HIP path first (so a kernel fault is not hidden behind a minute of oracle time)
             model.next_hidden = (h0.cuda(), c0.cuda())
+            if mfma_gemms:
+                eng = model._bind()
+                eng.var_main, eng.var_side = 8, 1
             loss, norm = uPIT.compute_loss(model, 0, batch)
         finally:
             if spec is not None:
@@ -89,7 +97,8 @@ def _run_pair(S, dtype, oracle_mod, seed, handoffs=(None,)):
         torch.cuda.synchronize()
         ops.lstm_status(ops.lstm_ws(T, B, H))
         runs.append(dict(loss=float(loss), norm=float(norm), best=best, grads=grads, mask=mask,
-                         tagged=bool(model._engine.tagged_fwd), split3=bool(model._engine.split3_fwd)))
+                         tagged=bool(model._engine.tagged_fwd), split3=bool(model._engine.split3_fwd),
+                         gemm_variants=(model._engine.var_main, model._engine.var_side)))
         del model
     # oracle
     orc = OU.OracleSepDNN(num_spk=S, hidden_dim=H, num_layers=L)
@@ -113,15 +122,22 @@ def _same_perms(r):
 
 
 def test_fp32_step_32x400_matches_oracle():
-    """configs[1]: masks <= 1e-4 relative, loss 1e-5, same permutations, every parameter gradient <= 2e-4 rel-L2 -- with the
-    forward recurrence as shipped (the product by the exact three-way bf16 split, flags), with the r03 default ("the data is
-    the flag": the operand h carries a 2-bit epoch, <= 3 ulp) AND with the plain fp32-MFMA product and flags, all three
-    against the same oracle step."""
-    split3, tagged, plain = _run_pair(2, "fp32", OU, 21, handoffs=(None, "0,1,1,0,0,8,1,0", "0,1,1,0,0,0,0,0"))
+    """configs[1]: masks <= 1e-4 relative, loss 1e-5, same permutations, every parameter gradient <= 2e-4 rel-L2 -- as
+    shipped (every aligned GEMM and the forward recurrence's product by the three-way bf16 split with six piece products, flags
+    hand-off), with the r03 forward hand-off ("the data is the flag": the operand h carries a 2-bit epoch, <= 3 ulp), with the
+    plain fp32-MFMA forward product, AND with fp32-MFMA kernels throughout (GEMMs too: r04's arithmetic) -- all four against the
+    same oracle step; the shipped arithmetic is not further from the oracle than the fp32-MFMA one (by more than half: two fp32
+    summation orders scatter that much around each other)."""
+    split3, tagged, plain, mfma = _run_pair(2, "fp32", OU, 21, handoffs=(None, "0,1,1,0,0,8,1,0", "0,1,1,0,0,0,0,0", "0,1,1,0,0,0,0,0|mfma"))
     assert split3["split3"] and not split3["tagged"] and tagged["tagged"] and not (plain["tagged"] or plain["split3"])
-    for r in (split3, tagged, plain):
-        _check_fp32(r)
+    assert split3["gemm_variants"] == (0, 2) and mfma["gemm_variants"] == (8, 1) and not mfma["split3"]
+    errs = [_check_fp32(r) for r in (split3, tagged, plain, mfma)]
     assert tagged["loss"] != plain["loss"] or not np.array_equal(tagged["mask"], plain["mask"])   # (they ARE different arithmetics)
+    assert split3["loss"] != mfma["loss"] or not np.array_equal(split3["mask"], mfma["mask"])
+    # (mask error, worst gradient error) of the shipped arithmetic against the all-fp32-MFMA one's
+    assert errs[0][0] <= 1.5 * errs[3][0] + 2e-6 and errs[0][1] <= 1.5 * errs[3][1] + 2e-6, (errs[0], errs[3])
+    print("fullsize fp32: (mask max rel err, worst grad rel-L2 err)  shipped %s  tagged fwd %s  plain fwd %s  fp32-MFMA throughout %s" % tuple(
+        "(%.2e, %.2e)" % e for e in errs))
 
 
 def _check_fp32(r):
@@ -140,6 +156,7 @@ def _check_fp32(r):
         if e > worst[1]:
             worst = (k, e)
     assert worst[1] < 2e-4, worst
+    return err, worst[1]
 
 
 def test_bf16_3spk_step_32x400_matches_bf16_oracle():

@@ -244,7 +244,9 @@ def test_gemm_split_kernels_of_the_large_products(ops, variant, M, N, K, tA, tB)
     """sk_gemm_f32_splitk variants 7 (stream-K 256 x 256 with split products) and 9 (256 x 128, the split done once per element
     while the tile is staged; K-major operands read back by ds_read_b64_tr_b16) in the N/T, N/N and T/N forms with ragged
     tile edges: against fp64 with bias, accumulate and the sigmoid epilogue; run-to-run identical; error not above the fp32-MFMA
-    kernels' (variant 8); variant 9 is bit for bit the 128 x 128 split kernel (2): same pieces, same products, same K order."""
+    kernels' (variant 8); variant 9 is bit for bit the 128 x 128 split kernel (2): same pieces, same products, same K order --
+    except in the N/N (data-gradient) form beyond 32 K steps, where its accumulators alternate their sign every 32 steps
+    (test_gemm_planes_data_gradient_form_has_no_dc_offset)."""
     g = torch.Generator().manual_seed(M + 3 * N + variant)
     A = torch.randn((K, M) if tA else (M, K), generator=g)
     B = torch.randn((N, K) if tB else (K, N), generator=g)
@@ -266,13 +268,41 @@ def test_gemm_split_kernels_of_the_large_products(ops, variant, M, N, K, tA, tB)
     err_mfma = float(((mfma.double() - ref).abs() / mag).max())
     assert err <= max(1.25 * err_mfma, 2.0 ** -22), (err, err_mfma)
     if variant == 9:
-        assert torch.equal(out, run(2))
+        flips = not tA and not tB and K > 32 * 16
+        assert torch.equal(out, run(2)) != flips
     Cw = torch.full((M, N + 8), 7.0).cuda()
     ops.gemm(dev(A), dev(B), Cw, M, N, K, A.shape[1], B.shape[1], N + 8, transA=tA, transB=tB, bias=dev(bias), act=1, variant=variant,
              ws_tag="t_sp")
     want = torch.sigmoid(ref - C0.double())
     assert float((Cw[:, :N].cpu().double() - want).abs().max()) < 1e-4
     assert bool((Cw[:, N:] == 7).all())
+
+
+def test_gemm_planes_data_gradient_form_has_no_dc_offset(ops):
+    """The bf16 MFMA truncates the alignment of its addends towards minus infinity: a split-product kernel's result carries a DC
+    offset (the same tiny negative amount in every element: on all-positive operands at K = 7168 a mean signed error of -1.5e-7
+    of the result where the fp32-MFMA kernels have 1e-10) -- harmless in a weight gradient, but the recurrence of the layer below
+    integrates the offset of a DATA gradient over the time axis.  The N/N instantiation of the planes kernel (what the engine's
+    data gradients take) alternates the sign of its accumulators every 32 K steps, so that the offsets of neighbouring phases
+    cancel: its mean signed error is pinned here to a tenth of the unflipped split kernel's (variant 2: same pieces, same
+    products) and its rel-L2 error against fp64 must not grow."""
+    M, N, K = 1024, 1792, 7168
+    g = torch.Generator().manual_seed(5)
+    A = torch.rand(M, K, generator=g) + 0.5
+    B = torch.rand(K, N, generator=g) + 0.5
+    ref = A.double() @ B.double()
+    res = {}
+    for v in (9, 2, 8):
+        C = torch.empty(M, N).cuda()
+        ops.gemm(dev(A), dev(B), C, M, N, K, K, N, N, variant=v, ws_tag="t_dc")
+        torch.cuda.synchronize()
+        d = C.cpu().double() - ref
+        res[v] = (float((d / ref).mean()), float(d.norm() / ref.norm()))
+    print("mean signed relative error / rel-L2 vs fp64: planes N/N %.2e / %.2e  128x128 split %.2e / %.2e  fp32 MFMA %.2e / %.2e" % (
+        res[9] + res[2] + res[8]))
+    assert res[2][0] < -5e-8                              # (the hardware behaviour this is about; if it ever goes away, so can FL)
+    assert abs(res[9][0]) < 0.1 * abs(res[2][0])
+    assert res[9][1] <= 1.05 * res[2][1] and res[9][1] <= res[8][1]
 
 
 def test_gemm_splitk_workspace_from_a_c_caller(ops):
