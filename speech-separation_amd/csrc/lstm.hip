@@ -112,6 +112,9 @@ constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 #ifndef SK_POLL_SLEEP
 #define SK_POLL_SLEEP 1
 #endif
+#ifndef SK_FWD_RING
+#define SK_FWD_RING 2  // split forward recurrence: fragment reads in flight ahead of their products (0: the compiler's order)
+#endif
 #ifndef SK_POLL_DELAY
 #define SK_POLL_DELAY 0
 #endif
@@ -633,6 +636,52 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         const float* hp = &hs[(kh * NQ) * 256 + lane * 4];
 #ifdef SK_TAIL_HALF
         const bool tail = PK && B > 16 && s >= a.lens[16];  // see SK_TAIL_HALF at BwdCfg
+#endif
+#if SK_FWD_RING > 0
+        if constexpr (S3) {
+          // The 3 NQ fragment reads of the product (piece lo, mid, hi of chunk 0, 1, ...) through a ring of SK_FWD_RING + 1
+          // registers: read i + SK_FWD_RING is ISSUED before the products of read i, so that an LDS latency (~100+ clocks) is
+          // covered by the 1-3 MFMAs (16 clocks each) of several reads instead of one.  Left to the compiler every read was
+          // followed by s_waitcnt lgkmcnt(0) (ISA: r|M r|MM r|MMM ...): one read in flight, the matrix pipe idle behind each.
+          // Same products, same order, same accumulators as the loop below: bit-identical results.  The order is stated
+          // (sched_group_barrier), the scheduler would sink the early reads again.  Measured (profiles/r05_fwd_ring.txt, three
+          // alternations): forward recurrences 6.17 -> 5.83 ms per training step (5.14 -> 4.86 us per time step), step 28.45 ->
+          // 28.05 ms; 2 and 3 reads ahead are equal (250 / 254 VGPRs, 4 would spill).  The same ring in the bf16 kernels (one
+          // 16-clock MFMA per read; 6 ahead forward, a sub-block's reads together backward) changed nothing there (12.93 vs
+          // 12.90 ms, profiles/r05_bf16_rings.txt): not kept.
+          constexpr int D = SK_FWD_RING, NR = 3 * NQ;
+          bf16x8 ring[D + 1];
+          auto rd = [&](int i) { return *reinterpret_cast<const bf16x8*>(hp + (i / 3) * 256 + (2 - i % 3) * PIECE); };
+#pragma unroll
+          for (int i = 0; i < D && i < NR; ++i) ring[i] = rd(i);
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            if (i + D < NR) ring[(i + D) % (D + 1)] = rd(i + D);
+            const bf16x8 hv = ring[i % (D + 1)];
+            const int q = i / 3;
+            if (i % 3 == 0) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], hv, acc0, 0, 0, 0);  // hi  * lo
+            } else if (i % 3 == 1) {
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], hv, acc1, 0, 0, 0);  // mid * mid
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], hv, acc0, 0, 0, 0);  // hi  * mid
+            } else {
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w3[q], hv, acc1, 0, 0, 0);  // lo  * hi
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[q], hv, acc0, 0, 0, 0);  // mid * hi
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], hv, acc1, 0, 0, 0);  // hi  * hi
+            }
+          }
+          __builtin_amdgcn_sched_group_barrier(0x100, D < NR ? D : NR, 0);
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            if (i + D < NR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i % 3 == 0)
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            else if (i % 3 == 1)
+              __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            else
+              __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+          }
+        } else
 #endif
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
