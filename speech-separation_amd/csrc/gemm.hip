@@ -1004,11 +1004,27 @@ __global__ __launch_bounds__(256, SK_SPLIT_OCC) void gemm_f32_kernel_split3(Gemm
     frag8_load<!TB>(bi, wn * 64, lane, vb0);
     frag8_load<TA>(ai, wm * 64 + 32, lane, va1);
     frag8_load<!TB>(bi, wn * 64 + 32, lane, vb1);
-    const Split3 a0 = split3(va0), b0 = split3(vb0);
+#ifdef SK_SPLIT_FREE_TN  // TIMING-ONLY diagnostic (wrong, finite numerics): the T/N form (weight gradients) finds its pieces for free
+    auto sp = [&](const float (&v)[8]) {
+      if constexpr (TA && !TB) {
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        Split3 f;
+        f.hi = __builtin_bit_cast(bf16x8_t, (u32x4_){__float_as_uint(v[0]) & 0x3f7f3f7fu, __float_as_uint(v[1]) & 0x3f7f3f7fu, __float_as_uint(v[2]) & 0x3f7f3f7fu, __float_as_uint(v[3]) & 0x3f7f3f7fu});
+        f.mid = __builtin_bit_cast(bf16x8_t, (u32x4_){__float_as_uint(v[4]) & 0x3f7f3f7fu, __float_as_uint(v[5]) & 0x3f7f3f7fu, __float_as_uint(v[6]) & 0x3f7f3f7fu, __float_as_uint(v[7]) & 0x3f7f3f7fu});
+        f.lo = f.hi;
+        return f;
+      } else {
+        return split3(v);
+      }
+    };
+#else
+    auto sp = [&](const float (&v)[8]) { return split3(v); };
+#endif
+    const Split3 a0 = sp(va0), b0 = sp(vb0);
     mma9(acc[0][0], a0, b0);
-    const Split3 a1 = split3(va1);
+    const Split3 a1 = sp(va1);
     mma9(acc[1][0], a1, b0);
-    const Split3 b1 = split3(vb1);
+    const Split3 b1 = sp(vb1);
     mma9(acc[0][1], a0, b1);
     mma9(acc[1][1], a1, b1);
     cur = (cur + 1) % NST;
