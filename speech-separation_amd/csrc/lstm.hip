@@ -112,6 +112,9 @@ constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 #ifndef SK_POLL_SLEEP
 #define SK_POLL_SLEEP 1
 #endif
+#ifndef SK_BWD_RING
+#define SK_BWD_RING 1  // fp32 backward recurrence: the next chunk's fragment read issued before this chunk's MFMAs (0: compiler's order)
+#endif
 #ifndef SK_FWD_RING
 #define SK_FWD_RING 2  // split forward recurrence: fragment reads in flight ahead of their products (0: the compiler's order)
 #endif
@@ -869,6 +872,33 @@ __device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* 
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
   const float* src = ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4;
+#if SK_BWD_RING > 0
+  if constexpr (!BF && n > 0 && KS <= 56) {  // (KS = 64: 4 more registers would pass the 192 this kernel must stay under)
+    // fp32: the fragment read of chunk j + 1 is issued before the four MFMAs of chunk j (the compiler's order: read, wait, four
+    // MFMAs -- the read's latency is covered by the previous chunk's 128 pipe clocks only as long as the LDS answers within them,
+    // and beside a hosted GEMM it does not always).  Same products, same order: bit-identical.  Backward recurrences 12.37 ->
+    // 12.17 ms per training step, three alternations (profiles/r05_bwd_ring.txt); 178 VGPRs.
+    float4 rg[2];
+    rg[0] = *reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      if (j + 1 < n) rg[(j + 1) & 1] = *reinterpret_cast<const float4*>(src + (j + 1) * 256);
+      const float4 db = rg[j & 1];
+      const int q = SBI * C::SB + j;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 0], db.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 1], db.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 2], db.z, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 3], db.w, acc1, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      if (j + 1 < n) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    return;
+  }
+#endif
 #pragma unroll
   for (int j = 0; j < n; ++j) {
     SK_TAIL_SKIP(j)
