@@ -1254,7 +1254,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
     // likes).  Left to itself the compiler found a good interleave for some instantiations and long VALU runs with the MFMA pipe
     // idle for others (the FL form lost 6 % to that, not to its 4 extra instructions).  Measured, one device
     // (profiles/r05_planes_sched.txt): N/N 181 -> 186-188 TFLOP/s WITH the sign phases (172 without the statement), N/T 204.5 ->
-    // 210-212, T/N 187 -> 195, 8192^3 215 -> 222; 3 and 4 are equal within the run-to-run spread, 2 loses.
+    // 210-212, T/N 187 -> 195, 8192^3 215 -> 222; 3 and 4 are equal within the run-to-run spread, 2 loses; a group of 8-24 VALU
+    // instructions stated in FRONT of the step's first MFMA (in the shadow of its first fragment reads) loses 1-4 % too.
     if constexpr (SK_PLANES_SCHED > 0 && decltype(store)::value) {
 #pragma unroll
       for (int i = 0; i < 24; ++i) {
