@@ -2142,7 +2142,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   // gradients: 172.8 vs 164.0 TFLOP/s, the unsplit T/N weight gradient 172.0 vs 141.3), 2 also the N/T projections
   static const int split_sk = [] { const char* e = getenv("SEPKERN_GEMM_SPLIT_SK"); return e ? atoi(e) : 1; }();
   if (variant == 0 && !split_on) variant = 8;
-  const bool split = !bf16 && (variant == 0 || variant == 2 || variant == 7 || variant == 9) && dma_ok(g, transA, transB);
+  bool split = !bf16 && (variant == 0 || variant == 2 || variant == 7 || variant == 9) && dma_ok(g, transA, transB);
   // split ONCE per element while staging (gemm_f32_kernel_planes_nt): unsplit, unbatched N/T products
   // For unsplit, unbatched products with enough 256 x 128 tiles to fill the chip it is what variant 0 takes (SEPKERN_GEMM_PLANES=0:
   // never): 180 / 193 / 179 TFLOP/s on the projection / data-gradient / unsplit weight-gradient shapes against 165 / 179 / 169
@@ -2151,6 +2151,11 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   static const bool planes_on = [] { const char* e = getenv("SEPKERN_GEMM_PLANES"); return !(e && e[0] == '0'); }();
   const bool planes = split && splitk == 1 && batch == 1 && M >= 256 && N >= 128 &&
                       (variant == 9 || (variant == 0 && planes_on && sk_cdiv(M, 256) * sk_cdiv(N, 128) >= 192));
+  // The data-gradient form (N/N) with a long K is where a split product's truncation offset matters (a recurrence integrates
+  // it: see FL in gemm_f32_kernel_planes).  The planes kernel cancels it with sign phases; the other split kernels do not, so
+  // under the library's own choice (variant 0) such a product that cannot take the planes kernel -- too few tiles, split-K,
+  // batched -- runs on the fp32-MFMA kernels, whose accumulation rounds to nearest.  (Small shapes: not the training step's.)
+  if (variant == 0 && split && !planes && !transA && !transB && K >= 1024) split = false;
   const bool mfma_choose = variant == 8 || (variant == 0 && !split);  // the r04 policy among the fp32-MFMA kernels
   // 256 x 128 block tiles, 8 waves (fp32 MFMA): variant 4, or chosen for the large unsplit N/T and N/N products -- measured
   // +2 % / +5 % on them stand-alone.  SEPKERN_GEMM_WIDE=0 (diagnostics): never chosen.

@@ -303,6 +303,14 @@ def test_gemm_planes_data_gradient_form_has_no_dc_offset(ops):
     assert res[2][0] < -5e-8                              # (the hardware behaviour this is about; if it ever goes away, so can FL)
     assert abs(res[9][0]) < 0.1 * abs(res[2][0])
     assert res[9][1] <= 1.05 * res[2][1] and res[9][1] <= res[8][1]
+    # the library's own choice (variant 0) never hands a long-K data-gradient form to a split kernel without sign phases: this
+    # shape (8 tiles: too few for the planes kernel) must come out without the offset too
+    Ms, Ns = 512, 256
+    Cs = torch.empty(Ms, Ns).cuda()
+    ops.gemm(dev(A[:Ms]), dev(B[:, :Ns].contiguous()), Cs, Ms, Ns, K, K, Ns, Ns, variant=0, ws_tag="t_dc")
+    torch.cuda.synchronize()
+    ds = Cs.cpu().double() - ref[:Ms, :Ns]
+    assert abs(float((ds / ref[:Ms, :Ns]).mean())) < 0.1 * abs(res[2][0])
 
 
 def test_gemm_splitk_workspace_from_a_c_caller(ops):
