@@ -93,15 +93,20 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  *      fp32 multiplier rounds away itself -- are not formed.  Error against fp64 is not above the fp32-MFMA kernels' (tests);
  *      160-173 TFLOP/s fp32-equivalent on the training step's large products against 124-135 (one MI355X, stand-alone; the
  *      fp32-MFMA pipe's own peak is 157).  Kernels: 9 for unsplit, unbatched products of at least 192 tiles of 256 x 128 (the split
- *      is done once per element while the tile is staged: 180-193 TFLOP/s; 72 KB of LDS, 200 VGPRs -- a caller that runs a product
- *      beside a persistent recurrence passes 2), else 2 (128 x 128 tiles; any splitk / batch).  SEPKERN_GEMM_PLANES=0: never 9,
+ *      is done once per element while the tile is staged: 186-212 TFLOP/s; 72 KB of LDS, 200 VGPRs -- a caller that runs a product
+ *      beside a persistent recurrence passes 2), else 2 (128 x 128 tiles; any splitk / batch).  The bf16 MFMA truncates the
+ *      alignment of its addends towards minus infinity: a split-product result carries a DC offset (about -2e-11 of the result per
+ *      K element: -1.5e-7 at K = 7168), harmless in a weight gradient but integrated over time by the recurrence below a DATA
+ *      gradient; kernel 9 therefore alternates the sign of its accumulators every 32 K steps in the N/N (data-gradient) form
+ *      (offset +1.6e-9), and an N/N product with K >= 1024 that cannot take kernel 9 (too few tiles, split-K, batched) runs on the
+ *      fp32-MFMA kernels as under 8.  SEPKERN_GEMM_PLANES=0: never 9,
  *      then 7 for large unsplit N/N and T/N products with K >= 4096 when ws >= sk_gemm_streamk_workspace_bytes() is given.  Other operands (F = 257 columns,
  *      K = 514): the fp32-MFMA kernels as under 8.  Operands beyond bf16's finite range (|x| > 3.39e38) round to inf.
  *      SEPKERN_GEMM_SPLIT=0 (diagnostics) makes 0 mean 8.
  *   1  the register-staged fp32-MFMA kernel (v_mfma_f32_32x32x2_f32), any alignment
  *   2  the 128 x 128-tile split kernel wherever the LDS-DMA conditions hold (else as 8)
  *   3 / 4  the 128 x 128 / 256 x 128-tile fp32-MFMA LDS-DMA kernels wherever they apply (diagnostics)
- *   9  256 x 128 tiles, split once per element while staging (unsplit, unbatched products; else as 2)
+ *   9  256 x 128 tiles, split once per element while staging (unsplit, unbatched products; else as 2); N/N: sign phases (above)
  *   6 / 7  256 x 256 tiles, one PERSISTENT workgroup per CU with a stream-K cut of the last partial round of tiles, fp32-MFMA (6) or
  *      split products (7): unsplit, unbatched products; splitk = 1 and ws >= sk_gemm_streamk_workspace_bytes(), zero-filled
  *      before its first use and left with zeroed counters by every launch (without ws: 4 / 2).  Tiles of the cut are summed
