@@ -19,7 +19,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) with extra objects:
   roofline      the dominant kernel (fp32 MFMA GEMM): algorithmic FLOP / HIP-event time, live in the timed region
   cpu_baseline  the CPU oracle's train step (torch-CPU port of the reference loop) on a bounded sample
   secondary     (default run on one GPU only) the other one-GPU BASELINE configurations, timed in the same process after the
-                headline's timed region: the variable-length set in fp32 and bf16, bf16 3-speaker, RSH 4-speaker (SECONDARY)
+                headline's timed region: the variable-length set in fp32 and bf16, bf16 3-speaker, RSH 4-speaker, the headline
+                workload on the fp32-MFMA kernels throughout (the reference's literal arithmetic) and the reference's own default
+                model and batch size, 2 x 600 / 100 utterances (SECONDARY)
+  aux           (default run on one GPU only) the HBM-bound kernels `north_star` names -- STFT, mask-apply + iSTFT, PIT loss forward
+                and backward: us per launch, GB/s of algorithmic bytes, fraction of the HBM peak
+  library       which libsepkern.so ran and its sk_build_flags() (0 = the product build; a diagnostic build needs --diagnostic)
 """
 import argparse
 import json
@@ -70,7 +75,13 @@ def parse(argv=None):
                          "(the r03 layout's cost) instead of the packed rows; frames still count the valid ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--aux", action="store_true", help="also time the STFT / iSTFT kernels (extra JSON fields)")
+    ap.add_argument("--aux", action="store_true", help="time the streaming kernels (STFT, mask-iSTFT, PIT forward / backward) "
+                                                       "also on a non-default run (the default run on one GPU always does)")
+    ap.add_argument("--no-aux", action="store_true")
+    ap.add_argument("--diagnostic", action="store_true",
+                    help="accept a library whose sk_build_flags() is not 0 (a timing-only / ablation build named by SEPKERN_LIB, "
+                         "with SEPKERN_ALLOW_DIAGNOSTIC_LIB=1): the line then carries its flags; without this flag bench.py exits")
+    ap.add_argument("--no-power-probe", action="store_true")
     ap.add_argument("--arch", choices=["upit", "rsh"], default="upit",
                     help="rsh: the recurrent-selective-hearing arch (BASELINE configs[4]); not the headline metric")
     ap.add_argument("--no-secondary", action="store_true",
@@ -402,6 +413,14 @@ def measure(args, env, standalone_pass=True):
         res["distributed"] = dist_info
     if lstm_fallback:
         res["lstm_fallback"] = lstm_fallback
+    # HBM-bound classes recorded in the timed region (the PIT loss kernels run in every step): bytes, not FLOP
+    streaming = {k: prof.pop(k) for k in list(prof) if k.split("@")[0] in STREAM_CLASSES}
+    if streaming:
+        res["streaming_in_step"] = {k: stream_row(v) for k, v in streaming.items()}
+    if prof_alone:
+        for k in list(prof_alone):
+            if k.split("@")[0] in STREAM_CLASSES:
+                del prof_alone[k]
     if prof:
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS     # the dtype's own dense MFMA peak
 
@@ -439,7 +458,7 @@ def measure(args, env, standalone_pass=True):
                                             "products per fp32 product): peak = the bf16 dense MFMA peak / 6 in fp32-equivalent FLOP; achieved "
                                             "= 2MNK / time.  The fp32-MFMA pipe (157.3 TFLOP/s) does not bound these launches")
             res["roofline"]["achieved_over_fp32_mfma_peak"] = round(ach / PEAK_F32_MFMA_TFLOPS, 4)
-        if prof_alone:
+        if prof_alone and kname in prof_alone:
             n1, ms1, fl1 = prof_alone[kname]
             ach1 = fl1 / (ms1 * 1e-3) / 1e12
             res["roofline"]["standalone"] = {
@@ -485,17 +504,36 @@ def measure(args, env, standalone_pass=True):
     return res, (pcms, T_mean)
 
 
+STREAM_CLASSES = ("stft_kernel", "istft_kernel", "pit_fwd", "pit_bwd")
+
+
+def stream_row(v):
+    """(launches, ms, algorithmic bytes) of an HBM-bound class -> us per launch, GB/s, fraction of the HBM peak."""
+    n, ms, by = v
+    gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"launches": n, "us_per_launch": round(1e3 * ms / max(1, n), 2), "MB_algorithmic_per_launch": round(by / max(1, n) / 1e6, 2),
+            "GBs_algorithmic": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
+
+
 # The other BASELINE.json configurations that fit one GPU, timed by the DEFAULT run after the headline's timed region (same
 # process, same harness, their own model / optimizer / resident batches), so that the driver's one line witnesses them too:
 #   ragged        SURVEY.md 8d's variable-length set (the WSJ0-2mix-SHAPED batches `north_star` names), fp32, packed rows
 #   bf16_3spk     BASELINE configs[3]: 3-speaker uPIT (6-permutation PIT loss), bf16, 32 x 400
 #   bf16_ragged   the same arithmetic on the variable-length set (2 speakers, as the ragged set is defined)
 #   rsh_4spk      BASELINE configs[4]'s one-GPU shape: RSH 2 x 600, 4 speakers, 32 x 400
+#   fp32_mfma     the headline workload in the reference's LITERAL arithmetic: every GEMM on the fp32-MFMA kernels (variants 8 / 1:
+#                 fp32 products, accumulation rounded to nearest) and the plain fp32-MFMA product in the forward recurrence -- what
+#                 nn.LSTM / nn.Linear on fp32 tensors compute (/root/reference/archs/uPIT.py:115,132,141) up to summation order
+#   ref_default_2x600_b100   the reference's OWN default model and batch size (archs/uPIT.py:115-119: 2 x 600; run_train.sh:18 and
+#                 steps/train_qsub.py:39-41: 100 utterances per batch), 400 frames each: the only path through "several batch groups
+#                 per workgroup" (G = 3) of the persistent recurrences
 SECONDARY = (
     ("ragged", dict(ragged=True)),
     ("bf16_3spk", dict(dtype="bf16", num_spk=3)),
     ("bf16_ragged", dict(dtype="bf16", ragged=True)),
     ("rsh_4spk", dict(arch="rsh", hidden=600, layers=2, num_spk=4)),
+    ("fp32_mfma", dict(env={"SEPKERN_GEMM_VARIANTS": "8,1", "SEPKERN_LSTM_FWD": "0,1,1,0,0,0,0,0"})),
+    ("ref_default_2x600_b100", dict(hidden=600, layers=2, batch=100)),
 )
 SECONDARY_STEPS, SECONDARY_WARMUP = 20, 3
 
@@ -517,8 +555,12 @@ def secondary_workloads(args, env, only=None):
         a = argparse.Namespace(**vars(args))
         a.steps, a.warmup, a.no_kernel_events, a.aux = SECONDARY_STEPS, SECONDARY_WARMUP, False, False
         for k, v in over.items():
-            setattr(a, k, v)
+            if k != "env":
+                setattr(a, k, v)
         log("secondary workload %s" % name)
+        # (the engine reads its switches when it is built: the workload's own environment holds for that long only)
+        saved_env = {k: os.environ.get(k) for k in over.get("env", {})}
+        os.environ.update(over.get("env", {}))
         try:
             r, _ = measure(a, env, standalone_pass=False)
         except (Exception, SystemExit) as e:            # noqa: BLE001 -- reported, not swallowed
@@ -526,6 +568,11 @@ def secondary_workloads(args, env, only=None):
             log("secondary workload %s FAILED: %s" % (name, out[name]["error"]))
             continue
         finally:
+            for k, v in saved_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             import gc
             gc.collect()
             env.torch.cuda.empty_cache()
@@ -555,6 +602,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         sys.exit("bench.py --gpus %d under a launcher that started %d ranks" % (args.gpus, world))
+    # which library: before anything touches the GPU.  The loader refuses a diagnostic build (sk_build_flags() != 0: timing-only /
+    # ablation / tuning builds of csrc/Makefile's variant targets) unless SEPKERN_ALLOW_DIAGNOSTIC_LIB=1; with it, this program still
+    # wants --diagnostic, and the line names the library and its flags either way.
+    from sepkern import _lib
+    _lib.load()
+    library = _lib.library_info()
+    if library["build_flags"] and not args.diagnostic:
+        sys.exit("bench: %s is a diagnostic build (sk_build_flags() = 0x%x: %s); its numbers are not the product's -- pass "
+                 "--diagnostic to time it anyway" % (library["path"], library["build_flags"], "; ".join(library["build_flag_names"])))
     # rehearsal on a 1-GPU box: SEPKERN_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 (use with
     # SEPKERN_DIST_BACKEND=gloo and SEPKERN_LSTM_MODE=2, since two processes cannot both keep a
     # persistent grid resident on one GPU)
@@ -570,13 +626,15 @@ def main():
     from sepkern import dist as skdist
     skdist.init_from_env()                                # nccl (= RCCL over xGMI) unless SEPKERN_DIST_BACKEND says otherwise
 
-    from sepkern import _lib
-    _lib.load()
     env = argparse.Namespace(torch=torch, dist=dist, skdist=skdist, world=world, rank=rank, local=local)
     res, aux_in = measure(args, env)
-    if args.aux and rank == 0:
+    res["library"] = library
+    default_run = world == 1 and is_headline(args)
+    if rank == 0 and world == 1 and not args.no_aux and (args.aux or default_run):
         from sepkern import ops
-        res["aux"] = aux_kernels(torch, ops, aux_in[0], aux_in[1], args.batch, args.num_spk)
+        res["aux"] = aux_kernels(torch, ops, aux_in[0], args.batch, args.num_spk)
+    if rank == 0 and default_run and not args.no_power_probe and "roofline" in res:
+        res["roofline"]["power_note"] = power_probe(torch)
     if world == 1 and not args.no_secondary and is_headline(args):
         res["secondary"] = secondary_workloads(args, env, only=[s for s in args.secondary_only.split(",") if s])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -623,11 +681,13 @@ def numerics_note(model, args):
     if args.dtype == "bf16":
         return "bf16 matrix-core inputs for every product incl. the recurrences, fp32 accumulate / state / optimizer"
     gemms = ("products with aligned operands (the large GEMMs: 99 % of the GEMM FLOP) are formed on the bf16 matrix pipe by the three-way "
-             "bf16 split of both fp32 operands -- x = hi + mid + lo exactly, pieces by rounding; the six piece products of relative "
-             "size >= 2^-18, each exact, are added into fp32 accumulators; the three left out are together <= 2^-26 of the product "
-             "(a quarter of an fp32 multiplier's own rounding): error vs fp64 not above the fp32-MFMA kernels' "
-             "(tests/test_gpu_kernels.py); SEPKERN_GEMM_SPLIT=0 = fp32-MFMA kernels throughout")
-    if os.environ.get("SEPKERN_GEMM_SPLIT", "1") == "0" or (eng is not None and eng.var_main not in (0, 2, 7, 9)):
+             "bf16 split of both fp32 operands -- x = hi + mid + lo exactly, pieces by rounding (|mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|); "
+             "the six piece products of relative size >= 2^-16, each exact, are added into fp32 accumulators (sign phases cancel the "
+             "bf16 MFMA's truncation offset); the three left out are together <= 2^-23 |a||b| in the worst case: a single product may "
+             "be off by ~1 ulp where an fp32 FMA is exact, on sums the error vs fp64 is not above the fp32-MFMA kernels' "
+             "(tests/test_gpu_kernels.py, test_gpu_signed_error.py, test_gpu_fullsize.py); secondary.fp32_mfma = the same step on "
+             "fp32-MFMA kernels throughout")
+    if os.environ.get("SEPKERN_GEMM_SPLIT", "1") == "0" or (eng is not None and eng.var_main not in (0, 2, 9)):
         gemms = "GEMMs on the fp32-MFMA kernels"
     if eng is not None and eng.split3_fwd:
         return ("fp32 storage, fp32 accumulation, no operand perturbed; " + gemms + "; the forward recurrence forms h W_hh^T the same way "
@@ -639,32 +699,117 @@ def numerics_note(model, args):
     return "fp32 storage and accumulation; " + gemms + "; recurrences: fp32-MFMA products, exact hand-off (flags)"
 
 
-def aux_kernels(torch, ops, pcms, T, B, S):
-    """HBM-bound front/back ends: STFT (train layout) and mask-apply + iSTFT, GB/s of algorithmic bytes."""
+def aux_kernels(torch, ops, pcms, B, S, reps=50):
+    """The HBM-bound kernels `north_star` names, at the workload's own shape: STFT (train layout, (S + 1) B utterances), mask-apply +
+    iSTFT (S B source signals), PIT loss forward (pairwise SSE + S! sums + arg-min) and backward on the packed rows.  Each is
+    enqueued `reps` times back to back between two HIP events on the launch stream (ops._timed); bytes = SURVEY 8d's algorithmic
+    bytes per frame.  Returns {name: {us_per_launch, MB_algorithmic_per_launch, GBs_algorithmic, frac_of_hbm_peak}}."""
+    from sepkern.packing import Packing
     wavs = [torch.from_numpy(p[k]).cuda() for p in pcms for k in range(S + 1)]
     specs = ops.stft_batch([torch.from_numpy(p[0]).cuda() for p in pcms], want_complex=True, layout="FT")
     masks = [[torch.rand(257, sp.shape[1], device="cuda") for _ in range(S)] for sp in specs]
-    out = {}
+    frames = [int(sp.shape[1]) for sp in specs]
+    pk = Packing.from_lens(sorted(frames, reverse=True), "cuda")
+    F = 257
+    mix = torch.rand(pk.Rp, F, device="cuda")
+    srcs = [torch.rand(pk.Rp, F, device="cuda") for _ in range(S)]
+    mask = torch.rand(pk.Rp, S * F, device="cuda")
+    gscale = torch.ones(1, device="cuda")
 
-    def timeit(fn, n=20):
-        fn()
+    def run():
+        ops.stft_batch(wavs, want_complex=False, layout="TF", repeat=reps)
+        ops.mask_istft(specs, masks, want_float=False, repeat=reps)
+        fw = ops.pit_mse_fwd(mask, mix, srcs, pk.lens, packing=pk, repeat=reps)
+        ops.pit_mse_bwd(mask, mix, srcs, fw["best_perm"], fw["out"], gscale, packing=pk, repeat=reps)
+    run()                                                  # warm-up (allocations, descriptor uploads)
+    torch.cuda.synchronize()
+    ops.PROF = {}
+    run()
+    torch.cuda.synchronize()
+    prof = ops.prof_summary()
+    ops.PROF = None
+    out = {}
+    for cls, (n, ms, by) in prof.items():
+        out[cls] = stream_row((n * reps, ms, by))
+    out["note"] = ("%d launches each, back to back between HIP events; bytes = algorithmic (SURVEY 8d): STFT 128 int16 samples in + 257 fp32 "
+                   "bins out per frame; mask-iSTFT 257 complex64 + 257 fp32 in, 128 int16 out per frame and source; PIT forward (2S+1) F fp32 "
+                   "per frame, backward (3S+1) F" % reps)
+    return out
+
+
+def power_probe(torch, seconds=2.5):
+    """The dominant GEMM class is POWER-bound (r05: 181 TFLOP/s sustained at 1.89 GHz and 1375 W of the 1400 W cap, where the same
+    kernel runs 186-212 for a few launches): a sustained run of the projection-shaped product on the planes kernel while the
+    device's own sensors are read from sysfs (no child process): package power, its cap, and the shader clock.  Returns a dict for
+    roofline.power_note -- the practical ceiling of the class next to `peak`."""
+    import glob
+    import threading
+    from sepkern import ops
+    note = {"measured_r05": "181 TFLOP/s sustained at 1.89 GHz, 1375 W of the 1400 W cap (profiles/r05_gemm_split6.txt): the split-product "
+                            "GEMMs are power-bound; ~0.45-0.5 of the bf16-pipe peak / 6 is the practical ceiling of this class"}
+    try:
+        M, N, K = 12800, 7168, 1792
+        A = torch.randn(M, K, device="cuda")
+        Bm = torch.randn(N, K, device="cuda")
+        C = torch.empty(M, N, device="cuda")
+        for _ in range(3):
+            ops.gemm(A, Bm, C, M, N, K, K, K, N, transB=True)
         torch.cuda.synchronize()
+        hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+
+        def read(path):
+            try:
+                with open(path) as f:
+                    return float(f.read().strip())
+            except (OSError, ValueError):
+                return None
+        samples, stop = [], threading.Event()
+
+        def sampler():
+            while not stop.is_set():
+                row = []
+                for h in hw:
+                    pw = read(h + "/power1_average")
+                    pw = read(h + "/power1_input") if pw is None else pw
+                    row.append((pw, read(h + "/freq1_input"), read(h + "/power1_cap")))
+                samples.append(row)
+                time.sleep(0.2)
+        th = threading.Thread(target=sampler)
+        th.start()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0, n = time.time(), 0
         e0.record()
-        for _ in range(n):
-            fn()
+        while time.time() - t0 < seconds:
+            for _ in range(40):
+                ops.gemm(A, Bm, C, M, N, K, K, K, N, transB=True)
+            n += 40
+            torch.cuda.synchronize()
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n
-    ms = timeit(lambda: ops.stft_batch(wavs, want_complex=False, layout="TF"))
-    utt_frames = sum(1 + len(p[0]) // 128 for p in pcms)
-    nfr = utt_frames * (S + 1)
-    by = nfr * (128 * 2 + 257 * 4)
-    out["stft_mag"] = {"ms_incl_host": round(ms, 4), "frames_per_s": round(nfr / ms * 1e3), "GBs_algorithmic": round(by / ms / 1e6, 1)}
-    ms = timeit(lambda: ops.mask_istft(specs, masks, want_float=False))
-    by = utt_frames * S * (257 * 8 + 257 * 4 + 128 * 2)
-    out["mask_istft"] = {"ms_incl_host": round(ms, 4), "frames_per_s": round(utt_frames * S / ms * 1e3), "GBs_algorithmic": round(by / ms / 1e6, 1)}
-    return out
+        stop.set()
+        th.join()
+        ms = e0.elapsed_time(e1) / n
+        note["sustained"] = {"shape": "12800 x 7168 x 1792 N/T (a layer's input projection)", "launches": n, "seconds": round(time.time() - t0, 2),
+                             "tflops_fp32_equivalent": round(2.0 * M * N * K / ms / 1e9, 1),
+                             "frac_of_split_peak": round(2.0 * M * N * K / ms / 1e9 / PEAK_F32_SPLIT_TFLOPS, 4)}
+        # the card under load: the hwmon whose power reading is highest in the second half of the run
+        if hw and samples:
+            late = samples[len(samples) // 2:]
+            best, best_w = None, -1.0
+            for i in range(len(hw)):
+                ws = [r[i][0] for r in late if r[i][0] is not None]
+                if ws and sum(ws) / len(ws) > best_w:
+                    best, best_w = i, sum(ws) / len(ws)
+            if best is not None:
+                fr = [r[best][1] for r in late if r[best][1] is not None]
+                cap = [r[best][2] for r in late if r[best][2] is not None]
+                note["sensors"] = {"watts": round(best_w / 1e6, 1), "sclk_mhz": round(sum(fr) / len(fr) / 1e6, 1) if fr else None,
+                                   "cap_watts": round(cap[0] / 1e6, 1) if cap else None, "samples": len(late), "source": hw[best]}
+        if "sensors" not in note:
+            note["sensors"] = None
+    except Exception as e:                                # noqa: BLE001 -- a probe must not cost the line
+        note["error"] = "%s: %s" % (type(e).__name__, e)
+    return note
 
 
 if __name__ == "__main__":

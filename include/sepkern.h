@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 120
+#define SK_VERSION 130
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -38,6 +38,16 @@ typedef void* sk_stream_t; /* hipStream_t */
 
 int sk_version(void);
 const char* sk_last_error(void);
+/* Which numerics- or timing-changing build options this library was compiled with: 0 for the product build (plain `make`).
+ * The kernel sources carry ablation / timing-only / tuning switches for the measurement scripts under profiles/ (`make variant`,
+ * `make gemm_variant` build them into libsepkern_<name>.so next to the product library); a library built with any of them
+ * reports it here, and the ctypes loader refuses it unless SEPKERN_ALLOW_DIAGNOSTIC_LIB=1 (sepkern/_lib.py), bench.py unless
+ * --diagnostic -- a headline can then not come from a wrong-numerics build by accident. */
+#define SK_BUILD_TIMING_ONLY 0x1 /* results WRONG by construction (work skipped or faked to bound a kernel's time)        */
+#define SK_BUILD_ARITH 0x2       /* another arithmetic than documented (nine piece products, no sign phases, ...)          */
+#define SK_BUILD_TUNING 0x4      /* same results, other tuning constants (LDS stages, ring depths, poll cadence, ...)      */
+#define SK_BUILD_STAMPS 0x8      /* per-phase clock stamps in the recurrence kernels                                       */
+unsigned sk_build_flags(void);
 /* number of CUs / LDS bytes per workgroup of the current device */
 int sk_device_info(int* num_cu, int* lds_bytes);
 
@@ -87,39 +97,46 @@ int sk_gemm_f32(const float* A, const float* B, float* C, const float* bias, int
  * variant (which kernel; results agree to fp32 summation order -- every variant is an fp32 product with fp32 accumulation):
  *   0  choose (the default everywhere).  Products whose operands allow LDS-DMA staging (every operand row 16-byte aligned, K a
  *      multiple of 16, not the T/T form) run on the BF16 MATRIX PIPE by the three-way split of both fp32 operands: x = hi + mid + lo
- *      exactly, three bf16 pieces made by rounding to nearest (|mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|); of the nine piece products
- *      per element pair, each exact in fp32, the six of relative size >= 2^-18 are added into fp32 accumulators by
- *      v_mfma_f32_32x32x16_bf16; the three of size <= 2^-27 -- together <= 2^-26 of the product, a quarter of the half ulp an
- *      fp32 multiplier rounds away itself -- are not formed.  Error against fp64 is not above the fp32-MFMA kernels' (tests);
- *      160-173 TFLOP/s fp32-equivalent on the training step's large products against 124-135 (one MI355X, stand-alone; the
- *      fp32-MFMA pipe's own peak is 157).  Kernels: 9 for unsplit, unbatched products of at least 192 tiles of 256 x 128 (the split
- *      is done once per element while the tile is staged: 186-212 TFLOP/s; 72 KB of LDS, 200 VGPRs -- a caller that runs a product
- *      beside a persistent recurrence passes 2), else 2 (128 x 128 tiles; any splitk / batch).  The bf16 MFMA truncates the
- *      alignment of its addends towards minus infinity: a split-product result carries a DC offset (about -2e-11 of the result per
- *      K element: -1.5e-7 at K = 7168), harmless in a weight gradient but integrated over time by the recurrence below a DATA
- *      gradient; kernel 9 therefore alternates the sign of its accumulators every 32 K steps in the N/N (data-gradient) form
- *      (offset +1.6e-9), and an N/N product with K >= 1024 that cannot take kernel 9 (too few tiles, split-K, batched) runs on the
- *      fp32-MFMA kernels as under 8.  SEPKERN_GEMM_PLANES=0: never 9,
- *      then 7 for large unsplit N/N and T/N products with K >= 4096 when ws >= sk_gemm_streamk_workspace_bytes() is given.  Other operands (F = 257 columns,
- *      K = 514): the fp32-MFMA kernels as under 8.  Operands beyond bf16's finite range (|x| > 3.39e38) round to inf.
- *      SEPKERN_GEMM_SPLIT=0 (diagnostics) makes 0 mean 8.
+ *      EXACTLY, three bf16 pieces made by rounding to nearest (bf16 has 8 significand bits: |x - hi| <= 2^-8 |x|, so |mid| <= 2^-8 |x|
+ *      and |lo| <= 2^-16 |x|; typical values are half of these bounds).  Of the nine piece products per element pair -- each exact in
+ *      fp32 (8 x 8 bits), of relative sizes 1, 2^-8 (two), 2^-16 (three), 2^-24 (two), 2^-32 -- the six of size >= 2^-16 are added
+ *      into fp32 accumulators by v_mfma_f32_32x32x16_bf16; the three smallest, together at most 2^-23 |a||b| in the worst case (one
+ *      fp32 ulp of the product; 2^-25 for typical pieces), are not formed: a SINGLE product may therefore be off by about one ulp
+ *      where an fp32 FMA is exact (tests: <= 2^-22 relative).  What justifies calling this an fp32 GEMM is measured, not this
+ *      bound: on sums the error against fp64 is not above the fp32-MFMA kernels' (tests, operands spanning 2^+-20; full-size
+ *      training step in four arithmetics against one oracle step).  160-212 TFLOP/s fp32-equivalent on the training step's large
+ *      products against 124-135 (one MI355X, stand-alone; the fp32-MFMA pipe's own peak is 157).  Kernels: 9 for unsplit,
+ *      unbatched products of at least 192 tiles of 256 x 128 (the split is done once per element while the tile is staged:
+ *      186-212 TFLOP/s; 72 KB of LDS, 200 VGPRs -- a caller that runs a product beside a persistent recurrence passes 2), else 2
+ *      (128 x 128 tiles; any splitk / batch).
+ *      SIGN PHASES: the bf16 MFMA truncates the alignment of its addends towards minus infinity, so a plain split-product result
+ *      carries a DC offset (about -2e-11 of the result per K element on all-positive operands: -1.5e-7 at K = 7168) that anything
+ *      integrating the result amplifies (r05: the recurrence below a data gradient).  Both split kernels, in every form, therefore
+ *      keep -sum instead of +sum in their accumulators over stretches of K (signs + - - + per period of about 128 K steps, the B
+ *      operand negated before it is split): truncation then pulls down and up in turn and the offsets cancel
+ *      (tests/test_gpu_signed_error.py: mean signed error at the fp32-MFMA kernels' level).
+ *      SEPKERN_GEMM_PLANES=0: never 9.  Other operands (F = 257 columns, K = 514): the fp32-MFMA kernels as under 8.  Operands
+ *      beyond bf16's finite range (|x| > 3.39e38) round to inf.  SEPKERN_GEMM_SPLIT=0 makes 0 mean 8.
  *   1  the register-staged fp32-MFMA kernel (v_mfma_f32_32x32x2_f32), any alignment
  *   2  the 128 x 128-tile split kernel wherever the LDS-DMA conditions hold (else as 8)
  *   3 / 4  the 128 x 128 / 256 x 128-tile fp32-MFMA LDS-DMA kernels wherever they apply (diagnostics)
- *   9  256 x 128 tiles, split once per element while staging (unsplit, unbatched products; else as 2); N/N: sign phases (above)
- *   6 / 7  256 x 256 tiles, one PERSISTENT workgroup per CU with a stream-K cut of the last partial round of tiles, fp32-MFMA (6) or
- *      split products (7): unsplit, unbatched products; splitk = 1 and ws >= sk_gemm_streamk_workspace_bytes(), zero-filled
- *      before its first use and left with zeroed counters by every launch (without ws: 4 / 2).  Tiles of the cut are summed
- *      piece by piece in a fixed order: deterministic.
- *   8  choose among the fp32-MFMA kernels only (the r04 default): LDS-DMA where the operands allow, stream-K (6) for the large
- *      unsplit N/T and N/N products when a ws is given, the register-staged kernel otherwise.
- *   (5 was the 256 x 256 tile without the stream-K cut: retired in r04.) */
+ *   9  256 x 128 tiles, split once per element while staging (unsplit, unbatched products; else as 2)
+ *   6  256 x 256 tiles, one PERSISTENT workgroup per CU with a stream-K cut of the last partial round of tiles, fp32 MFMA:
+ *      unsplit, unbatched products; splitk = 1 and ws >= sk_gemm_streamk_workspace_bytes(), zero-filled before its first use and
+ *      left with zeroed counters by every launch (without ws: 4).  Tiles of the cut are summed piece by piece in a fixed order:
+ *      deterministic.
+ *   8  choose among the fp32-MFMA kernels only -- the reference's literal arithmetic (fp32 products, fp32 accumulation rounded to
+ *      nearest): LDS-DMA where the operands allow, stream-K (6) for the large unsplit N/T and N/N products when a ws is given, the
+ *      register-staged kernel otherwise.  bench.py times the whole step on it as secondary.fp32_mfma.
+ *   (5: the 256 x 256 tile without the stream-K cut, retired in r04; 7: the split-product form of 6, retired in r06 -- since the
+ *   planes kernel it served no launch of any configuration.  Both are SK_EINVAL.) */
 size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 /* Which kernel the calling thread's LAST sk_gemm_f32[_splitk] / sk_gemm_bf16_splitk launch took (profiling: bench.py prices a
- * launch against the peak of the matrix pipe it ran on): 1 register-staged fp32 MFMA, 3 / 4 / 6 the 128 x 128 / 256 x 128 /
- * stream-K fp32-MFMA LDS-DMA kernels, 2 / 7 / 10 the 128 x 128 / stream-K / 256 x 128 split-while-staging SPLIT kernels (bf16 pipe, six piece
- * products), 9 bf16 inputs;
- * 0 before the first launch. */
+ * launch against the peak of the matrix pipe it ran on; tests/test_gpu_census.py generates DESIGN.md's kernel census from it):
+ * 1 register-staged fp32 MFMA, 3 / 4 / 6 the 128 x 128 / 256 x 128 / stream-K fp32-MFMA LDS-DMA kernels, 2 / 10 the 128 x 128 /
+ * 256 x 128 split-while-staging SPLIT kernels (bf16 pipe, six piece products), 9 bf16 inputs; 0 before the first launch.
+ * A thread-local read-back: with the error string of sk_last_error() the library's only mutable state that is not a caller's
+ * buffer (SURVEY 8b's rule has these two exceptions, both thread-local and neither read by any kernel or launch decision). */
 int sk_gemm_last_kernel(void);
 size_t sk_gemm_streamk_workspace_bytes(void);
 /* Zero the ticket counters at the head of a split-K workspace (once, before its first use; a buffer that was allocated
@@ -216,10 +233,13 @@ int sk_hprev_rows(const float* y, int ldy, const float* h0, const int32_t* offs,
  * bit 28 (fp32 forward, H <= 896): the product h W_hh^T by the EXACT three-way bf16 split of both fp32
  * operands on the bf16 matrix pipe -- x = hi + mid + lo with three bf16 pieces (24 significand bits = 3 x 8); of the nine piece
  * products per element pair (each exact in fp32) the six of relative size >= 2^-16 are added into fp32 accumulators by
- * v_mfma_f32_16x16x32_bf16, the three of size <= 2^-24 -- at or below half an ulp of the fp32 product -- are not formed: an
- * fp32 product in another summation order (error against fp64 not above the fp32-MFMA kernel's, results within 2.2e-6 of it,
- * no operand perturbed), 96 instead of 256 matrix-pipe cycles per 32 k.  W_hh is split once per launch, h by its producer
- * (three bf16 images, flags hand-off).  The engine ships it for the fp32 forward recurrence (bench.py's config.numerics
+ * v_mfma_f32_16x16x32_bf16, the three of size <= 2^-24 -- together at most 2^-23 of |w||h|, see sk_gemm_f32_splitk variant 0 --
+ * are not formed: an fp32 product in another summation order (error against fp64 not above the fp32-MFMA kernel's, results
+ * within 2.2e-6 of it, no operand perturbed), 96 instead of 256 matrix-pipe cycles per 32 k.  W_hh is split once per launch,
+ * h by its producer (three bf16 images, flags hand-off).  Sign phases (r06): the two K halves of a workgroup accumulate with
+ * opposite signs (one on -W_hh), so that the bf16 MFMA's truncation towards minus infinity pulls one partial sum down and the
+ * other up -- the cell state integrates over the sequence what is left of it (tests/test_gpu_signed_error.py: 400 steps
+ * against an fp64 recurrence).  The engine ships it for the fp32 forward recurrence (bench.py's config.numerics
  * names it);
  * bit 29 (fp32 forward; not together with bit 28): "the data is the flag" -- every exchanged h word carries the step's epoch
  * in its two low mantissa bits, producers publish without drain / barrier / flag, consumers hold back, pull, check every word

@@ -17,6 +17,8 @@ extern "C" int sk_version(void) { return SK_VERSION; }
 
 extern "C" const char* sk_last_error(void) { return g_err; }
 
+extern "C" unsigned sk_build_flags(void) { return sk_gemm_build_flags() | sk_lstm_build_flags(); }
+
 extern "C" int sk_device_info(int* num_cu, int* lds_bytes) {
   int dev = 0;
   hipDeviceProp_t p;

@@ -8,7 +8,7 @@
 //   * fp32 MFMA (v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain): gemm_f32_kernel (register-staged, any
 //     alignment), _dma / _dma256 / _streamk (LDS-DMA staging);
 //   * SPLIT products on the bf16 matrix pipe (r05, the default wherever operands are aligned): both operands cut exactly into
-//     three bf16 pieces, six exact piece products per element pair -- gemm_f32_kernel_split3, gemm_f32_kernel_streamk<.., S6>;
+//     three bf16 pieces, six exact piece products per element pair -- gemm_f32_kernel_split3, gemm_f32_kernel_planes;
 //     the bf16 pipe is 16x the fp32 one, so six products still leave 2.7x its rate.
 // The fp32-MFMA kernel's design notes follow.
 //
@@ -50,6 +50,7 @@ struct GemmArgs {
                        // themselves (finish_splitk); nullptr = the separate splitk_reduce_kernel does
   int64_t sA, sB, sC, sbias;
   int sk_tiles, sk_full;  // stream-K kernel: tiles of the product, data-parallel rounds before the stream-K region
+  int flip_q;             // split-product kernels: quarter period of the sign phases in K steps of BK (0: none), see SignPhase
 };
 constexpr size_t COUNTER_BYTES = 65536;  // head of a split-K workspace: 16384 counters
 
@@ -579,8 +580,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_dma256(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// The three-way bf16 split of an fp32 operand (used by the S6 form of the stream-K kernel and by gemm_f32_kernel_split3 below;
-// the arithmetic is described there): x = hi + mid + lo exactly, three bf16 pieces.
+// The three-way bf16 split of an fp32 operand (used by gemm_f32_kernel_split3 and gemm_f32_kernel_planes below; the arithmetic is
+// described there): x = hi + mid + lo exactly, three bf16 pieces.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Split3 {
@@ -622,8 +623,8 @@ __device__ __forceinline__ Split3 split3(const float (&v)[8]) {
   return o;
 }
 
-__device__ __forceinline__ void mma9(f32x16& acc, const Split3& a, const Split3& b) {
-  // small terms first (it is one fp32 accumulator either way); SK_SPLIT_NINE: all nine piece products (diagnostic build)
+__device__ __forceinline__ void mma6(f32x16& acc, const Split3& a, const Split3& b) {
+  // the SIX piece products, small terms first (it is one fp32 accumulator either way); SK_SPLIT_NINE: all nine (diagnostic build)
 #ifdef SK_SPLIT_NINE
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.lo, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.mid, acc, 0, 0, 0);
@@ -636,6 +637,39 @@ __device__ __forceinline__ void mma9(f32x16& acc, const Split3& a, const Split3&
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.mid, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, acc, 0, 0, 0);
 }
+
+// Sign phases of the split-product kernels.  The bf16 MFMA does not round the alignment of its addends to nearest: it TRUNCATES
+// TOWARDS MINUS INFINITY (measured, profiles/r05_planes_flip.txt: on all-positive operands the fp32-MFMA kernels' mean signed error
+// is 1e-10 of the result, a split kernel's -3.7e-8 at K = 1792, -1.5e-7 at K = 7168, -2.7e-7 at K = 12800) -- a DC offset, the same
+// in every element, far below the kernel's rel-L2 error against fp64 but COHERENT: whatever integrates a product's result over
+// many elements or steps (the recurrence below a data gradient, r05: layer-0 / 1 gradients 5.9e-6 from a float64 step instead of
+// 6.2e-7) sees it.  Cure without a second accumulator: the accumulators hold +sum in some stretches of K and -sum in others (at a
+// boundary acc = -acc, and within a negative stretch the B operand's values are negated before they are split: the pieces of -x
+// are the negated pieces of x, rounding to nearest is symmetric), so that truncation pulls the sum down in one and up in the next.
+// Stretches of q K steps, signs + - - + + - - + ...: over a period of 4 q the offsets cancel both for a sum of constant size and
+// for one that grows linearly with k (all-positive operands), and the sign changes at every second boundary only.  q (GemmArgs::
+// flip_q, chosen by the launcher from the WHOLE K: periods of about 128 steps, a whole number of them) is counted in GLOBAL K
+// steps, so the slices of a split-K product continue one pattern.  r05 had this in the N/N planes kernel only (+ - + -, 32 steps);
+// r06: every split-product kernel and form (tests/test_gpu_signed_error.py pins the mean signed error of each).
+struct SignPhase {
+  int q, left, p;
+  unsigned mask;  // 0 or the sign bit: the sign of the stretch the tracked K step lies in
+  __device__ __forceinline__ void init(int q_, int kstep0) {
+    q = q_; p = 0; left = 0x7fffffff; mask = 0u;
+    if (q > 0) {
+      p = kstep0 / q;
+      left = q - (kstep0 - p * q);
+      mask = ((p + 1) & 2) ? 0x80000000u : 0u;
+    }
+  }
+  __device__ __forceinline__ void advance() {
+    if (--left == 0) {
+      left = q;
+      ++p;
+      mask = ((p + 1) & 2) ? 0x80000000u : 0u;
+    }
+  }
+};
 
 
 // ------------------------------------------------------------------------------------------------------
@@ -650,13 +684,9 @@ __device__ __forceinline__ void mma9(f32x16& acc, const Split3& a, const Split3&
 // the tile's pieces in workgroup order (deterministic), applies bias / accumulate / act and stores: nobody ever waits for
 // anybody, so the grid need not be co-resident.  The K steps of consecutive segments form ONE software pipeline: the
 // next segment's first two stages are in flight while a tile is stored.
-// S6 (variant 7): the same kernel with its products formed on the bf16 matrix pipe by the three-way split of both operands, six
-// piece products per element pair (gemm_f32_kernel_split3 below describes the arithmetic).  The fp32 images in LDS and the
-// fragment reads are the fp32 form's: a lane's two half-step reads of a fragment are 8 values of its row, k = 4 (kh + 2 cp) + i,
-// and since A and B fragments use the same k <-> slot map, they are a valid operand pair of v_mfma_f32_32x32x16_bf16 as they
-// are.  Per K step and wave: 6 fragments split once (216 VALU instructions) feed 48 MFMAs of 32 cycles -- each split fragment
-// is used by 2 (B) or 4 (A) products, twice the reuse of the 128 x 128 kernel's 64 x 64 wave tiles.
-template <bool TA, bool TB, bool S6 = false>
+// (r05 also carried a split-product form of this kernel, variant 7; since the planes kernel it served no launch of any
+// configuration and was retired in r06.)
+template <bool TA, bool TB>
 __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
   constexpr int BMW = 256, BNW = 256;
   constexpr int TILE = BMW * BK * 4, STAGE = 2 * TILE;
@@ -771,27 +801,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
     fetch((cur + 2) % NST);
     const char* ai = lds[cur];
     const char* bi = lds[cur] + TILE;
-    if constexpr (S6) {
-      Split3 sa[2], sb[4];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float lo4[4], hi4[4];
-        frag_load_w<TA, BMW>(ai, fa[i], 0, lo4);
-        frag_load_w<TA, BMW>(ai, fa[i], 1, hi4);
-        const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-        sa[i] = split3(v);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float lo4[4], hi4[4];
-        frag_load_w<!TB, BNW>(bi, fb[j], 0, lo4);
-        frag_load_w<!TB, BNW>(bi, fb[j], 1, hi4);
-        const float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-        sb[j] = split3(v);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) mma9(acc[i][j], sa[i], sb[j]);
-      }
-    } else {
+    {
 #pragma unroll
       for (int cp = 0; cp < 2; ++cp) {
         float a[2][4], bb[4][4];
@@ -986,17 +996,14 @@ __global__ __launch_bounds__(256, SK_SPLIT_OCC) void gemm_f32_kernel_split3(Gemm
   for (int i = 0; i < NST - 1; ++i)
     if (i < nk) stage(i);
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // step kt has landed when only the DMAs of the (up to NST - 2) stages issued after it may still fly: 4 instructions each
-    const int later = min(NST - 2, nk - 1 - kt);
-    if (later >= 2)
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (later == 1)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // everybody's pieces of step kt have landed; all reads of the buffer refilled next are done
-    if (kt + NST - 1 < nk) stage((cur + NST - 1) % NST);
+  // sign phases (SignPhase above): this slice's steps are the global K steps kbeg / BK ...; `held` = the sign the accumulators carry
+  SignPhase ph;
+  ph.init(g.flip_q, kbeg / BK);
+  unsigned held = 0u;
+  // One K step; sg = -1 in a negative stretch: the B fragments' values are multiplied by it before they are split (exact; eight
+  // v_pk_mul_f32 per wave and step beside the ~150 of the splits.  Two copies of the body, one with the negation folded into the
+  // split's source modifiers, were tried first: 180 instead of 122 VGPRs -- the kernel no longer fits beside a recurrence).
+  auto kstep = [&](const float sg) {
     const char* ai = lds[cur];
     const char* bi = lds[cur] + TILE;
     float va0[8], va1[8], vb0[8], vb1[8];
@@ -1004,6 +1011,13 @@ __global__ __launch_bounds__(256, SK_SPLIT_OCC) void gemm_f32_kernel_split3(Gemm
     frag8_load<!TB>(bi, wn * 64, lane, vb0);
     frag8_load<TA>(ai, wm * 64 + 32, lane, va1);
     frag8_load<!TB>(bi, wn * 64 + 32, lane, vb1);
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const f32x2 s2 = {sg, sg};
+      const f32x2 p0 = (f32x2){vb0[j], vb0[j + 1]} * s2, p1 = (f32x2){vb1[j], vb1[j + 1]} * s2;
+      vb0[j] = p0[0]; vb0[j + 1] = p0[1];
+      vb1[j] = p1[0]; vb1[j + 1] = p1[1];
+    }
 #ifdef SK_SPLIT_FREE_TN  // TIMING-ONLY diagnostic (wrong, finite numerics): the T/N form (weight gradients) finds its pieces for free
     auto sp = [&](const float (&v)[8]) {
       if constexpr (TA && !TB) {
@@ -1021,14 +1035,39 @@ __global__ __launch_bounds__(256, SK_SPLIT_OCC) void gemm_f32_kernel_split3(Gemm
     auto sp = [&](const float (&v)[8]) { return split3(v); };
 #endif
     const Split3 a0 = sp(va0), b0 = sp(vb0);
-    mma9(acc[0][0], a0, b0);
+    mma6(acc[0][0], a0, b0);
     const Split3 a1 = sp(va1);
-    mma9(acc[1][0], a1, b0);
+    mma6(acc[1][0], a1, b0);
     const Split3 b1 = sp(vb1);
-    mma9(acc[0][1], a0, b1);
-    mma9(acc[1][1], a1, b1);
+    mma6(acc[0][1], a0, b1);
+    mma6(acc[1][1], a1, b1);
+  };
+  auto negate_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = -acc[i][j];
+  };
+  for (int kt = 0; kt < nk; ++kt) {
+    // step kt has landed when only the DMAs of the (up to NST - 2) stages issued after it may still fly: 4 instructions each
+    const int later = min(NST - 2, nk - 1 - kt);
+    if (later >= 2)
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // everybody's pieces of step kt have landed; all reads of the buffer refilled next are done
+    if (kt + NST - 1 < nk) stage((cur + NST - 1) % NST);
+    if (ph.mask != held) {  // a stretch of the other sign begins: the accumulators change sign with the products
+      negate_acc();
+      held = ph.mask;
+    }
+    kstep(held ? -1.0f : 1.0f);
+    ph.advance();
     cur = (cur + 1) % NST;
   }
+  if (held) negate_acc();  // the last stretch held -sum
   store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
   if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
 }
@@ -1071,13 +1110,13 @@ __device__ __forceinline__ Pl4 split4(const float4& x4) {
 // stages 4 consecutive DIMS of one k row) and the fragments are gathered by ds_read_b64_tr_b16 (see kmaj_frag below): within a k
 // row the 32-byte chunk c (16 dims) sits at chunk c ^ 2 (k & 3), so that the 8 segments a half-wave reads in one instruction (two
 // adjacent 16-dim blocks x 4 k rows) fall on 8 different 32-byte bank groups.
-#ifndef SK_PLANES_FLIP
-#define SK_PLANES_FLIP 32  // phase length in K steps of the N/N instantiation (0: none -- `make gemm_variant DEFS=-DSK_PLANES_FLIP=0`)
+#ifndef SK_SPLIT_FLIP
+#define SK_SPLIT_FLIP 1  // sign phases of the split-product kernels (SignPhase above; 0: none -- `make gemm_variant DEFS=-DSK_SPLIT_FLIP=0`)
 #endif
 #ifndef SK_PLANES_SCHED
 #define SK_PLANES_SCHED 4  // VALU instructions stated behind every MFMA of a K step (0: the scheduler's own choice)
 #endif
-template <bool AKM, bool BKM, int FL = 0>
+template <bool AKM, bool BKM>
 __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
   constexpr int BMW = 256, BNW = 128, NJ = 2;
   constexpr int NL = 3;                    // float4 per thread and K step: 2 of the A tile, 1 of the B tile
@@ -1154,37 +1193,28 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
     *reinterpret_cast<u32x2_*>(base + plane + off) = (u32x2_){p.m[0], p.m[1]};
     *reinterpret_cast<u32x2_*>(base + 2 * plane + off) = (u32x2_){p.l[0], p.l[1]};
   };
-  // sm: the sign mask (0 or the sign bit) of the step the pieces belong to (see FL below): applied to the B tile's four values
+  // sm: the sign mask (0 or the sign bit) of the step the pieces belong to (SignPhase above): applied to the B tile's four values
   // before they are split -- the pieces of -x are the negated pieces of x (rounding to nearest is symmetric)
   auto put_piece = [&](int buf, int j, const float4* ld, unsigned sm) {  // j = 0, 1: the A tile's two pieces; 2: the B tile's
     if (j < 2) {
       put(lds[buf], PLANE_A, wo[j], split4(ld[j]));
     } else {
       float4 b = ld[2];
-      if (FL > 0) {
-        b.x = __uint_as_float(__float_as_uint(b.x) ^ sm);
-        b.y = __uint_as_float(__float_as_uint(b.y) ^ sm);
-        b.z = __uint_as_float(__float_as_uint(b.z) ^ sm);
-        b.w = __uint_as_float(__float_as_uint(b.w) ^ sm);
-      }
+      b.x = __uint_as_float(__float_as_uint(b.x) ^ sm);
+      b.y = __uint_as_float(__float_as_uint(b.y) ^ sm);
+      b.z = __uint_as_float(__float_as_uint(b.z) ^ sm);
+      b.w = __uint_as_float(__float_as_uint(b.w) ^ sm);
       put(lds[buf] + OPER_A, PLANE_B, wo[2], split4(b));
     }
   };
-  // FL > 0 (the data-gradient form N/N, see sk_gemm's launcher): sign-alternating accumulation.  The bf16 MFMA does not round
-  // the alignment of its addends to nearest: it TRUNCATES TOWARDS MINUS INFINITY (measured, profiles/r05_planes_flip.txt: on
-  // all-positive operands the fp32-MFMA kernels' mean signed error is 1e-10 of the result, this kernel's -3.7e-8 at K = 1792,
-  // -1.5e-7 at K = 7168, -2.7e-7 at K = 12800 -- a DC offset, the same in every element, far below the kernel's own rel-L2 error
-  // against fp64 (7e-7, SMALLER than the fp32-MFMA kernels' 1.2e-6) but COHERENT: the backward recurrence of the layer below
-  // integrates the offset of the top layer's data gradient (K = 7168) over 400 time steps, which left that layer's parameter
-  // gradients 8 x further from a float64 step than with fp32-MFMA products: 5.9e-6 against 6e-7, gate 2e-4).  Cure without a
-  // second accumulator: every FL K steps the accumulators change sign (acc = -acc) and the B values are negated while they are
-  // staged, so that the registers hold +sum in even phases and -sum in odd ones: truncation pulls the sum down, then up -- the
-  // offsets of neighbouring phases cancel (all-positive bias at K = 7168: -1.5e-7 -> +1.6e-9; layer-0 / 1 gradients of the
-  // full-size step against float64: 5.9e-6 -> 6.2e-7 = the fp32-MFMA arrangement's).  Cost: 4 v_xor per thread and K step + 64
-  // per phase change -- nothing once the loop's interleave is stated (SK_PLANES_SCHED below; left to itself the compiler
-  // scheduled THIS instantiation's loop 6 % slower than the unflipped one).  Only where it matters: the forward projections
-  // (K <= 1792) and the weight gradients (integrated by nothing) measured no effect of their offsets.
-  auto mask_of = [&](int kt) -> unsigned { return FL > 0 ? ((unsigned)((kt / (FL > 0 ? FL : 1)) & 1) << 31) : 0u; };
+  // Sign phases (SignPhase above; r05: the N/N form only, r06: all three).  ph_cur follows the step whose products are formed,
+  // ph_nx the step being staged (one ahead); `held` is the sign the accumulators carry.  Cost: 4 v_xor per thread and K step + 64
+  // at every second stretch boundary -- nothing once the loop's interleave is stated (SK_PLANES_SCHED below; left to itself the
+  // compiler scheduled the r05 flipped instantiation's loop 6 % slower than the plain one).
+  SignPhase ph_cur, ph_nx;
+  ph_cur.init(g.flip_q, 0);
+  ph_nx.init(g.flip_q, 1);
+  unsigned held = 0u;
   // ---- fragments of 32 dims starting at d0: lane (l31 = dim, kh = k half)
   const int l31 = lane & 31, kh = lane >> 5;
   auto dm_frag = [&](int row) { return row * 32 + ((kh ^ ((row >> 3) & 1)) << 4); };
@@ -1229,13 +1259,17 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
   auto step = [&](int buf, int kt, const float4* nx, auto store) {
     const char* ai = lds[buf];
     const char* bi = lds[buf] + OPER_A;
-    if (FL > 0 && kt > 0 && kt % (FL > 0 ? FL : 1) == 0) {  // a new phase: the accumulators change sign with the products
+    (void)kt;
+    if (ph_cur.mask != held) {  // a stretch of the other sign begins: the accumulators change sign with the products
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = -acc[i][j];
+      held = ph_cur.mask;
     }
-    const unsigned sg_next = mask_of(kt + 1);
+    const unsigned sg_next = ph_nx.mask;
+    ph_cur.advance();
+    ph_nx.advance();
     Split3 sa[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) sa[i] = frag(ai, PLANE_A, fa[i], AKM, 2 * BMW);
@@ -1243,7 +1277,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
     for (int j = 0; j < NJ; ++j) {
       const Split3 sb = frag(bi, PLANE_B, fb[j], BKM, 2 * BNW);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) mma9(acc[i][j], sa[i], sb);
+      for (int i = 0; i < 2; ++i) mma6(acc[i][j], sa[i], sb);
       if constexpr (decltype(store)::value) {  // three pieces over two groups
         put_piece(buf ^ 1, j, nx, sg_next);
         if (j == 1) put_piece(buf ^ 1, 2, nx, sg_next);
@@ -1299,7 +1333,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
       __syncthreads();
       cur ^= 1;
     }
-    if (mask_of(nk - 1) != 0u) {  // the last phase held -sum
+    if (held) {  // the last stretch held -sum
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -2114,7 +2148,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
                 int ldb, int ldc, int transA, int transB, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                 int64_t sC, int64_t sbias, int splitk, void* ws, int variant, sk_stream_t stream) {
   SK_CHECK_ARG(A && B && C, "sk_gemm: null pointer");
-  SK_CHECK_ARG(variant >= 0 && variant <= 9 && variant != 5, "sk_gemm: unknown variant %d", variant);
+  SK_CHECK_ARG(variant >= 0 && variant <= 9 && variant != 5 && variant != 7, "sk_gemm: unknown variant %d (5 and 7 are retired)", variant);
   SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm: bad splitk %d / missing workspace", splitk);
   SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
   SK_CHECK_ARG(lda >= (transA ? M : K) && ldb >= (transB ? K : N) && ldc >= N, "sk_gemm: leading dimension too small");
@@ -2128,48 +2162,46 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.vecB = ((uintptr_t)B % 16 == 0) && (ldb % 4 == 0) && (sB % 4 == 0);
   g.tilesN = (int)sk_cdiv(N, BN);
   g.sA = sA; g.sB = sB; g.sC = sC; g.sbias = sbias;
-  g.sk_tiles = 0; g.sk_full = 0;
+  g.sk_tiles = 0; g.sk_full = 0; g.flip_q = 0;
   g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), bk) * bk);
   splitk = (int)sk_cdiv(K, g.kchunk);  // slices that actually hold work
   g.splitk = splitk;
   // ---- which kernel.  fp32 products run by default (variant 0) on the bf16 matrix pipe by the three-way split of both operands
-  // with six piece products (gemm_f32_kernel_split3 / the S6 form of the stream-K kernel) wherever the LDS-DMA conditions
-  // hold: 160-173 TFLOP/s fp32-equivalent on the training step's large products against 124-135 of the fp32-MFMA kernels
-  // (stand-alone, one MI355X), 30.1 vs 34.7 ms per training step.  Variant 8 = the r04 choice among the fp32-MFMA kernels
-  // (SEPKERN_GEMM_SPLIT=0 makes variant 0 that); operands with unaligned rows or K % 16 != 0 take the fp32-MFMA kernels always.
+  // with six piece products (gemm_f32_kernel_planes / gemm_f32_kernel_split3) wherever the LDS-DMA conditions hold: 160-212 TFLOP/s
+  // fp32-equivalent on the training step's large products against 124-135 of the fp32-MFMA kernels (stand-alone, one MI355X).
+  // Variant 8 = the choice among the fp32-MFMA kernels (the reference's literal arithmetic; SEPKERN_GEMM_SPLIT=0 makes variant 0
+  // that); operands with unaligned rows or K % 16 != 0 take the fp32-MFMA kernels always.
   static const bool split_on = [] { const char* e = getenv("SEPKERN_GEMM_SPLIT"); return !(e && e[0] == '0'); }();
-  // the stream-K form of the split kernel: 0 never, 1 (default) the large unsplit N/N and T/N products with a long K (data
-  // gradients: 172.8 vs 164.0 TFLOP/s, the unsplit T/N weight gradient 172.0 vs 141.3), 2 also the N/T projections
-  static const int split_sk = [] { const char* e = getenv("SEPKERN_GEMM_SPLIT_SK"); return e ? atoi(e) : 1; }();
   if (variant == 0 && !split_on) variant = 8;
-  bool split = !bf16 && (variant == 0 || variant == 2 || variant == 7 || variant == 9) && dma_ok(g, transA, transB);
-  // split ONCE per element while staging (gemm_f32_kernel_planes_nt): unsplit, unbatched N/T products
-  // For unsplit, unbatched products with enough 256 x 128 tiles to fill the chip it is what variant 0 takes (SEPKERN_GEMM_PLANES=0:
-  // never): 180 / 193 / 179 TFLOP/s on the projection / data-gradient / unsplit weight-gradient shapes against 165 / 179 / 169
-  // of the stream-K split kernel and 163 / 165 of the 128 x 128 one; 158 vs 100-124 on the N = 514 Linear product.  It needs 72 KB of
-  // LDS and 200 VGPRs: callers that run a product BESIDE a persistent recurrence pass variant 2 (sepkern/engine.py).
+  const bool split = !bf16 && (variant == 0 || variant == 2 || variant == 9) && dma_ok(g, transA, transB);
+  // split ONCE per element while staging (gemm_f32_kernel_planes): unsplit, unbatched products.  With enough 256 x 128 tiles to
+  // fill the chip it is what variant 0 takes (SEPKERN_GEMM_PLANES=0: never): 186-212 TFLOP/s on the projection / data-gradient /
+  // unsplit weight-gradient shapes against 160-168 of the 128 x 128 kernel; 158 vs 100-124 on the N = 514 Linear product.  It
+  // needs 72 KB of LDS and 200 VGPRs: callers that run a product BESIDE a persistent recurrence pass variant 2 (sepkern/engine.py).
   static const bool planes_on = [] { const char* e = getenv("SEPKERN_GEMM_PLANES"); return !(e && e[0] == '0'); }();
   const bool planes = split && splitk == 1 && batch == 1 && M >= 256 && N >= 128 &&
                       (variant == 9 || (variant == 0 && planes_on && sk_cdiv(M, 256) * sk_cdiv(N, 128) >= 192));
-  // The data-gradient form (N/N) with a long K is where a split product's truncation offset matters (a recurrence integrates
-  // it: see FL in gemm_f32_kernel_planes).  The planes kernel cancels it with sign phases; the other split kernels do not, so
-  // under the library's own choice (variant 0) such a product that cannot take the planes kernel -- too few tiles, split-K,
-  // batched -- runs on the fp32-MFMA kernels, whose accumulation rounds to nearest.  (Small shapes: not the training step's.)
-  if (variant == 0 && split && !planes && !transA && !transB && K >= 1024) split = false;
+  // Sign phases of the split products (SignPhase): stretches of q K steps, signs + - - +, a whole number of periods of about
+  // 128 steps over the WHOLE K (the slices of a split-K product continue one pattern); products shorter than 16 steps: none.
+  if (split && SK_SPLIT_FLIP) {
+    const int nks = K / BK;
+    if (nks >= 16) {
+      const int periods = nks >= 192 ? (nks + 64) / 128 : 1;
+      g.flip_q = (nks + 4 * periods - 1) / (4 * periods);
+    }
+  }
   const bool mfma_choose = variant == 8 || (variant == 0 && !split);  // the r04 policy among the fp32-MFMA kernels
   // 256 x 128 block tiles, 8 waves (fp32 MFMA): variant 4, or chosen for the large unsplit N/T and N/N products -- measured
   // +2 % / +5 % on them stand-alone.  SEPKERN_GEMM_WIDE=0 (diagnostics): never chosen.
   static const bool wide_ok = [] { const char* e = getenv("SEPKERN_GEMM_WIDE"); return !(e && e[0] == '0'); }();
   const bool wide = !bf16 && !split && M >= 256 && dma_ok(g, transA, transB) &&
                     (variant == 4 || variant == 6 || (mfma_choose && wide_ok && !transA && M >= 4096 && N >= 1024 && splitk == 1));
-  // 256 x 256 tiles, persistent, with a stream-K cut of the last partial round: variant 6 (fp32 MFMA) / 7 (split products), or
-  // chosen for large unsplit products when the caller passes the workspace of sk_gemm_streamk_workspace_bytes().
+  // 256 x 256 tiles, persistent, with a stream-K cut of the last partial round (fp32 MFMA): variant 6, or chosen under 8 for
+  // large unsplit products when the caller passes the workspace of sk_gemm_streamk_workspace_bytes().
   // SEPKERN_GEMM_STREAMK=0 (diagnostics): never chosen.
   static const bool streamk_ok = [] { const char* e = getenv("SEPKERN_GEMM_STREAMK"); return !(e && e[0] == '0'); }();
   const bool sk_shape = ws && batch == 1 && M >= 256 && N >= 256 && splitk == 1 && dma_ok(g, transA, transB);
-  const bool sk_split = split && sk_shape && (variant == 7 || (variant == 0 && streamk_ok && M >= 4096 && N >= 1024 &&
-                                                               ((split_sk >= 1 && !transB && K >= 4096) || (split_sk >= 2 && !transA))));
-  bool streamk = !bf16 && !planes && sk_shape && (sk_split || (!split && (variant == 6 || (mfma_choose && streamk_ok && !transA && M >= 4096 && N >= 1024))));
+  bool streamk = !bf16 && !split && sk_shape && (variant == 6 || (mfma_choose && streamk_ok && !transA && M >= 4096 && N >= 1024));
   if (streamk) {
     const int P = streamk_wgs();
     const int64_t nt = sk_cdiv(M, 256) * sk_cdiv(N, 256), nk = K / BK;
@@ -2189,7 +2221,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   g.counters = inkernel ? (unsigned*)ws : nullptr;
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
-  t_last_kernel = bf16 ? 9 : planes ? 10 : streamk ? (split ? 7 : 6) : wide ? 4 : split ? 2 : (variant != 1 && dma_ok(g, transA, transB, mfma_choose)) ? 3 : 1;
+  t_last_kernel = bf16 ? 9 : planes ? 10 : streamk ? 6 : wide ? 4 : split ? 2 : (variant != 1 && dma_ok(g, transA, transB, mfma_choose)) ? 3 : 1;
   if (bf16) {
     if (!transA && !transB)
       hipLaunchKernelGGL((bf::gemm_bf16_kernel<false, false>), grid, dim3(256), 0, st, g);
@@ -2202,14 +2234,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   } else if (streamk) {
     g.counters = (unsigned*)ws;
     const dim3 pgrid((unsigned)streamk_wgs());
-    if (split) {
-      if (!transA && !transB)
-        hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, false, true>), pgrid, dim3(512), 0, st, g);
-      else if (!transA && transB)
-        hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, true, true>), pgrid, dim3(512), 0, st, g);
-      else
-        hipLaunchKernelGGL((gemm_f32_kernel_streamk<true, false, true>), pgrid, dim3(512), 0, st, g);
-    } else if (!transA && !transB)
+    if (!transA && !transB)
       hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, false>), pgrid, dim3(512), 0, st, g);
     else if (!transA && transB)
       hipLaunchKernelGGL((gemm_f32_kernel_streamk<false, true>), pgrid, dim3(512), 0, st, g);
@@ -2226,7 +2251,7 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
     if (!transA && transB)
       hipLaunchKernelGGL((gemm_f32_kernel_planes<false, false>), grid, dim3(512), 0, st, g);
     else if (!transA && !transB)
-      hipLaunchKernelGGL((gemm_f32_kernel_planes<false, true, SK_PLANES_FLIP>), grid, dim3(512), 0, st, g);  // (data gradients)
+      hipLaunchKernelGGL((gemm_f32_kernel_planes<false, true>), grid, dim3(512), 0, st, g);  // (data gradients)
     else
       hipLaunchKernelGGL((gemm_f32_kernel_planes<true, true>), grid, dim3(512), 0, st, g);
   } else if (split) {
@@ -2389,3 +2414,17 @@ extern "C" int sk_cast_bf16_rows(const float* src, int R, int C, int ld_src, voi
 }
 
 extern "C" int sk_gemm_last_kernel(void) { return t_last_kernel; }
+
+// The numerics- or timing-changing macros this translation unit was built with (sk_build_flags, include/sepkern.h)
+unsigned sk_gemm_build_flags() {
+  unsigned f = 0;
+#if defined(SK_SPLIT_FREE) || defined(SK_SPLIT_FREE_TN) || defined(SK_ABL_HALFDMA) || defined(SK_ABL_NOBAR) || defined(SK_ABL_NODMA)
+  f |= SK_BUILD_TIMING_ONLY;
+#endif
+#ifdef SK_SPLIT_NINE
+  f |= SK_BUILD_ARITH;
+#endif
+  if (SK_SPLIT_FLIP != 1) f |= SK_BUILD_ARITH;
+  if (SK_SPLIT_NST != 2 || SK_SPLIT_OCC != 2 || SK_PLANES_SCHED != 4) f |= SK_BUILD_TUNING;
+  return f;
+}

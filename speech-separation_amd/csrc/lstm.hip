@@ -121,6 +121,9 @@ constexpr long long SPIN_TICKS = 200000000LL;  // 2 s of the 100 MHz wall clock
 #ifndef SK_POLL_DELAY
 #define SK_POLL_DELAY 0
 #endif
+#ifndef SK_FWD_S3_FLIP
+#define SK_FWD_S3_FLIP 1  // split forward recurrence: the two K halves accumulate with opposite signs (0: both positive, the r05 form)
+#endif
 constexpr int NTHREADS = 512;
 constexpr int NREP = 8;  // flag replicas (one per XCD label) when replication is on
 constexpr int FSPREAD = 32;  // option: one flag per 128-byte line (stride in dwords) instead of 32 flags per line
@@ -206,6 +209,7 @@ struct BwdArgs {
   int map, nby, poll_delay;
   __bf16* dgx_bf;  // optional bf16 twin of dgx (rows (t, b), ld_bf elements apart), written with the fp32 values; may be NULL
   int ld_bf;
+  int fast;  // mode bit 29: read by the timing-only build -DSK_BWD_BOUND38 alone
 };
 
 // Flag replication (opt bit 1): every producer raises its flag in NREP copies with ONE store instruction (NREP lanes,
@@ -421,10 +425,15 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
         if (rowok && k < H) v0 = *reinterpret_cast<const float4*>(wrow + k);
         if (rowok && k + 4 < H) v1 = *reinterpret_cast<const float4*>(wrow + k + 4);
-        if (S3)
+        if (S3) {
+          if (SK_FWD_S3_FLIP && kh == 1) {  // sign phases (see the reduce below): this K half holds -W, its partial sum is -S
+            v0 = make_float4(-v0.x, -v0.y, -v0.z, -v0.w);
+            v1 = make_float4(-v1.x, -v1.y, -v1.z, -v1.w);
+          }
           split3x8(v0, v1, w1[q], w2[q], w3[q]);
-        else
+        } else {
           wb[q] = pack8(v0, v1);
+        }
       } else {
         const int k = 16 * (kh * NQ + q) + 4 * kq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -728,7 +737,15 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
       float y_out = 0.f, c_out = 0.f;
       bool valid = false;
       if (owner) {
-        acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
+        // S3, sign phases: the bf16 MFMA TRUNCATES the alignment of its addends towards minus infinity, so a partial sum formed on
+        // it sits a little below the exact one -- the same way in every cell, every step, and the cell state integrates it over
+        // the sequence.  The K half of the kh == 1 waves therefore runs on -W (negated when the slice was split: the pieces of -x
+        // are the negated pieces of x) and accumulates -S1; the owner forms S0 - (-S1): one half's truncation pulls the sum down,
+        // the other's up, by amounts of the same expectation.  No instruction, no register.  (tests/test_gpu_signed_error.py)
+        if (S3 && SK_FWD_S3_FLIP)
+          acc -= *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
+        else
+          acc += *reinterpret_cast<const f32x4*>(&red[mt][lane][0]);
         // 5. cell update: D row = 4*(lane>>4) + reg -> this lane holds gates i,f,g,o of (unit, b)
         float c_reg = st_c[gi][oi], h_reg = st_h[gi][oi];
         const float gi_ = fast_sigmoid(acc[0] + gxv.x);
@@ -872,6 +889,21 @@ __device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* 
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
   const float* src = ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4;
+#ifdef SK_BWD_BOUND38
+  // TIMING-ONLY diagnostic (-DSK_BWD_BOUND38, never shipped, WRONG numerics): launches that pass mode bit 29 issue three of every
+  // eight MFMAs of the product -- the matrix-pipe time six bf16 piece products would take (96 instead of 256 cycles per 32 k'),
+  // with the pieces for free: an upper bound for a split-product form of this kernel (profiles/r06_bwd_split_top_layer.txt)
+  if (!BF && tail) {
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      const float4 db = *reinterpret_cast<const float4*>(src + j * 256);
+      const int q = SBI * C::SB + j;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 0], db.x, acc0, 0, 0, 0);
+      if (!(j & 1)) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 1], db.y, acc1, 0, 0, 0);
+    }
+    return;
+  }
+#endif
 #if SK_BWD_RING > 0
   if constexpr (!BF && n > 0 && KS <= 56) {  // (KS = 64: 4 more registers would pass the 192 this kernel must stay under)
     // fp32: the fragment read of chunk j + 1 is issued before the four MFMAs of chunk j (the compiler's order: read, wait, four
@@ -1126,6 +1158,8 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
         SK_STAMP(0);
 #ifdef SK_TAIL_HALF
         dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane, a.offs && B > 16 && s >= a.lens[16]);
+#elif defined(SK_BWD_BOUND38)
+        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane, a.fast != 0);
 #else
         dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
 #endif
@@ -1358,6 +1392,28 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
 
 }  // namespace
 
+// The numerics- or timing-changing macros this translation unit was built with (sk_build_flags, include/sepkern.h)
+unsigned sk_lstm_build_flags() {
+  unsigned f = 0;
+#ifdef SK_TAIL_HALF
+  f |= SK_BUILD_TIMING_ONLY;
+#endif
+#ifdef SK_BWD_BOUND38
+  f |= SK_BUILD_TIMING_ONLY;
+#endif
+#ifdef SK_LSTM_STAMPS
+  f |= SK_BUILD_STAMPS;
+#endif
+#ifdef SK_DMA_BUILTIN
+  f |= SK_BUILD_TUNING;
+#endif
+  if (SK_BF_NSB != 4 || SK_BF_DEPTH != 2 || SK_F32_NSB != 8 || SK_F32_DEPTH != 3 || SK_POLL_SLEEP != 1 || SK_BWD_RING != 1 ||
+      SK_FWD_RING != 2 || SK_POLL_DELAY != 0)
+    f |= SK_BUILD_TUNING;
+  if (SK_FWD_S3_FLIP != 1) f |= SK_BUILD_ARITH;
+  return f;
+}
+
 extern "C" size_t sk_lstm_workspace_bytes(int T, int B, int H) {
   (void)T;
   if (B <= 0 || H <= 0 || pick_ks(H) == 0) return 0;
@@ -1440,6 +1496,7 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, 
   // (7.59 -> 7.50 us/step) and not kept
   const int map = ((mode >> 18) & 3) | (((mode >> 22) & 1) << 2);
   int poll_delay = (mode >> 23) & 31;  // as sk_lstm_fwd; 0 = none here until measured otherwise
+  const int fast = (mode >> 29) & 1;   // (diagnostic builds only, BwdArgs::fast)
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -1448,7 +1505,7 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, 
   a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens; a.offs = offs;
   a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0; a.dhn = dhn; a.dcn = dcn;
   a.dbias = dbias;
-  a.dgx_bf = (__bf16*)dgx_bf16; a.ld_bf = ld_bf16;
+  a.dgx_bf = (__bf16*)dgx_bf16; a.ld_bf = ld_bf16; a.fast = fast;
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;

@@ -12,6 +12,9 @@
 // thread-local message for the last failing call (sk_last_error)
 char* sk_errbuf();
 int sk_fail(int code, const char* fmt, ...);
+// build-option bits of the translation units that carry diagnostic switches (sk_build_flags)
+unsigned sk_gemm_build_flags();
+unsigned sk_lstm_build_flags();
 
 #define SK_CHECK_ARG(cond, ...)                          \
   do {                                                   \

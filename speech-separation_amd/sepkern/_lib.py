@@ -13,7 +13,15 @@ import torch  # noqa: F401,E402
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SEPKERN_LIB") or os.path.join(_HERE, "libsepkern.so")   # SEPKERN_LIB: diagnostic builds
 
-SK_VERSION = 120
+# sk_build_flags() bits (include/sepkern.h): what a library built by `make variant` / `make gemm_variant` reports
+BUILD_FLAG_NAMES = {0x1: "TIMING_ONLY (wrong results by construction)", 0x2: "ARITH (another arithmetic than documented)",
+                    0x4: "TUNING (same results, other tuning constants)", 0x8: "STAMPS (clock stamps in the recurrence kernels)"}
+
+
+def build_flag_names(mask):
+    return [n for b, n in sorted(BUILD_FLAG_NAMES.items()) if mask & b] + (["unknown 0x%x" % (mask & ~0xf)] if mask & ~0xf else [])
+
+SK_VERSION = 130
 
 _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -21,6 +29,7 @@ _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 PROTOTYPES = {
     "sk_version": (_i, []),
     "sk_last_error": (C.c_char_p, []),
+    "sk_build_flags": (C.c_uint, []),
     "sk_device_info": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "sk_stft": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _i, _i, _p]),
     "sk_mask_istft": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p]),
@@ -91,8 +100,23 @@ def load():
     v = lib.sk_version()
     if v != SK_VERSION:
         raise SepkernError("libsepkern.so version %d does not match binding %d; rebuild" % (v, SK_VERSION))
+    flags = lib.sk_build_flags()
+    if flags and os.environ.get("SEPKERN_ALLOW_DIAGNOSTIC_LIB") != "1":
+        # a measurement build (csrc/Makefile: variant / gemm_variant / stamps) lying where the product library is looked for, or
+        # named by SEPKERN_LIB: its numbers or its numerics are not the product's -- nothing may run on it by accident
+        raise SepkernError("%s is a DIAGNOSTIC build (sk_build_flags() = 0x%x: %s); refusing to load it -- set "
+                           "SEPKERN_ALLOW_DIAGNOSTIC_LIB=1 for a measurement script, or rebuild with plain `make -C "
+                           "speech-separation_amd/csrc`" % (LIB_PATH, flags, "; ".join(build_flag_names(flags))))
     _lib = lib
     return lib
+
+
+def library_info():
+    """{"path", "build_flags", "build_flag_names", "version"} of the loaded library (bench.py prints it on its line)."""
+    lib = load()
+    flags = int(lib.sk_build_flags())
+    return {"path": os.path.relpath(LIB_PATH, os.path.dirname(os.path.dirname(_HERE))), "version": int(lib.sk_version()),
+            "build_flags": flags, "build_flag_names": build_flag_names(flags)}
 
 
 def check(rc, what=""):

@@ -155,6 +155,9 @@ class Engine:
         self.var_proj = v[2] if len(v) > 2 else None
         self.var_dgrad = v[3] if len(v) > 3 else None
         self.pad_in = int(os.environ.get("SEPKERN_PAD_IN", "16"))   # diagnostics: 4 = the r04 padding of the input width
+        # diagnostics: sk_lstm_bwd mode bit 29 for the top layer's launch (1) or every layer's (2) -- read by timing-only builds
+        # of the recurrence alone (csrc/lstm.hip SK_BWD_BOUND38); the product library ignores the bit
+        self.bwd_diag = int(os.environ.get("SEPKERN_BWD_DIAG", "0"))
         self.side = None
         self.grads_fresh = True        # True: next backward may overwrite instead of accumulate
         self.version = 0               # bumped by whoever writes the parameters (ClipAdam, load_state_dict): see backward()
@@ -512,6 +515,8 @@ class Engine:
             whh = self.p("weight_hh_l%d" % l)
             dgx = gates                                  # overwritten in place, cell by cell
             mode = self.lstm_mode | self.bwd_bits
+            if self.bwd_diag == 2 or (self.bwd_diag == 1 and l == L - 1):
+                mode |= 0x20000000
             sl = slice(2 * l, 2 * l + 2)
             nbg = (B + 15) // 16
             dbias = torch.empty(nbg, 8 * H, device=dev)      # by-product of the recurrence: bias-gradient partials

@@ -120,9 +120,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     bf16 on the way into the matrix cores (fp32 accumulate; everything in memory stays fp32).  variant (fp32 only,
     sk_gemm_f32_splitk's `variant`): 0 choose -- the three-way bf16 split of both operands on the bf16 matrix pipe (six piece
     products per element pair: fp32 products in another summation order) wherever the operands are aligned, else the
-    fp32-MFMA kernels; 1 the register-staged fp32-MFMA kernel; 2 / 7 / 9 the 128 x 128 / persistent 256 x 256 stream-K /
-    256 x 128 split-once-while-staging split kernels; 3 / 4 / 6 the 128 x 128 / 256 x 128 / stream-K 256 x 256 fp32-MFMA LDS-DMA kernels; 8 choose among the
-    fp32-MFMA kernels only (the r04 default; SEPKERN_GEMM_SPLIT=0 makes 0 mean this)."""
+    fp32-MFMA kernels; 1 the register-staged fp32-MFMA kernel; 2 / 9 the 128 x 128 / 256 x 128 split-once-while-staging split
+    kernels; 3 / 4 / 6 the 128 x 128 / 256 x 128 / stream-K 256 x 256 fp32-MFMA LDS-DMA kernels; 8 choose among the fp32-MFMA
+    kernels only (the reference's literal arithmetic; SEPKERN_GEMM_SPLIT=0 makes 0 mean this)."""
     for t in (A, B, Cout, bias):
         _chk(t)
     if splitk == 0:
@@ -130,7 +130,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
     ws = None
     if splitk > 1:
         ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag)
-    elif not bf16 and batch == 1 and (variant in (6, 7) or (_STREAMK and M >= 4096 and N >= 1024 and
+    elif not bf16 and batch == 1 and (variant == 6 or (_STREAMK and M >= 4096 and N >= 1024 and
                                                 (variant == 0 or (variant == 8 and not transA)))):
         ws = _streamk_ws()                                                              # pieces of the stream-K cut
     with _timed("gemm_bf16_kernel" if bf16 else "gemm_f32_kernel", 2.0 * M * N * K * batch) as rec:
@@ -140,7 +140,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=No
             _lib.call("sk_gemm_bf16_splitk", *args, _stream())
         else:
             _lib.call("sk_gemm_f32_splitk", *args, int(variant), _stream())
-            if PROF is not None and _lib.load().sk_gemm_last_kernel() in (2, 7, 10):
+            if PROF is not None and _lib.load().sk_gemm_last_kernel() in (2, 10):
                 # the launch ran on the bf16 matrix pipe (split products): its own class -- another pipe, another peak
                 rec.cls = "gemm_f32_split_kernel"
 
@@ -236,7 +236,7 @@ def _i64(vals, device):
     return torch.tensor(vals, dtype=torch.int64, device=device)
 
 
-def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, stride_t=None, stride_f=None, lengths=None):
+def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, stride_t=None, stride_f=None, lengths=None, repeat=1):
     """STFT (n_fft 512, hop 128, reflect-centred, periodic Hann) of a list of 1-D waveforms.
 
     wavs: list of 1-D CUDA tensors, float32 in [-1,1) or int16 PCM (scaled by 1/32768 in-kernel) -- or, with
@@ -244,6 +244,7 @@ def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, s
     PCIe as one copy).
     layout "TF": returns list of (T_u, 257) tensors; "FT": list of (257, T_u) (the reference's npz layout).
     With `out` given, writes element (t,f) of utterance u at out_offs[u] + t*stride_t[u] + f*stride_f[u].
+    repeat (bench.py's aux leg): the launch is enqueued that many times back to back (same result) between the profile's events.
     """
     if lengths is not None:
         cat = wavs.contiguous()
@@ -283,12 +284,15 @@ def stft_batch(wavs, want_complex=False, layout="TF", out=None, out_offs=None, s
     d_woffs, d_ns = _i64(woffs, dev), torch.tensor(ns, dtype=torch.int32, device=dev)
     d_ooffs, d_st, d_sf = _i64(out_offs, dev), _i64(stride_t, dev), _i64(stride_f, dev)
     frame_major = all(int(v) == 1 for v in stride_f)
-    _lib.call("sk_stft", _ptr(cat), int(pcm16), _ptr(d_woffs), _ptr(d_ns), len(ns), 512, 128, int(want_complex),
-              _ptr(out), _ptr(d_ooffs), _ptr(d_st), _ptr(d_sf), int(frame_major), max(Ts), _stream())
+    # algorithmic bytes: 128 new samples in, 257 bins out per frame
+    with _timed("stft_kernel", repeat * float(sum(Ts)) * (128 * (2 if pcm16 else 4) + 257 * (8 if want_complex else 4))):
+        for _ in range(repeat):
+            _lib.call("sk_stft", _ptr(cat), int(pcm16), _ptr(d_woffs), _ptr(d_ns), len(ns), 512, 128, int(want_complex),
+                      _ptr(out), _ptr(d_ooffs), _ptr(d_st), _ptr(d_sf), int(frame_major), max(Ts), _stream())
     return ret if ret is not None else out
 
 
-def mask_istft_flat(mixcat, maskcat, Ts, S, want_pcm=True, want_float=True):
+def mask_istft_flat(mixcat, maskcat, Ts, S, want_pcm=True, want_float=True, repeat=1):
     """Mask-apply + iSTFT on buffers that crossed PCIe as ONE copy each: mixcat = the utterances' (257, T_u) complex64
     spectra back to back (flattened), maskcat = None or, per utterance and source (utterance-major), the (257, T_u) float32
     masks back to back.  Returns (wav float32 flat or None, pcm int16 flat or None, offsets): source s of utterance u is
@@ -315,13 +319,17 @@ def mask_istft_flat(mixcat, maskcat, Ts, S, want_pcm=True, want_float=True):
     if maskcat is not None:
         d_koffs, d_kst, d_ksf = _i64(koffs, dev), d_mst, d_msf
     d_T, d_ooffs = torch.tensor(list(Ts), dtype=torch.int32, device=dev), _i64(ooffs, dev)
-    _lib.call("sk_mask_istft", _ptr(mixcat), _ptr(d_moffs), _ptr(d_mst), _ptr(d_msf),
-              _ptr(maskcat), _ptr(d_koffs), _ptr(d_kst), _ptr(d_ksf),
-              _ptr(d_T), nutt, S, 512, 128, _ptr(wav), _ptr(pcm), _ptr(d_ooffs), max(Ts), _stream())
+    # algorithmic bytes per frame and source: the complex spectrum (read once per source), the mask, 128 samples out
+    per = 257 * 8 + (257 * 4 if maskcat is not None else 0) + 128 * ((2 if want_pcm else 0) + (4 if want_float else 0))
+    with _timed("istft_kernel", repeat * float(sum(Ts)) * S * per):
+        for _ in range(repeat):
+            _lib.call("sk_mask_istft", _ptr(mixcat), _ptr(d_moffs), _ptr(d_mst), _ptr(d_msf),
+                      _ptr(maskcat), _ptr(d_koffs), _ptr(d_kst), _ptr(d_ksf),
+                      _ptr(d_T), nutt, S, 512, 128, _ptr(wav), _ptr(pcm), _ptr(d_ooffs), max(Ts), _stream())
     return wav, pcm, ooffs
 
 
-def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True):
+def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True, repeat=1):
     """Mask-apply + iSTFT.  mix_specs: list of (257, T_u) complex64 CUDA tensors (the reference's
     feats_test layout); masks: None or list (per utterance) of lists (per source) of (257, T_u) float32.
     Returns (list of lists of float32 waveforms or None, list of lists of int16 waveforms or None)."""
@@ -339,7 +347,7 @@ def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True):
             for s in range(S):
                 _chk(masks[u][s])
         maskcat = torch.cat([masks[u][s].contiguous().view(-1) for u in range(nutt) for s in range(S)])
-    wav, pcm, ooffs = mask_istft_flat(mixcat, maskcat, Ts, S, want_pcm, want_float)
+    wav, pcm, ooffs = mask_istft_flat(mixcat, maskcat, Ts, S, want_pcm, want_float, repeat=repeat)
 
     def split(buf):
         if buf is None:
@@ -349,7 +357,7 @@ def mask_istft(mix_specs, masks=None, want_pcm=True, want_float=True):
 
 
 # ----------------------------------------------------------------------------- PIT-MSE
-def pit_mse_fwd(mask, mix, srcs, lens, norm_dev=None, packing=None):
+def pit_mse_fwd(mask, mix, srcs, lens, norm_dev=None, packing=None, repeat=1):
     """mask (T,B,S*F), mix (T,B,F), srcs list of S (T,B,F), lens int32 (B), norm_dev: optional device
     scalar replacing sum(lens)*F (the global norm under data parallelism) ->
     dict(out (3,), pair (B,S,S), perm_loss (S!,B), best_perm (B)).
@@ -376,12 +384,15 @@ def pit_mse_fwd(mask, mix, srcs, lens, norm_dev=None, packing=None):
     ws = workspace(_lib.load().sk_pit_workspace_bytes(T, B, S), "pit")
     sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
     _chk(norm_dev)
-    _lib.call("sk_pit_mse_fwd", _ptr(mask), _ptr(mix), sp, _ptr(lens), _ptr(packing.offs) if packing is not None else None,
-              T, B, F, S, _ptr(norm_dev), _ptr(pair), _ptr(perm_loss), _ptr(best), _ptr(out), _ptr(ws), _stream())
+    rows = packing.R if packing is not None else T * B
+    with _timed("pit_fwd", repeat * float(rows) * (2 * S + 1) * F * 4):       # algorithmic bytes: mask, mixture, S sources
+        for _ in range(repeat):
+            _lib.call("sk_pit_mse_fwd", _ptr(mask), _ptr(mix), sp, _ptr(lens), _ptr(packing.offs) if packing is not None else None,
+                      T, B, F, S, _ptr(norm_dev), _ptr(pair), _ptr(perm_loss), _ptr(best), _ptr(out), _ptr(ws), _stream())
     return dict(out=out, pair=pair, perm_loss=perm_loss, best_perm=best)
 
 
-def pit_mse_bwd(mask, mix, srcs, best_perm, out, gscale, packing=None):
+def pit_mse_bwd(mask, mix, srcs, best_perm, out, gscale, packing=None, repeat=1):
     S = len(srcs)
     dmask = torch.empty_like(mask)
     sp = (C.c_void_p * S)(*[s.data_ptr() for s in srcs])
@@ -392,8 +403,11 @@ def pit_mse_bwd(mask, mix, srcs, best_perm, out, gscale, packing=None):
             dmask[R:].zero_()            # tail rows of an (Rp, .) buffer stay zero
     else:
         (T, B, F), R, offs = mix.shape, 0, None
-    _lib.call("sk_pit_mse_bwd", _ptr(mask), _ptr(mix), sp, _ptr(best_perm), _ptr(out), _ptr(gscale), _ptr(offs), R, T, B, F, S,
-              _ptr(dmask), _stream())
+    rows = R if packing is not None else T * B
+    with _timed("pit_bwd", repeat * float(rows) * (3 * S + 1) * F * 4):        # the forward's operands + dmask written
+        for _ in range(repeat):
+            _lib.call("sk_pit_mse_bwd", _ptr(mask), _ptr(mix), sp, _ptr(best_perm), _ptr(out), _ptr(gscale), _ptr(offs), R, T, B, F, S,
+                      _ptr(dmask), _stream())
     return dmask
 
 

@@ -290,9 +290,13 @@ def test_bench_line_carries_the_contract_fields():
 def test_bench_default_run_carries_the_secondary_block():
     """The DEFAULT `python bench.py` (the command the round driver runs; here with fewer headline steps and without the CPU
     baseline) also times the other one-GPU BASELINE configurations in the same process and reports them under "secondary":
-    the variable-length set (fp32 and bf16), bf16 3-speaker, RSH 4-speaker -- VERDICT r04 item 1.  The headline fields stay
-    what they were; every secondary entry is self-consistent (value = frames per step / time per step) and names its
-    workload; a run with a workload flag does not carry the block."""
+    the variable-length set (fp32 and bf16), bf16 3-speaker, RSH 4-speaker -- VERDICT r04 item 1 --, the headline workload on
+    the fp32-MFMA kernels throughout (the reference's literal arithmetic) and the reference's own default model and batch size
+    (2 x 600, 100 utterances) -- VERDICT r05 item 2; `aux` carries the streaming kernels `north_star` names (STFT, mask-iSTFT, PIT
+    forward / backward) as us, GB/s of algorithmic bytes and fraction of the HBM peak, `library` the path and build flags of the
+    library that ran, `roofline.power_note` the sustained rate / clock / watts of the dominant GEMM class.  The headline fields
+    stay what they were; every secondary entry is self-consistent (value = frames per step / time per step) and names its
+    workload."""
     import json
     root = os.path.dirname(PKG)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
@@ -303,7 +307,7 @@ def test_bench_default_run_carries_the_secondary_block():
     d = json.loads(lines[0])
     assert d["dtype"] == "f32" and d["config"]["frames_per_step"] == 32 * 400 and "uPIT 3x896 BLSTM, 2-spk" in d["config"]["workload"]
     sec = d["secondary"]
-    assert set(sec) == {"ragged", "bf16_3spk", "bf16_ragged", "rsh_4spk"}
+    assert set(sec) == {"ragged", "bf16_3spk", "bf16_ragged", "rsh_4spk", "fp32_mfma", "ref_default_2x600_b100"}
     for name, s in sec.items():
         assert "error" not in s, (name, s)
         for k in ("value", "ms_per_step", "frames_per_step", "dtype", "step_frac_of_mfma_peak", "by_kernel", "workload", "numerics"):
@@ -319,6 +323,22 @@ def test_bench_default_run_carries_the_secondary_block():
     assert "RSH 2x600" in sec["rsh_4spk"]["workload"] and "4-spk" in sec["rsh_4spk"]["workload"]
     # the bf16 configurations are faster than their fp32 counterparts, the ragged step is not slower than the uniform one
     assert sec["bf16_3spk"]["ms_per_step"] < d["ms_per_step"] and sec["bf16_ragged"]["ms_per_step"] < sec["ragged"]["ms_per_step"]
+    # the literal fp32 arithmetic: same workload, GEMMs on the fp32-MFMA kernels and named so; slower than the shipped arithmetic
+    fm = sec["fp32_mfma"]
+    assert fm["frames_per_step"] == 12800 and fm["dtype"] == "f32" and "GEMMs on the fp32-MFMA kernels" in fm["numerics"]
+    assert "recurrences: fp32-MFMA products" in fm["numerics"] and fm["ms_per_step"] > d["ms_per_step"]
+    assert not any(k.startswith("gemm_f32_split") for k in fm["by_kernel"])
+    rd = sec["ref_default_2x600_b100"]
+    assert "uPIT 2x600 BLSTM, 2-spk" in rd["workload"] and rd["frames_per_step"] == 100 * 400
+    # streaming kernels: all four, sane numbers
+    aux = d["aux"]
+    assert {"stft_kernel", "istft_kernel", "pit_fwd", "pit_bwd"} <= set(aux)
+    for k in ("stft_kernel", "istft_kernel", "pit_fwd", "pit_bwd"):
+        assert aux[k]["us_per_launch"] > 0 and 0 < aux[k]["frac_of_hbm_peak"] <= 1, (k, aux[k])
+        assert abs(aux[k]["GBs_algorithmic"] - aux[k]["MB_algorithmic_per_launch"] / aux[k]["us_per_launch"] * 1e3) / aux[k]["GBs_algorithmic"] < 0.02
+    assert d["library"]["build_flags"] == 0 and d["library"]["path"].endswith("libsepkern.so")
+    pn = d["roofline"]["power_note"]
+    assert "error" not in pn and pn["sustained"]["tflops_fp32_equivalent"] > 100
 
 
 def test_staged_batches_equal_the_plain_loader_and_keep_up_with_the_step(tmp_path):

@@ -58,3 +58,42 @@ def test_no_cpu_path():
     import uPIT
     with pytest.raises(_lib.SepkernError):
         uPIT.SepDNN(-1)
+
+
+def test_product_build_reports_no_build_flags():
+    from sepkern import _lib
+    assert _lib.load().sk_build_flags() == 0
+    info = _lib.library_info()
+    assert info["build_flags"] == 0 and info["build_flag_names"] == [] and info["path"].endswith("libsepkern.so")
+
+
+def test_a_diagnostic_build_is_refused_by_the_loader_and_by_bench(tmp_path):
+    """`make gemm_variant DEFS=-DSK_SPLIT_FREE` builds a TIMING-ONLY library (wrong numerics) from the product
+    sources into the product's directory, with the product's SK_VERSION.  sk_build_flags() tells them apart: the ctypes loader refuses
+    such a library unless SEPKERN_ALLOW_DIAGNOSTIC_LIB=1, and bench.py exits non-zero on it without --diagnostic -- before it
+    touches a GPU."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "speech-separation_amd", "csrc")
+    lib = os.path.join(ROOT, "speech-separation_amd", "sepkern", "libsepkern_t_refusal.so")
+    try:
+        subprocess.check_call(["make", "-C", csrc, "gemm_variant", "NAME=t_refusal", "DEFS=-DSK_SPLIT_FREE"], stdout=subprocess.DEVNULL)
+        code = ("import sys; sys.path.insert(0, %r); from sepkern import _lib\n"
+                "try:\n    _lib.load(); print('LOADED', _lib.load().sk_build_flags())\n"
+                "except _lib.SepkernError as e:\n    print('REFUSED', e)\n" % os.path.join(ROOT, "speech-separation_amd"))
+        env = dict(os.environ, SEPKERN_LIB=lib)
+        env.pop("SEPKERN_ALLOW_DIAGNOSTIC_LIB", None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout
+        assert out.startswith("REFUSED") and "DIAGNOSTIC build" in out and "TIMING_ONLY" in out, out
+        env["SEPKERN_ALLOW_DIAGNOSTIC_LIB"] = "1"
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300).stdout
+        assert out.split()[:2] == ["LOADED", "1"], out
+        # bench.py: refuses before it needs a GPU, names the flag; --diagnostic gets past the check (and then fails here for want of a GPU)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode != 0 and "diagnostic build" in r.stderr and "--diagnostic" in r.stderr, (r.returncode, r.stderr[-800:])
+        assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    finally:
+        for f in (lib, os.path.join(csrc, "gemm_t_refusal.o")):
+            if os.path.exists(f):
+                os.remove(f)
