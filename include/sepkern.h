@@ -134,7 +134,8 @@ size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
 /* Which kernel the calling thread's LAST sk_gemm_f32[_splitk] / sk_gemm_bf16_splitk launch took (profiling: bench.py prices a
  * launch against the peak of the matrix pipe it ran on; tests/test_gpu_census.py generates DESIGN.md's kernel census from it):
  * 1 register-staged fp32 MFMA, 3 / 4 / 6 the 128 x 128 / 256 x 128 / stream-K fp32-MFMA LDS-DMA kernels, 2 / 10 the 128 x 128 /
- * 256 x 128 split-while-staging SPLIT kernels (bf16 pipe, six piece products), 9 bf16 inputs; 0 before the first launch.
+ * 256 x 128 split-while-staging SPLIT kernels (bf16 pipe, six piece products), 9 bf16 inputs (fp32 operands rounded on the way
+ * in); sk_gemm_bf16_nt / _mm: 11 / 12 the 256 x 128 / 256 x 256-tile bf16-operand kernel, 13 its stream-K form; 0 before the first launch.
  * A thread-local read-back: with the error string of sk_last_error() the library's only mutable state that is not a caller's
  * buffer (SURVEY 8b's rule has these two exceptions, both thread-local and neither read by any kernel or launch decision). */
 int sk_gemm_last_kernel(void);
@@ -249,7 +250,13 @@ size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 const int32_t* offs, float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
                 int T, int B, int H, int mode, sk_stream_t stream);
-/* Backward of the recurrence.  dy (T,B,2H) is the gradient of the layer output, dhn / dcn (2,B,H; either may be NULL = 0)
+/* Backward of the recurrence.  mode as sk_lstm_fwd (bits 0..7, 8..15, 16, 18..19, 22, 23..27); bit 28 (fp32, 608 < H <= 896,
+ * r06; ignored elsewhere): the product dh = dG W_hh by the exact three-way bf16 split of both operands on the bf16 matrix pipe, six
+ * piece products, sign phases over the eight K slices of a workgroup -- the forward kernel's bit-28 arithmetic.  W_hh^T is held as
+ * three register pieces (245 VGPRs): NO kernel can be co-resident with this form; it is meant for launches that host nothing beside
+ * them (the engine: the top layer's).  dG travels as fp32 and is split by the wave that multiplies it.  bit 29: read by
+ * timing-only diagnostic builds alone.
+ * dy (T,B,2H) is the gradient of the layer output, dhn / dcn (2,B,H; either may be NULL = 0)
  * the gradient wrt the final state (the RSH arch carries the hidden state from pass to pass, reference archs/RSH.py:172);
  * produces dgx (T,B,2,4H) = gradient of the gate pre-activations (gate-interleaved like gx; padded layout: zero at padded
  * positions), from which the caller forms dW_ih, dW_hh (with sk_hprev_rows), db and dx with the GEMMs, and dh0/dc0

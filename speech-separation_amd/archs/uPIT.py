@@ -145,7 +145,18 @@ class WavCollator():
 
   def __call__(self, batch):
     order = np.argsort(np.array([1 + len(d['mix']) // 128 for d in batch]))[::-1]
-    keys = ['mix'] + sorted((k for k in batch[0] if k != 'mix'), key=lambda k: int(k[6:]))
+    others = [k for k in batch[0] if k != 'mix']
+    bad = [k for k in others if not (k.startswith('source') and k[6:].isdigit())]
+    if bad:
+      raise ValueError("WavCollator: signals besides 'mix' must be named 'source<N>' (got %r)" % bad)
+    keys = ['mix'] + sorted(others, key=lambda k: int(k[6:]))
+    # ONE list of sample counts ('lens', the mixture's) describes every key of the flat tensor: a source whose length differs
+    # from its mixture's by a single sample would shift every later signal -- wrong targets, no error -- so it is one here
+    for d in batch:
+      for k in keys:
+        if k not in d or len(d[k]) != len(d['mix']):
+          raise ValueError("WavCollator: signal %r of an utterance has %s samples, its mixture %d -- the sources of a mixture "
+                           "must have the mixture's length" % (k, len(d[k]) if k in d else "no", len(d['mix'])))
     flat = np.concatenate([batch[i][k] for k in keys for i in order])
     return {'pcm': {'flat': torch.from_numpy(flat), 'keys': keys, 'lens': [int(len(batch[i]['mix'])) for i in order]}}
 
@@ -197,6 +208,10 @@ class SepDNN(SepDNNBase):
 
   def forward(self, x):
     # x: packed sequence of dim feat_dim  ->  tensor of shape (batch, seq_length, feat_dim*num_spk)
+    # RESTRICTION (variable-length batches, gradients): the values at zero-padded frames are filled in as the constant the
+    # reference's network shows there, sigmoid(lin(bn(0))), and carry NO gradient back into lin / bn (UnpackFn).  A loss that
+    # zeroes padded frames -- the reference's PIT-MSE does: mix = 0 there, archs/uPIT.py:181-197 -- gets the reference's parameter
+    # gradients exactly; a loss that reads the padded frames of model(x) would miss their contribution to d lin / d bn.
     x2d, pk = _to_packed(x, self.lin.weight.device)
     mask = self.forward_packed(x2d, pk)
     # (padded frames: the constant the reference's BatchNorm / Linear / sigmoid produce there, archs/uPIT.py:135-144)

@@ -648,7 +648,7 @@ __device__ __forceinline__ void mma6(f32x16& acc, const Split3& a, const Split3&
 // are the negated pieces of x, rounding to nearest is symmetric), so that truncation pulls the sum down in one and up in the next.
 // Stretches of q K steps, signs + - - + + - - + ...: over a period of 4 q the offsets cancel both for a sum of constant size and
 // for one that grows linearly with k (all-positive operands), and the sign changes at every second boundary only.  q (GemmArgs::
-// flip_q, chosen by the launcher from the WHOLE K: periods of about 128 steps, a whole number of them) is counted in GLOBAL K
+// flip_q, chosen by the launcher from the WHOLE K: periods of about 64 steps, a whole number of them) is counted in GLOBAL K
 // steps, so the slices of a split-K product continue one pattern.  r05 had this in the N/N planes kernel only (+ - + -, 32 steps);
 // r06: every split-product kernel and form (tests/test_gpu_signed_error.py pins the mean signed error of each).
 struct SignPhase {
@@ -2181,12 +2181,17 @@ int gemm_launch(bool bf16, const float* A, const float* B, float* C, const float
   static const bool planes_on = [] { const char* e = getenv("SEPKERN_GEMM_PLANES"); return !(e && e[0] == '0'); }();
   const bool planes = split && splitk == 1 && batch == 1 && M >= 256 && N >= 128 &&
                       (variant == 9 || (variant == 0 && planes_on && sk_cdiv(M, 256) * sk_cdiv(N, 128) >= 192));
-  // Sign phases of the split products (SignPhase): stretches of q K steps, signs + - - +, a whole number of periods of about
-  // 128 steps over the WHOLE K (the slices of a split-K product continue one pattern); products shorter than 16 steps: none.
+  // Sign phases of the split products (SignPhase): stretches of q K steps, signs + - - +, a whole number of periods of about 64
+  // steps over the WHOLE K (the slices of a split-K product continue one pattern: K = 1792: q = 14, 7168: 16, 12800: 17 -- a sign
+  // change per ~32 steps, the r05 N/N kernel's rate).  What is left of the offset is at most one stretch's worth inside the
+  // result's last binade: measured on all-positive operands -5e-10 ... +3e-9 of the result where the plain form has -3.6e-8
+  // (K = 1792) ... -2.7e-7 (K = 12800) and the fp32-MFMA kernels -4e-10 ... -1e-9 (profiles/r06_signed_error.txt).  Products
+  // shorter than 48 steps (K < 768: the layer-0 projection's K = 272; offset -5e-9) keep the plain form -- three uneven
+  // stretches would over-correct it.
   if (split && SK_SPLIT_FLIP) {
     const int nks = K / BK;
-    if (nks >= 16) {
-      const int periods = nks >= 192 ? (nks + 64) / 128 : 1;
+    if (nks >= 48) {
+      const int periods = (nks + 32) / 64;
       g.flip_q = (nks + 4 * periods - 1) / (4 * periods);
     }
   }
@@ -2364,6 +2369,7 @@ extern "C" int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const flo
   SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm_bf16_mm: too many tiles");
   dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
   hipStream_t st = (hipStream_t)stream;
+  t_last_kernel = streamk ? 13 : wide ? 12 : 11;  // (sk_gemm_last_kernel: the bf16-operand kernels)
 #define SK_BF2_LAUNCH(BNV, AK, BKV) hipLaunchKernelGGL((bf2::gemm_bf16_nt_kernel<BNV, AK, BKV>), grid, dim3(bf2::NT), 0, st, g)
 #define SK_BF2_STREAMK(AK, BKV) \
   hipLaunchKernelGGL((bf2::gemm_bf16_streamk_kernel<AK, BKV>), dim3((unsigned)streamk_wgs()), dim3(bf2::NT), 0, st, g)

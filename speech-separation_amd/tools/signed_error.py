@@ -115,6 +115,54 @@ def lstm_case(ops, gx, whh, h0, c0, ref, bits, bf16=False):
                 c_mean_signed=float(ec.mean()), c_rel_l2=float(ec.norm() / c_ref.norm()))
 
 
+def lstm_bwd_fp64(gx, whh, h0, c0, dy):
+    """Gradients of sum(y * dy) through the fp64 host recurrence (autograd): dgx (T, B, 2, 4H) gate-interleaved like gx -- the
+    gradient of the gate pre-activations, what sk_lstm_bwd writes --, dh0, dc0 (2, B, H)."""
+    g64 = gx.double().requires_grad_(True)
+    h64, c64 = h0.double().requires_grad_(True), c0.double().requires_grad_(True)
+    T, B, _, H4 = gx.shape
+    H = H4 // 4
+    gv = g64.view(T, B, 2, H, 4)
+    w = whh.double()
+    ys = []
+    for d in range(2):
+        h, c = h64[d], c64[d]
+        wt = w[d].t().contiguous()                      # (H, 4H), columns g H + u
+        out = [None] * T
+        for s in range(T):
+            t = T - 1 - s if d else s
+            pre = (h @ wt).view(B, 4, H) + gv[t, :, d].permute(0, 2, 1)
+            i_, f_, g_, o_ = torch.sigmoid(pre[:, 0]), torch.sigmoid(pre[:, 1]), torch.tanh(pre[:, 2]), torch.sigmoid(pre[:, 3])
+            c = f_ * c + i_ * g_
+            h = o_ * torch.tanh(c)
+            out[t] = h
+        ys.append(torch.stack(out))
+    y = torch.cat(ys, 2)
+    (y * dy.double()).sum().backward()
+    return g64.grad.detach(), h64.grad.detach(), c64.grad.detach()
+
+
+def lstm_bwd_case(ops, gx, whh, h0, c0, dy, ref, bits):
+    """sk_lstm_bwd (mode 1 | bits) on the activations saved by the fp32-MFMA forward kernel, against lstm_bwd_fp64's result."""
+    T, B, _, H4 = gx.shape
+    H = H4 // 4
+    lens = torch.full((B,), T, dtype=torch.int32).cuda()
+    gg = gx.reshape(T * B, 8 * H).cuda()
+    y, cs = torch.zeros(T * B, 2 * H).cuda(), torch.zeros(T * B, 2 * H).cuda()
+    whh_d, c0_d = whh.cuda(), c0.cuda()
+    ws = ops.lstm_fwd(gg, whh_d, h0.cuda(), c0_d, lens, y, gg, cs, None, None, T, B, H, 1 | ops.lstm_variant_bits(False, 1, True, False, False, 0))
+    ops.lstm_status(ws)
+    dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+    ws = ops.lstm_bwd(dy.reshape(T * B, 2 * H).cuda(), whh_d, gg, cs, c0_d, lens, gg, dh0, dc0, T, B, H, 1 | bits)
+    ops.lstm_status(ws)
+    dgx_ref, dh_ref, _ = ref
+    eg = gg.cpu().double().view(T, B, 2, 4 * H) - dgx_ref
+    eh = dh0.cpu().double() - dh_ref
+    scale = float(dgx_ref.abs().mean())
+    return dict(dgx_mean_signed=float(eg.mean()) / scale, dgx_rel_l2=float(eg.norm() / dgx_ref.norm()),
+                dh0_mean_signed=float(eh.mean()) / float(dh_ref.abs().mean()), dh0_rel_l2=float(eh.norm() / dh_ref.norm()))
+
+
 # what the training step launches (3 x 896, 32 x 400: R = 12800 rows), reduced in M and N -- the offset is per element
 GEMM_CASES = (
     # name, form, M, N, K, variant, splitk, batch
@@ -162,6 +210,21 @@ def main():
             r = lstm_case(ops, *inp, ref, bits, bf16=bf)
             print("    %-16s y %+.2e (%+.2e) / %.2e   c_T %+.2e / %.2e" % (
                 name, r["y_mean_signed"], r["y_late_mean_signed"], r["y_rel_l2"], r["c_mean_signed"], r["c_rel_l2"]))
+        g = torch.Generator().manual_seed(5)
+        dy = torch.randn(T, B, 2 * H, generator=g)
+        dy = dy.abs() if positive else dy
+        f = os.path.join(cache, "lstm_bwd_fp64_%d_%d_%d_%d.pt" % (T, B, H, positive)) if cache else None
+        if f and os.path.exists(f):
+            bref = torch.load(f)
+        else:
+            bref = lstm_bwd_fp64(*inp, dy)
+            if f:
+                torch.save(bref, f)
+        for name, bits in (("bwd split (top layer)", ops.lstm_variant_bits(False, 1, split3=True, poll_delay=31)),
+                           ("bwd fp32 MFMA", ops.lstm_variant_bits(False, 1, poll_delay=31))):
+            r = lstm_bwd_case(ops, *inp, dy, bref, bits)
+            print("    %-22s dgx %+.2e / %.2e (mean signed / mean |dgx|, rel-L2)   dh0 %+.2e / %.2e" % (
+                name, r["dgx_mean_signed"], r["dgx_rel_l2"], r["dh0_mean_signed"], r["dh0_rel_l2"]))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,204 @@
+"""Kernel census: which `__global__` serves which launch of which BASELINE configuration.
+
+One training step of every one-GPU BASELINE configuration (+ the reference's default model at its default batch size, + the
+headline in the reference's literal fp32-MFMA arithmetic) runs with a spy on the ctypes boundary: every C entry point called, and
+for the GEMMs the kernel the library chose (sk_gemm_last_kernel()).  The table generated from that is the one DESIGN.md section 4
+carries between its census markers: this test regenerates it and compares, so the document cannot go stale.
+`python tests/test_gpu_census.py` prints the table (and writes gpurun_out/census.md).
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(ROOT, "speech-separation_amd", "archs"))
+
+GEMM_KERNELS = {
+    1: "gemm_f32_kernel (fp32 MFMA, register-staged)", 2: "gemm_f32_kernel_split3 (split products, 128x128)",
+    3: "gemm_f32_kernel_dma (fp32 MFMA, LDS-DMA 128x128)", 4: "gemm_f32_kernel_dma256 (fp32 MFMA, 256x128)",
+    6: "gemm_f32_kernel_streamk (fp32 MFMA, 256x256 persistent)", 9: "bf::gemm_bf16_kernel (fp32 operands rounded on the way in)",
+    10: "gemm_f32_kernel_planes (split products, split once while staging, 256x128)",
+    11: "bf2::gemm_bf16_nt_kernel<128>", 12: "bf2::gemm_bf16_nt_kernel<256>", 13: "bf2::gemm_bf16_streamk_kernel",
+}
+# entry point -> the kernel(s) it launches when the choice does not depend on the arguments
+FIXED = {
+    "sk_stft": "stft_kernel", "sk_mask_istft": "istft_kernel", "sk_pit_mse_fwd": "pit_pair_kernel + pit_finalize_kernel",
+    "sk_pit_mse_bwd": "pit_bwd_kernel", "sk_bn_stats": "colred_kernel + colfin_kernel + colfin_var_kernel", "sk_bn_fold": "bn_fold_kernel",
+    "sk_bn_unfold_grad": "bn_unfold_grad_kernel", "sk_bn_update_running": "bn_running_kernel", "sk_bn_apply": "bn_apply_kernel",
+    "sk_bn_bwd_sums": "colred_kernel + colfin_kernel", "sk_bn_bwd_apply": "bn_bwd_apply_kernel", "sk_colsum": "colred_kernel + colfin_kernel",
+    "sk_sigmoid_bwd": "sigmoid_bwd_kernel", "sk_pad_rows": "pad_rows_kernel", "sk_gate_rows": "gate_rows_kernel",
+    "sk_hprev_rows": "hprev_rows_kernel", "sk_pack_rows": "pack_rows_kernel", "sk_unpack_rows": "pack_rows_kernel (unpack form)",
+    "sk_cast_bf16_rows": "bf2::cast_kernel", "sk_grad_norm": "sumsq_kernel + norm_fin_kernel", "sk_clip_adam": "clip_adam_kernel",
+    "sk_rsh_loss_fwd": "rsh_sse_kernel + rsh_select_kernel", "sk_rsh_loss_bwd": "rsh_bwd_kernel", "sk_att_update": "att_update_kernel",
+    "sk_att_update_bwd": "att_update_bwd_kernel",
+}
+
+
+def _pick_ks(H, bf):
+    need = (H + 15) // 16
+    for o in (20, 40 if bf else 38, 56, 64):
+        if o >= need:
+            return o
+    return 0
+
+
+def _lstm_kernel(name, args):
+    """The template instantiation and grid of a recurrence launch, restated from csrc/lstm.hip's dispatch."""
+    if name == "sk_lstm_fwd":
+        T, B, H, mode, offs = args[12], args[13], args[14], args[15], args[5]
+    else:
+        T, B, H, mode, offs = args[16], args[17], args[18], args[19], args[8]
+    bf = bool(mode & 0x10000)
+    s3 = name == "sk_lstm_fwd" and bool(mode & 0x10000000) and not bf and _pick_ks(H, True) != 64
+    ks = _pick_ks(H, bf or s3)
+    nbg = (B + 15) // 16
+    g = next(g_ for g_ in range(1, 9) if ks * ((nbg + g_ - 1) // g_) * 2 <= 256)
+    wgs = ks * ((nbg + g - 1) // g) * 2
+    if name == "sk_lstm_fwd":
+        k = "lstm_fwd_kernel<%d, %s, 8, %s, %s>" % (ks, "true" if bf else "false", "true" if s3 else "false", "true" if offs else "false")
+    else:
+        k = "lstm_bwd_kernel<%d, %s>" % (ks, "true" if bf else "false")
+    return k, "T=%d B=%d H=%d: %d persistent workgroups (one per CU), %d batch group(s) each" % (T, B, H, wgs, g)
+
+
+class Spy:
+    def __init__(self):
+        from sepkern import _lib
+        self._lib, self.rows, self.orig = _lib, {}, _lib.call
+
+    def __enter__(self):
+        lib = self._lib
+
+        def call(name, *args):
+            self.orig(name, *args)
+            side = torch.cuda.current_stream() != torch.cuda.default_stream()
+            val = lambda a: getattr(a, "value", a)      # noqa: E731
+            if name in ("sk_gemm_f32_splitk", "sk_gemm_bf16_splitk", "sk_gemm_bf16_mm", "sk_gemm_bf16_nt"):
+                kid = lib.load().sk_gemm_last_kernel()
+                M, N, K = args[4], args[5], args[6]
+                if name == "sk_gemm_bf16_nt":
+                    form, batch, splitk = "N/T", args[12], args[17]
+                else:
+                    form = ("T" if args[10] else "N") + "/" + (("N" if args[11] else "T") if name == "sk_gemm_bf16_mm" else ("T" if args[11] else "N"))
+                    batch, splitk = args[14], args[19]
+                shape = "%s %d x %d x %d%s%s" % (form, M, N, K, " x%d" % batch if batch > 1 else "", " in %d K slices" % splitk if splitk > 1 else "")
+                key = (name, GEMM_KERNELS.get(kid, "kernel %d" % kid), shape, "side" if side else "main")
+            elif name in ("sk_lstm_fwd", "sk_lstm_bwd"):
+                k, shape = _lstm_kernel(name, [val(a) for a in args])
+                key = (name, k, shape, "side" if side else "main")
+            elif name in FIXED:
+                key = (name, FIXED[name], "", "side" if side else "main")
+            else:
+                return
+            self.rows[key] = self.rows.get(key, 0) + 1
+        lib.call = call
+        return self
+
+    def __exit__(self, *exc):
+        self._lib.call = self.orig
+        return False
+
+
+def _step(arch, H, L, S, B, T, dtype, env=None):
+    """One training step of the given configuration on a uniform batch; returns the spy's rows."""
+    import uPIT
+    from sepkern.optim import ClipAdam
+    from sepkern.packing import Packing
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        torch.manual_seed(0)
+        F = 257
+        if arch == "rsh":
+            import RSH
+            model = RSH.SepDNN(0, hidden_dim=str(H), num_layers=str(L), dtype=dtype)
+        else:
+            model = uPIT.SepDNN(0, num_spk=str(S), hidden_dim=str(H), num_layers=str(L), dtype=dtype)
+        model.cuda()
+        model.train()
+        opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
+        g = torch.Generator(device="cuda").manual_seed(1)
+        pk = Packing.from_lens([T] * B, "cuda")
+        mix = torch.rand(pk.Rp, F, device="cuda", generator=g)
+        srcs = [torch.rand(pk.Rp, F, device="cuda", generator=g) * 0.6 for _ in range(S)]
+
+        def step():
+            if arch == "rsh":
+                lens = torch.full((B,), T, dtype=torch.int32, device="cuda")
+                mp = mix.view(T, B, F)
+                combos = torch.cat([mp, torch.ones_like(mp)], 2).contiguous()
+                loss, _ = RSH.compute_loss_padded(model, [(S, combos, [s_.view(T, B, F) for s_ in srcs], lens)])
+            else:
+                loss, _ = uPIT.compute_loss_packed(model, mix, srcs, pk)
+            loss.backward()
+            opt.step()
+        step()                                             # warm-up: lazily built engine, workspaces
+        torch.cuda.synchronize()
+        with Spy() as spy:
+            step()
+            torch.cuda.synchronize()
+        model.check_status()
+        return spy.rows
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+CONFIGS = (
+    ("BASELINE configs[1] (the headline): uPIT 3x896, 2-spk, 32 x 400, fp32", dict(arch="upit", H=896, L=3, S=2, B=32, T=400, dtype="fp32")),
+    ("the same step in the reference's literal arithmetic (bench.py secondary.fp32_mfma: GEMM variants 8 / 1, plain forward product)",
+     dict(arch="upit", H=896, L=3, S=2, B=32, T=400, dtype="fp32", env={"SEPKERN_GEMM_VARIANTS": "8,1", "SEPKERN_LSTM_FWD": "0,1,1,0,0,0,0,0"})),
+    ("BASELINE configs[3]: uPIT 3x896, 3-spk, 32 x 400, bf16", dict(arch="upit", H=896, L=3, S=3, B=32, T=400, dtype="bf16")),
+    ("BASELINE configs[0]'s model at the reference's batch size: uPIT 2x600, 2-spk, 100 x 400, fp32", dict(arch="upit", H=600, L=2, S=2, B=100, T=400, dtype="fp32")),
+    ("BASELINE configs[4] (one GPU): RSH 2x600, 4-spk, 32 x 400, fp32", dict(arch="rsh", H=600, L=2, S=4, B=32, T=400, dtype="fp32")),
+)
+
+
+def census_markdown():
+    out = []
+    for title, cfg in CONFIGS:
+        rows = _step(**cfg)
+        out.append("**%s** -- one training step:" % title)
+        out.append("")
+        out.append("| launches | entry point | kernel | shape / grid | stream |")
+        out.append("|---|---|---|---|---|")
+        order = sorted(rows.items(), key=lambda kv: (0 if "gemm" in kv[0][0] else 1 if "lstm" in kv[0][0] else 2, kv[0][0], kv[0][2], kv[0][3]))
+        for (name, kern, shape, stream), n in order:
+            out.append("| %d | `%s` | %s | %s | %s |" % (n, name, kern, shape, stream))
+        out.append("")
+    return "\n".join(out).rstrip() + "\n"
+
+
+BEGIN, END = "<!-- census:begin (generated by tests/test_gpu_census.py; do not edit) -->", "<!-- census:end -->"
+
+
+def test_design_md_carries_the_generated_census():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    md = census_markdown()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "census.md"), "w") as f:
+        f.write(md)
+    doc = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert BEGIN in doc and END in doc, "DESIGN.md has no census block"
+    have = doc[doc.index(BEGIN) + len(BEGIN):doc.index(END)].strip()
+    assert have == md.strip(), "DESIGN.md's kernel census is stale: regenerate it (gpurun_out/census.md holds the current one)"
+    # every fp32 GEMM kernel the library still carries serves a launch of some configuration above
+    used = {r.split("|")[3].strip() for r in md.splitlines() if r.startswith("| ")}
+    for kid in (1, 2, 3, 4, 6, 10, 11, 12, 13):
+        assert GEMM_KERNELS[kid] in used, "no configuration launches " + GEMM_KERNELS[kid]
+
+
+if __name__ == "__main__":
+    text = census_markdown()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "census.md"), "w") as fh:
+        fh.write(text)
+    print(text)

@@ -4,11 +4,14 @@ oracle/stft.py is "parity unpinned" (librosa absent): these tests hold it to the
 mathematical known answers listed in SURVEY.md section 4 and to two independent
 implementations of the same documented semantics (torch.stft, scipy.signal)."""
 import itertools
+import os
 
 import numpy as np
 import pytest
 import scipy.signal
 import torch
+
+from conftest import ROOT
 
 from oracle import stft as S
 from oracle import upit as O
@@ -185,6 +188,32 @@ def test_frame_counts_from_file_headers(tmp_path):
         p = str(tmp_path / ("w%d.wav" % n))
         scipy.io.wavfile.write(p, 8000, np.zeros(n, np.int16))
         assert wav_frames(p) == 1 + n // 128
+
+
+def test_wav_collator_refuses_sources_that_do_not_match_their_mixture():
+    """archs/uPIT.py WavCollator (the --wav-input route): the batch crosses to the trainer as ONE int16 tensor described by the
+    mixtures' sample counts alone, so a source that is one sample shorter than its mixture would silently shift every later
+    signal.  It is an error; so is a signal that is not named 'mix' / 'source<N>'.  The good batch is key-major,
+    longest utterance first."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "speech-separation_amd", "archs"))
+    import uPIT
+    rng = np.random.default_rng(3)
+
+    def utt(n, short=0):
+        return {"mix": rng.integers(-100, 100, n).astype(np.int16), "source1": rng.integers(-100, 100, n - short).astype(np.int16),
+                "source2": rng.integers(-100, 100, n).astype(np.int16)}
+    good = [utt(1000), utt(3000), utt(2000)]
+    out = uPIT.WavCollator()(good)["pcm"]
+    assert out["keys"] == ["mix", "source1", "source2"] and out["lens"] == [3000, 2000, 1000]
+    want = np.concatenate([good[i][k] for k in out["keys"] for i in (1, 2, 0)])
+    assert np.array_equal(out["flat"].numpy(), want)
+    with pytest.raises(ValueError, match="must have the mixture's length"):
+        uPIT.WavCollator()([utt(1000), utt(3000, short=1)])
+    bad = utt(1000)
+    bad["noise"] = bad["mix"]
+    with pytest.raises(ValueError, match="source<N>"):
+        uPIT.WavCollator()([bad])
 
 
 @pytest.mark.parametrize("lens", [[9, 7, 7, 3], [5, 5, 5], [1], [6, 1, 1, 1, 1], list(range(40, 0, -1))])
