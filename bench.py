@@ -428,8 +428,7 @@ def measure(args, env, standalone_pass=True):
             """The peak of the matrix pipe a kernel class runs on (fp32-equivalent TFLOP/s)."""
             if args.dtype == "bf16":
                 return PEAK_BF16_MFMA_TFLOPS
-            if cls.startswith("gemm_f32_split") or cls.startswith("lstm_bwd_s3") or \
-                    (cls.startswith("lstm_fwd") and model._engine is not None and model._engine.split3_fwd):
+            if cls.startswith("gemm_f32_split") or (cls.startswith("lstm_fwd") and model._engine is not None and model._engine.split3_fwd):
                 return PEAK_F32_SPLIT_TFLOPS
             return PEAK_F32_MFMA_TFLOPS
         # launches recorded on the side stream are the weight-gradient GEMMs that the engine co-schedules with the
@@ -533,7 +532,7 @@ SECONDARY = (
     ("bf16_3spk", dict(dtype="bf16", num_spk=3)),
     ("bf16_ragged", dict(dtype="bf16", ragged=True)),
     ("rsh_4spk", dict(arch="rsh", hidden=600, layers=2, num_spk=4)),
-    ("fp32_mfma", dict(env={"SEPKERN_GEMM_VARIANTS": "8,1", "SEPKERN_LSTM_FWD": "0,1,1,0,0,0,0,0", "SEPKERN_LSTM_BWD_TOP": "0"})),
+    ("fp32_mfma", dict(env={"SEPKERN_GEMM_VARIANTS": "8,1", "SEPKERN_LSTM_FWD": "0,1,1,0,0,0,0,0"})),
     ("ref_default_2x600_b100", dict(hidden=600, layers=2, batch=100)),
 )
 SECONDARY_STEPS, SECONDARY_WARMUP = 20, 3
@@ -691,10 +690,8 @@ def numerics_note(model, args):
     if os.environ.get("SEPKERN_GEMM_SPLIT", "1") == "0" or (eng is not None and eng.var_main not in (0, 2, 9)):
         gemms = "GEMMs on the fp32-MFMA kernels"
     if eng is not None and eng.split3_fwd:
-        bwd = ("backward recurrences: the top layer's the same way, the others (which host the weight-gradient GEMMs) fp32-MFMA products"
-               if eng.bwd_top_split else "backward recurrences: fp32-MFMA products")
         return ("fp32 storage, fp32 accumulation, no operand perturbed; " + gemms + "; the forward recurrence forms h W_hh^T the same way "
-                "(SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = plain fp32-MFMA product); " + bwd)
+                "(SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = plain fp32-MFMA product); backward recurrences: fp32-MFMA products")
     if eng is not None and eng.tagged_fwd and eng.lstm_mode != 2:
         return ("fp32 storage and accumulation; " + gemms + "; forward-recurrence hand-off 'tagged': the operand h entering h W_hh^T "
                 "carries a 2-bit epoch in its low mantissa bits (<= 3 ulp), all stored values exact; SEPKERN_LSTM_FWD=0,1,1,0,0,0,0,0 = "

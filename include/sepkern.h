@@ -250,13 +250,8 @@ size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 const int32_t* offs, float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
                 int T, int B, int H, int mode, sk_stream_t stream);
-/* Backward of the recurrence.  mode as sk_lstm_fwd (bits 0..7, 8..15, 16, 18..19, 22, 23..27); bit 28 (fp32, 608 < H <= 896,
- * r06; ignored elsewhere): the product dh = dG W_hh by the exact three-way bf16 split of both operands on the bf16 matrix pipe, six
- * piece products, sign phases over the eight K slices of a workgroup -- the forward kernel's bit-28 arithmetic.  W_hh^T is held as
- * three register pieces (245 VGPRs): NO kernel can be co-resident with this form; it is meant for launches that host nothing beside
- * them (the engine: the top layer's).  dG travels as fp32 and is split by the wave that multiplies it.  bit 29: read by
- * timing-only diagnostic builds alone.
- * dy (T,B,2H) is the gradient of the layer output, dhn / dcn (2,B,H; either may be NULL = 0)
+/* Backward of the recurrence.  mode as sk_lstm_fwd (bits 0..7, 8..15, 16, 18..19, 22, 23..27; bit 29: read by timing-only
+ * diagnostic builds alone).  dy (T,B,2H) is the gradient of the layer output, dhn / dcn (2,B,H; either may be NULL = 0)
  * the gradient wrt the final state (the RSH arch carries the hidden state from pass to pass, reference archs/RSH.py:172);
  * produces dgx (T,B,2,4H) = gradient of the gate pre-activations (gate-interleaved like gx; padded layout: zero at padded
  * positions), from which the caller forms dW_ih, dW_hh (with sk_hprev_rows), db and dx with the GEMMs, and dh0/dc0

@@ -677,6 +677,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
             if (i + D < NR) ring[(i + D) % (D + 1)] = rd(i + D);
             const bf16x8 hv = ring[i % (D + 1)];
             const int q = i / 3;
+#ifdef SK_UNITS12_BOUND  // TIMING-ONLY (wrong numerics): three quarters of the product -- what a 12-unit workgroup would multiply
+            if ((q & 3) == 3) continue;
+#endif
             if (i % 3 == 0) {
               acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[q], hv, acc0, 0, 0, 0);  // hi  * lo
             } else if (i % 3 == 1) {
@@ -705,6 +708,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
         for (int q = 0; q < NQ; ++q) {
 #ifdef SK_TAIL_HALF
           if (tail && (q & 1)) continue;
+#endif
+#ifdef SK_UNITS12_BOUND
+          if ((q & 3) == 3) continue;
 #endif
           if (S3) {
             // SIX of the nine piece products per 32 k (see split3 above), the small ones first.  The piece that is needed first is
@@ -873,12 +879,10 @@ __device__ __forceinline__ void bwd_issue(const float* xbase, unsigned xoff, uns
 }
 
 // Register slice of W_hh^T of one wave: fp32 4 floats per chunk, bf16 8 bf16 (4 VGPRs) per chunk.
-// S3 (fp32, the split-product form, see lstm_bwd_s3_kernel): three bf16x8 pieces per PAIR of chunks (12 VGPRs per 32 k').
-template <int KS, bool BF, bool S3 = false>
+template <int KS, bool BF>
 struct BwdW {
-  float f[(BF || S3) ? 1 : 4 * BwdCfg<KS, BF>::NQ];
+  float f[BF ? 1 : 4 * BwdCfg<KS, BF>::NQ];
   bf16x8 b[BF ? BwdCfg<KS, BF>::NQ : 1];
-  bf16x8 p1[S3 ? BwdCfg<KS, BF>::NQ / 2 : 1], p2[S3 ? BwdCfg<KS, BF>::NQ / 2 : 1], p3[S3 ? BwdCfg<KS, BF>::NQ / 2 : 1];
 };
 
 // TIMING-ONLY diagnostic (-DSK_TAIL_HALF, `make variant NAME=tailhalf DEFS=-DSK_TAIL_HALF`; never shipped, WRONG numerics): an
@@ -891,43 +895,12 @@ struct BwdW {
 #define SK_TAIL_SKIP(j)
 #endif
 
-template <int KS, bool BF, int SBI, bool S3 = false>
-__device__ __forceinline__ void bwd_consume(const BwdW<KS, BF, S3>& W, const float* ring, int lane, f32x4& acc0, f32x4& acc1,
+template <int KS, bool BF, int SBI>
+__device__ __forceinline__ void bwd_consume(const BwdW<KS, BF>& W, const float* ring, int lane, f32x4& acc0, f32x4& acc1,
                                             bool tail) {
   using C = BwdCfg<KS, BF>;
   constexpr int n = C::cnt(SBI);
   const float* src = ring + (SBI % C::DEPTH) * C::SB * 256 + lane * 4;
-  if constexpr (S3) {
-    // Split products (r06): the fp32 dG fragments of TWO chunks (k' = 16 (2p) + 4 (lane>>4) + 0..3 and the same of chunk 2p + 1:
-    // the eight k' slots of this lane's v_mfma_f32_16x16x32_bf16 operand -- W's pieces were laid out with the same slot map) are
-    // cut into three bf16x8 pieces HERE, by the wave that multiplies them (every dG element is read by exactly one wave of the
-    // workgroup, so nothing is split twice inside it; 36 VALU instructions per pair, in the shadow of the other wave's products
-    // and of the sub-block DMAs), and the six piece products of size >= 2^-16 go to the bf16 matrix pipe: 96 instead of 256
-    // pipe cycles per 32 k'.  The exchange is untouched: 16 bytes per cell, fp32.  The next pair's reads are issued first.
-    static_assert(C::SB % 2 == 0 && n % 2 == 0, "pairs of chunks");
-    float4 ra[2], rb[2];
-    if (n > 0) {
-      ra[0] = *reinterpret_cast<const float4*>(src);
-      rb[0] = *reinterpret_cast<const float4*>(src + 256);
-    }
-#pragma unroll
-    for (int j = 0; j < n; j += 2) {
-      if (j + 2 < n) {
-        ra[((j >> 1) + 1) & 1] = *reinterpret_cast<const float4*>(src + (j + 2) * 256);
-        rb[((j >> 1) + 1) & 1] = *reinterpret_cast<const float4*>(src + (j + 3) * 256);
-      }
-      bf16x8 h1, h2, h3;
-      split3x8(ra[(j >> 1) & 1], rb[(j >> 1) & 1], h1, h2, h3);
-      const int q = (SBI * C::SB + j) >> 1;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.p1[q], h3, acc0, 0, 0, 0);  // hi  * lo
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.p2[q], h2, acc1, 0, 0, 0);  // mid * mid
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.p1[q], h2, acc0, 0, 0, 0);  // hi  * mid
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.p3[q], h1, acc1, 0, 0, 0);  // lo  * hi
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.p2[q], h1, acc0, 0, 0, 0);  // mid * hi
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W.p1[q], h1, acc1, 0, 0, 0);  // hi  * hi
-    }
-    return;
-  }
 #ifdef SK_BWD_BOUND38
   // TIMING-ONLY diagnostic (-DSK_BWD_BOUND38, never shipped, WRONG numerics): launches that pass mode bit 29 issue three of every
   // eight MFMAs of the product -- the matrix-pipe time six bf16 piece products would take (96 instead of 256 cycles per 32 k'),
@@ -956,6 +929,9 @@ __device__ __forceinline__ void bwd_consume(const BwdW<KS, BF, S3>& W, const flo
       if (j + 1 < n) rg[(j + 1) & 1] = *reinterpret_cast<const float4*>(src + (j + 1) * 256);
       const float4 db = rg[j & 1];
       const int q = SBI * C::SB + j;
+#ifdef SK_UNITS12_BOUND
+      if ((q & 3) == 3) continue;
+#endif
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 0], db.x, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 1], db.y, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(W.f[4 * q + 2], db.z, acc0, 0, 0, 0);
@@ -1006,14 +982,14 @@ __device__ __forceinline__ void bwd_prologue(const float* xbase, unsigned xoff, 
 
 // Sub-block I of the DEPTH-deep ring: wait until it has landed (only the DMAs of the next DEPTH-1 sub-blocks may
 // still be in flight), multiply, and refill its slot with sub-block I+DEPTH.
-template <int KS, bool BF, int I, bool S3 = false>
-__device__ __forceinline__ void bwd_ring(const BwdW<KS, BF, S3>& wreg, const float* xbase, unsigned xoff, float* ring,
+template <int KS, bool BF, int I>
+__device__ __forceinline__ void bwd_ring(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
                                          unsigned ring_lds, int w, int lane, f32x4& acc0, f32x4& acc1, bool tail) {
   using C = BwdCfg<KS, BF>;
   if constexpr (I < C::NSB) {
     constexpr int younger = bwd_younger<KS, BF>(I);
     wait_vmcnt<younger>();
-    bwd_consume<KS, BF, I, S3>(wreg, ring, lane, acc0, acc1, tail);
+    bwd_consume<KS, BF, I>(wreg, ring, lane, acc0, acc1, tail);
     if constexpr (I + C::DEPTH < C::NSB) {
       if constexpr (C::cnt(I + C::DEPTH) > 0) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // all reads of this ring slot returned before it is refilled
@@ -1021,7 +997,7 @@ __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF, S3>& wreg, const flo
         bwd_issue<KS, BF, I + C::DEPTH>(xbase, xoff, ring_lds, w, lane);
       }
     }
-    bwd_ring<KS, BF, I + 1, S3>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, tail);
+    bwd_ring<KS, BF, I + 1>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, tail);
   }
 }
 
@@ -1032,8 +1008,8 @@ __device__ __forceinline__ void bwd_ring(const BwdW<KS, BF, S3>& wreg, const flo
 __device__ __forceinline__ int red_slot(int m, int n) { return (m >> 1) * 32 + 16 * ((m ^ (m >> 2)) & 1) + n; }
 
 // Returns, for the cell-owning lanes, sum over all k' of dG * W for their (unit, batch).
-template <int KS, bool BF, bool S3 = false>
-__device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF, S3>& wreg, const float* xbase, unsigned xoff, float* ring,
+template <int KS, bool BF>
+__device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const float* xbase, unsigned xoff, float* ring,
                                             float (*red)[256], int w, int lane, bool tail = false) {
   // xbase: the exchange buffer (kernel argument: scalar), xoff: byte offset of this stream's block of the step (uniform)
   const unsigned ring_lds = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring);
@@ -1042,7 +1018,7 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF, S3>& wreg, const 
   // nothing may be scheduled into this region (the cell loads of the step were issued before it).
   __builtin_amdgcn_sched_barrier(0);
   bwd_prologue<KS, BF, 0>(xbase, xoff, ring_lds, w, lane);
-  bwd_ring<KS, BF, 0, S3>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, tail);
+  bwd_ring<KS, BF, 0>(wreg, xbase, xoff, ring, ring_lds, w, lane, acc0, acc1, tail);
   __builtin_amdgcn_sched_barrier(0);
   // D row m = 4*(lane>>4) + reg (out unit), col n = lane&15 (batch)
 #pragma unroll
@@ -1050,17 +1026,20 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF, S3>& wreg, const 
   __syncthreads();
   const int m = 4 * (w & 3) + (lane >> 4), n = lane & 15;  // the cell of this lane (owner waves: w < 4)
   float v = 0.f;
-  // S3, sign phases: the odd waves hold -W (negated when their slice was split) and deliver -S_k, so that the bf16 MFMA's
-  // truncation towards minus infinity pulls four of the eight partial sums down and four up (see lstm_fwd_kernel's reduce)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) v = (S3 && (k & 1)) ? v - red[k][red_slot(m, n)] : v + red[k][red_slot(m, n)];
+  for (int k = 0; k < 8; ++k) v += red[k][red_slot(m, n)];
   __syncthreads();
   return v;
 }
 
-// The kernel body; instantiated by lstm_bwd_kernel (fp32-MFMA / bf16 products, capped at 192 VGPRs) and lstm_bwd_s3_kernel below.
-template <int KS, bool BF, bool S3>
-__device__ __forceinline__ void lstm_bwd_body(const BwdArgs& a) {
+// Keep this kernel at 192 VGPRs or fewer (bias-gradient sums live in LDS for that reason): two waves per SIMD then leave 128 registers per lane for ONE co-resident GEMM wave (the
+// weight-gradient GEMMs of the layer above run next to this recurrence on the same CUs, sepkern/engine.py); at 200+
+// no GEMM block fits beside it and the co-scheduling is lost (measured: 39.3 -> 40.9 ms per step).
+// (r06: a split-product form of this kernel for the top layer's launch -- W_hh^T as three register pieces, dG split by the wave that
+// multiplies it, six bf16 piece products -- was built, parity-pinned and measured: its 36 VALU instructions per 32 k' cost what the
+// fp32 MFMAs they replace cost; not kept.  profiles/r06_bwd_split_top_layer.txt, the code: profiles/r06_bwd_split_top_layer.patch)
+template <int KS, bool BF>
+__global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) void lstm_bwd_kernel(BwdArgs a) {
   using C = BwdCfg<KS, BF>;
   constexpr int HP = 16 * KS, NQ = C::NQ;
   __shared__ __attribute__((aligned(16))) float ring_all[8][C::DEPTH * C::SB * 256];
@@ -1080,28 +1059,11 @@ __device__ __forceinline__ void lstm_bwd_body(const BwdArgs& a) {
 
   // ---- W_hh^T slice -> registers: A[m = out unit i][k'] = W_hh[gate r * H + unit_k][ug*16 + i]
   //      bf16: chunk cc holds k' = 32 cc + 8 (l>>4) + j, i.e. unit_k = 8 cc + 2 (l>>4) + (j>>2), gate j&3.
-  BwdW<KS, BF, S3> wreg;
+  BwdW<KS, BF> wreg;
   {
     const int i = lane & 15, kq = lane >> 4;
     const int uout = ug * 16 + i;
     const float* wbase = a.whh + (size_t)dir * 4 * H * H + uout;
-    if constexpr (S3) {
-      // the three bf16x8 pieces of the slice, per pair of chunks (slots 0..3: chunk 2p, 4..7: chunk 2p + 1 -- bwd_consume's map);
-      // odd waves hold -W (sign phases, bwd_matmul's reduce)
-      const float sg = (w & 1) ? -1.f : 1.f;
-#pragma unroll
-      for (int pp = 0; pp < NQ / 2; ++pp) {
-        float v[8];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int unit_k = 4 * (w * NQ + 2 * pp + c) + kq;
-          const bool ok = uout < H && unit_k < H;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * c + r] = ok ? sg * wbase[((size_t)r * H + unit_k) * H] : 0.f;
-        }
-        split3x8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), wreg.p1[pp], wreg.p2[pp], wreg.p3[pp]);
-      }
-    } else
 #pragma unroll
     for (int s = 0; s < NQ; ++s) {
       if (BF) {
@@ -1213,11 +1175,11 @@ __device__ __forceinline__ void lstm_bwd_body(const BwdArgs& a) {
         }
         SK_STAMP(0);
 #ifdef SK_TAIL_HALF
-        dh_rec = bwd_matmul<KS, BF, S3>(wreg, a.xbuf, xo, ring, red, w, lane, a.offs && B > 16 && s >= a.lens[16]);
+        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane, a.offs && B > 16 && s >= a.lens[16]);
 #elif defined(SK_BWD_BOUND38)
-        dh_rec = bwd_matmul<KS, BF, S3>(wreg, a.xbuf, xo, ring, red, w, lane, a.fast != 0);
+        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane, a.fast != 0);
 #else
-        dh_rec = bwd_matmul<KS, BF, S3>(wreg, a.xbuf, xo, ring, red, w, lane);
+        dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
 #endif
         SK_STAMP(2);
       }
@@ -1312,7 +1274,7 @@ __device__ __forceinline__ void lstm_bwd_body(const BwdArgs& a) {
       }
       __syncthreads();
       if (s_abort) return;
-      float dh_rec = bwd_matmul<KS, BF, S3>(wreg, a.xbuf, xo, ring, red, w, lane);
+      float dh_rec = bwd_matmul<KS, BF>(wreg, a.xbuf, xo, ring, red, w, lane);
       if (cellok) {
         dh_rec += st_carry[gi][oi];
         if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
@@ -1325,29 +1287,6 @@ __device__ __forceinline__ void lstm_bwd_body(const BwdArgs& a) {
     }
   }
 }
-
-// Keep this kernel at 192 VGPRs or fewer (bias-gradient sums live in LDS for that reason): two waves per SIMD then leave 128 registers per lane for ONE co-resident GEMM wave (the
-// weight-gradient GEMMs of the layer above run next to this recurrence on the same CUs, sepkern/engine.py); at 200+
-// no GEMM block fits beside it and the co-scheduling is lost (measured: 39.3 -> 40.9 ms per step).
-template <int KS, bool BF>
-__global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) void lstm_bwd_kernel(BwdArgs a) {
-  lstm_bwd_body<KS, BF, false>(a);
-}
-
-// The split-product form of the fp32 backward recurrence (r06, mode bit 28; KS = 56: 608 < H <= 896): dh = dG W_hh by the exact
-// three-way bf16 split of both operands on the bf16 matrix pipe, six piece products per element pair (the forward kernel's S3
-// arithmetic: an fp32 product in another summation order) -- 96 instead of 256 pipe cycles per 32 k', MFMA floor of a step 1.12
-// instead of 2.99 us.  W_hh^T is split once per launch into register pieces (168 instead of 112 VGPRs, so this kernel has NO
-// 192-register cap and no GEMM wave fits beside it: it is for launches that host nothing -- the engine passes the bit for the TOP
-// layer, whose side stream carries only the Linear layer's small weight gradient, which the 32 CUs outside the grid take); dG
-// travels as fp32 exactly as before and is split by the wave that multiplies it (bwd_consume).  Bound measured first
-// (profiles/r06_bwd_split_top_layer.txt: three of eight MFMAs issued, pieces for free): top layer alone -0.56 ms per training
-// step; every layer -1.8 ms, but the hosted layers would lose their co-resident weight-gradient GEMMs to the registers.
-template <int KS>
-__global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_s3_kernel(BwdArgs a) {
-  lstm_bwd_body<KS, false, true>(a);
-}
-
 
 // Rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g*H + u inside each block of 4H rows: the
 // order of weight_ih / weight_hh / bias rows, gates i,f,g,o) and the recurrence's gate-interleaved order (row 4u + g).
@@ -1425,11 +1364,7 @@ int dispatch_fwd(int KS, bool bf, const FwdArgs& a, int nblocks, hipStream_t st)
     default: return launch_fwd<64, false>(a, nblocks, st);
   }
 }
-int dispatch_bwd(int KS, bool bf, const BwdArgs& a, dim3 grid, hipStream_t st, bool s3 = false) {
-  if (s3 && !bf && KS == 56) {
-    hipLaunchKernelGGL((lstm_bwd_s3_kernel<56>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
-    return 0;
-  }
+int dispatch_bwd(int KS, bool bf, const BwdArgs& a, dim3 grid, hipStream_t st) {
   if (bf) switch (KS) {
       case 20: return launch_bwd<20, true>(a, grid, st);
       case 40: return launch_bwd<40, true>(a, grid, st);
@@ -1481,6 +1416,9 @@ unsigned sk_lstm_build_flags() {
   f |= SK_BUILD_TIMING_ONLY;
 #endif
 #ifdef SK_BWD_BOUND38
+  f |= SK_BUILD_TIMING_ONLY;
+#endif
+#ifdef SK_UNITS12_BOUND
   f |= SK_BUILD_TIMING_ONLY;
 #endif
 #ifdef SK_LSTM_STAMPS
@@ -1579,7 +1517,6 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, 
   const int map = ((mode >> 18) & 3) | (((mode >> 22) & 1) << 2);
   int poll_delay = (mode >> 23) & 31;  // as sk_lstm_fwd; 0 = none here until measured otherwise
   const int fast = (mode >> 29) & 1;   // (diagnostic builds only, BwdArgs::fast)
-  const bool s3 = (mode >> 28) & 1;    // bit 28 (fp32, KS = 56): the split-product form, for launches that host no GEMM
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -1606,16 +1543,16 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, 
     SK_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)L.NBG * 8 * H * sizeof(float), st));  // rows >= grid y stay 0
   if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;
-    dispatch_bwd(L.KS, bf, a, grid, st, s3);
+    dispatch_bwd(L.KS, bf, a, grid, st);
   } else {
     a.final_mm = 0;  // a step launch never waits on other workgroups
     for (int s = 0; s < T; ++s) {
       a.s_begin = s; a.s_end = s + 1;
-      dispatch_bwd(L.KS, bf, a, grid, st, s3);
+      dispatch_bwd(L.KS, bf, a, grid, st);
     }
     if (want_d0) {
       a.s_begin = T; a.s_end = T; a.final_mm = 1;
-      dispatch_bwd(L.KS, bf, a, grid, st, s3);
+      dispatch_bwd(L.KS, bf, a, grid, st);
     }
   }
   SK_CHECK_LAUNCH("sk_lstm_bwd");

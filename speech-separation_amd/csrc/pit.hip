@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int MAXS = 4;
-constexpr int TCH = 16;  // frames per block in the pairwise pass
+constexpr int TCH = 8;   // frames per block in the pairwise pass (r06: 8 instead of 16 -- 1600 blocks for 32 x 400 frames, ~6 per CU)
 constexpr int RB = 4;    // (frame, utterance) rows per block in the backward pass
 
 struct SrcPtrs {
@@ -37,8 +37,12 @@ __global__ __launch_bounds__(256) void pit_pair_kernel(const float* __restrict__
   // the chunk's frames x bins as one flat range, so that F = 257 does not leave a nearly empty second sweep
   const int Tb = offs ? min(T, lens[b]) : T;  // packed rows end with the utterance
   const int t0 = ch * TCH, nel = max(0, min(Tb, t0 + TCH) - t0) * F;
+  // (frame, bin) of element i = threadIdx.x + 256 k, carried along instead of divided out: an integer division by the run-time F
+  // per element cost more instructions than the element's arithmetic (r06: 26.5 -> see profiles/r06*_bench.json aux.pit_fwd)
+  int dt = threadIdx.x / F, f = threadIdx.x - dt * F;
+  const int dstep = 256 / F, fstep = 256 - dstep * F;
+#pragma unroll 2
   for (int i = threadIdx.x; i < nel; i += 256) {
-    const int dt = i / F, f = i - dt * F;
     const int64_t row = (offs ? (int64_t)offs[t0 + dt] : (int64_t)(t0 + dt) * B) + b;
     const float mx = mix[row * F + f];
     float sv[S];
@@ -52,6 +56,12 @@ __global__ __launch_bounds__(256) void pit_pair_kernel(const float* __restrict__
         const float d = mm - sv[r];
         acc[s][r] += d * d;
       }
+    }
+    dt += dstep;
+    f += fstep;
+    if (f >= F) {
+      f -= F;
+      ++dt;
     }
   }
 #pragma unroll

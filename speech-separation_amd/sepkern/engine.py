@@ -133,12 +133,6 @@ class Engine:
         self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0,0,0" if self.bf16 else
                                 ("0,1,1,0,0,0,0,1" if hidden <= 896 else "0,1,1,0,0,8,1,0"))
         self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31,0,0")
-        # r06: the TOP layer's backward recurrence hosts no weight-gradient GEMM of a layer above (only the Linear layer's small
-        # one, which the CUs outside the persistent grid take), so the 192-register cap that keeps a GEMM wave co-resident buys
-        # nothing there: that launch takes the split-product form of the kernel (mode bit 28: dh = dG W_hh on the bf16 matrix pipe by
-        # the exact three-way split, six piece products, as the forward recurrence; 608 < H <= 896, else the library ignores the
-        # bit).  SEPKERN_LSTM_BWD_TOP=0: the fp32-MFMA kernel there too.
-        self.bwd_top_split = os.environ.get("SEPKERN_LSTM_BWD_TOP", "1") != "0" and not self.bf16 and 608 < hidden <= 896
         self.split3_fwd = bool(self.fwd_bits & 0x10000000) and not self.bf16 and hidden <= 896
         self.tagged_fwd = bool(self.fwd_bits & 0x20000000) and not self.bf16 and not self.split3_fwd
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one: the
@@ -523,8 +517,6 @@ class Engine:
             mode = self.lstm_mode | self.bwd_bits
             if self.bwd_diag == 2 or (self.bwd_diag == 1 and l == L - 1):
                 mode |= 0x20000000
-            if self.bwd_top_split and l == L - 1:
-                mode |= 0x10000000
             sl = slice(2 * l, 2 * l + 2)
             nbg = (B + 15) // 16
             dbias = torch.empty(nbg, 8 * H, device=dev)      # by-product of the recurrence: bias-gradient partials

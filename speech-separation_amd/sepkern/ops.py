@@ -589,9 +589,8 @@ def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, sprea
     """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..29);
     poll_delay: the forward kernel's polling wave holds its first poll of a step back (units of 0.1 us, 0 = the library's
     choice, 31 = none); tagged (forward, fp32): the exchanged h carries the step's epoch in its two low mantissa bits and
-    nothing else is signalled (mode bit 29); split3 (fp32): the recurrent product by the exact three-way bf16 split of both
-    operands on the bf16 matrix pipe (mode bit 28; forward: flags hand-off, the tagged one does not combine with it; backward:
-    the form for launches that host no GEMM, 608 < H <= 896)."""
+    nothing else is signalled (mode bit 29); split3 (forward, fp32): the product h W_hh^T by the exact three-way bf16 split
+    of both operands on the bf16 matrix pipe (mode bit 28; flags hand-off, the tagged one does not combine with it)."""
     if half:      # (the first field of SEPKERN_LSTM_FWD / _BWD keeps its place so that recorded switch strings stay readable)
         raise _lib.SepkernError("the 8-unit / 256-thread forward recurrence (field `half`, mode bit 17) was retired in r05: "
                                 "measured slower at every shape (DESIGN_HISTORY.md)")
@@ -624,9 +623,7 @@ def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=N
     _chk(dgx_bf16, torch.bfloat16)
     if dgx_bf16 is not None and (dgx_bf16.dim() != 2 or dgx_bf16.stride(1) != 1):
         raise _lib.SepkernError("lstm_bwd: the bf16 twin must be a row-major (rows, ld) matrix")
-    # (mode bit 28, fp32, 608 < H <= 896: the split-product form -- another matrix pipe, its own class in the profile)
-    s3 = bool(mode & 0x10000000) and not bf16 and 608 < H <= 896
-    with _timed("lstm_bwd_s3_kernel" if s3 else "lstm_bwd_kernel", 2.0 * (T * B if rows is None else rows) * 2 * 4 * H * H):
+    with _timed("lstm_bwd_kernel", 2.0 * (T * B if rows is None else rows) * 2 * 4 * H * H):
         _lib.call("sk_lstm_bwd", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
                   _ptr(lens), _ptr(offs), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(dbias), _ptr(dgx_bf16),
                   0 if dgx_bf16 is None else dgx_bf16.stride(0), _ptr(ws), T, B, H, mode, _stream())

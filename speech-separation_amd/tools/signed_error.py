@@ -220,8 +220,7 @@ def main():
             bref = lstm_bwd_fp64(*inp, dy)
             if f:
                 torch.save(bref, f)
-        for name, bits in (("bwd split (top layer)", ops.lstm_variant_bits(False, 1, split3=True, poll_delay=31)),
-                           ("bwd fp32 MFMA", ops.lstm_variant_bits(False, 1, poll_delay=31))):
+        for name, bits in (("bwd fp32 MFMA", ops.lstm_variant_bits(False, 1, poll_delay=31)),):
             r = lstm_bwd_case(ops, *inp, dy, bref, bits)
             print("    %-22s dgx %+.2e / %.2e (mean signed / mean |dgx|, rel-L2)   dh0 %+.2e / %.2e" % (
                 name, r["dgx_mean_signed"], r["dgx_rel_l2"], r["dh0_mean_signed"], r["dh0_rel_l2"]))

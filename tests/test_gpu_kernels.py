@@ -629,7 +629,6 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, layout, T, B, H, I, lens):
     y = rw.new(2 * H)
     cs = rw.new(2 * H)
     hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
-    gx_pre = gx.clone()                                               # (the forward overwrites gx with the gates, the backward with dgx)
     ws = ops.lstm_fwd(gx, whh, dev(h0), dev(c0), rw.lens, y, gx, cs, hn, cn, T, B, H, mode, offs=rw.offs)
     ops.lstm_status(ws)
     tol = dict(rtol=2e-5, atol=2e-6)
@@ -647,26 +646,6 @@ def test_lstm_layer_fwd_bwd_matches_oracle(ops, mode, layout, T, B, H, I, lens):
     gtol = dict(rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(dh0.cpu().numpy(), h0r.grad.numpy(), **gtol)
     np.testing.assert_allclose(dc0.cpu().numpy(), c0r.grad.numpy(), **gtol)
-    if H == 896:
-        # the split-product form of the backward kernel (mode bit 28; what the engine launches for the top layer): same gates, not
-        # the same bits as the fp32-MFMA kernel, reproducible, equal in the other launch mode
-        s3 = ops.lstm_variant_bits(False, 0, split3=True)
-        outs = []
-        for m in (mode, mode, 3 - mode):
-            gsv, cs2 = gx_pre.clone(), rw.new(2 * H)
-            ops.lstm_fwd(gsv, whh, dev(h0), dev(c0), rw.lens, rw.new(2 * H), gsv, cs2, None, None, T, B, H, mode, offs=rw.offs)
-            d2, e2 = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
-            ws2 = ops.lstm_bwd(rw.put(dy), whh, gsv, cs2, dev(c0), rw.lens, gsv, d2, e2, T, B, H, m | s3, dhn=dev(dhn), dcn=dev(dcn),
-                               offs=rw.offs)
-            ops.lstm_status(ws2)
-            outs.append((gsv, d2, e2))
-        np.testing.assert_allclose(outs[0][1].cpu().numpy(), h0r.grad.numpy(), **gtol)
-        np.testing.assert_allclose(outs[0][2].cpu().numpy(), c0r.grad.numpy(), **gtol)
-        rows_ok = slice(0, rw.pk.R) if rw.packed else slice(None)
-        for a_, b_, c_ in zip(*outs):
-            assert torch.equal(a_[rows_ok], b_[rows_ok]) and torch.equal(a_[rows_ok], c_[rows_ok])
-        assert not torch.equal(outs[0][1], dh0)                              # (another summation order than the fp32-MFMA kernel's)
-        np.testing.assert_allclose(outs[0][0][rows_ok].cpu().numpy(), gx[rows_ok].cpu().numpy(), rtol=2e-4, atol=2e-6)
     dgx_pad = rw.get(gx, 8 * H).contiguous()                         # (T, B, 8H), zero at padded positions in either layout
     if rw.packed:
         assert bool((dgx_pad[~rw.valid] == 0).all())
