@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SK_VERSION 130
+#define SK_VERSION 131
 
 #define SK_OK 0
 #define SK_EINVAL (-1)   /* bad argument / unsupported shape */
@@ -135,7 +135,8 @@ size_t sk_gemm_workspace_bytes(int M, int N, int batch, int splitk);
  * launch against the peak of the matrix pipe it ran on; tests/test_gpu_census.py generates DESIGN.md's kernel census from it):
  * 1 register-staged fp32 MFMA, 3 / 4 / 6 the 128 x 128 / 256 x 128 / stream-K fp32-MFMA LDS-DMA kernels, 2 / 10 the 128 x 128 /
  * 256 x 128 split-while-staging SPLIT kernels (bf16 pipe, six piece products), 9 bf16 inputs (fp32 operands rounded on the way
- * in); sk_gemm_bf16_nt / _mm: 11 / 12 the 256 x 128 / 256 x 256-tile bf16-operand kernel, 13 its stream-K form; 0 before the first launch.
+ * in); sk_gemm_bf16_nt / _mm: 11 / 12 the 256 x 128 / 256 x 256-tile bf16-operand kernel, 13 its stream-K form; sk_gemm_pl3_tn: 14;
+ * 0 before the first launch.
  * A thread-local read-back: with the error string of sk_last_error() the library's only mutable state that is not a caller's
  * buffer (SURVEY 8b's rule has these two exceptions, both thread-local and neither read by any kernel or launch decision). */
 int sk_gemm_last_kernel(void);
@@ -181,6 +182,25 @@ int sk_gemm_bf16_nt(const void* A, const void* B, float* C, const float* bias, i
 int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const float* bias, int M, int N, int K, int lda, int ldb,
                     int ldc, int a_kmajor, int b_kmajor, int accumulate, int act, int batch, int64_t sA, int64_t sB,
                     int64_t sC, int64_t sbias, int splitk, void* ws, sk_stream_t stream);
+/* ---------------------------------------------------------------- operands that arrive split (r06)
+ * The weight gradients of the training step are T/N products of activation / gradient matrices whose ROWS are the contraction
+ * index.  As fp32 split products (sk_gemm_f32_splitk variant 2) every wave of the GEMM cuts the fragments it reads into their
+ * three bf16 pieces -- each element twice per workgroup, and beside a persistent recurrence that VALU work and the longer launch
+ * are taken from the recurrence too.  Here the PRODUCERS cut each operand once: sk_split_rows (layer inputs, recurrent inputs),
+ * sk_lstm_bwd's plane_bf16 (dgx); sk_gemm_pl3_tn multiplies the planes.
+ * sk_split_rows: dst plane p (p = 0 hi, 1 mid, 2 lo; `plane` elements apart), row r, column c = piece p of src[r][c] (pieces by
+ * rounding to nearest even, exactly the pieces the split kernels make); zeros for C <= c < ld_dst and for rows R .. R_pad - 1.
+ * ld_dst % 8 == 0, plane >= R_pad * ld_dst and % 8 == 0, dst 16-byte aligned. */
+int sk_split_rows(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, int R_pad, int64_t plane, sk_stream_t stream);
+/* C[M,N] (+)= A^T B on operands that arrive split: A = three bf16 planes [K][lda] (element (k, m) of plane p at
+ * Apl[p * planeA + k * lda + m]), B likewise [K][ldb]; fp32 accumulation of the six piece products per element pair with the sign
+ * phases of the split kernels -- bit for bit sk_gemm_f32_splitk variant 2 on the fp32 matrices the planes were cut from.  K % 16 ==
+ * 0 (zero tail rows in the planes), lda / ldb / planeA / planeB / sA / sB multiples of 8 elements, lda >= M rounded up to 8 (+ the
+ * batch offset), planes 16-byte aligned; batch, splitk / ws (zero-filled once) as sk_gemm_f32_splitk.  128 x 128 tiles, 120
+ * VGPRs, 48 KB of LDS: meant to run beside a persistent recurrence (and alone). */
+int sk_gemm_pl3_tn(const void* Apl, const void* Bpl, float* C, int M, int N, int K, int lda, int ldb, int ldc, int64_t planeA,
+                   int64_t planeB, int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC, int splitk, void* ws,
+                   sk_stream_t stream);
 /* dst[r][c] = bf16(src[r][c]) (round to nearest even) for r < R, c < C; 0 for C <= c < ld_dst and for the rows
  * R .. R_pad-1 (R_pad >= R): a copy that also serves as a K-MAJOR factor of sk_gemm_bf16_mm (its rows are then the
  * contraction index, read in whole K steps of 64).  ld_dst % 8 == 0. */
@@ -245,7 +265,13 @@ int sk_hprev_rows(const float* y, int ldy, const float* h0, const int32_t* offs,
  * bit 29 (fp32 forward; not together with bit 28): "the data is the flag" -- every exchanged h word carries the step's epoch
  * in its two low mantissa bits, producers publish without drain / barrier / flag, consumers hold back, pull, check every word
  * and pull again what was not complete; the next step's product runs on the tagged words (<= 3 ulp = 3.6e-7 relative),
- * everything stored (y, gates, cs, states) is exact.  The r03 default; still the engine's choice for H > 896. */
+ * everything stored (y, gates, cs, states) is exact.  The r03 default; still the engine's choice for H > 896;
+ * bit 30 (bf16 forward with bit 16, persistent launches, 608 < H <= 896, B <= 32, a device of 8 XCDs x 32 CUs; ignored otherwise;
+ * r06): XCD-LOCAL streams of 8 rows -- every (direction, 8-row batch group) stream is 28 workgroups of 32 hidden units on ONE
+ * XCD, h_t published with plain stores and a plain flag (within an XCD the L2 is the coherence point; polls and pulls stay sc1),
+ * 14 KB instead of 28 KB pulled per workgroup and step.  Same arithmetic bit for bit.  A workgroup joins the stream of the XCD it
+ * runs on (HW_REG_XCC_ID + one counter per XCD): no dependence on the order in which blocks are dealt; an XCD that received fewer
+ * than 28 workgroups ends in the bounded-spin status word (sk_lstm_status: SK_ETIMEOUT, the step is skipped). */
 size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 const int32_t* offs, float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
@@ -262,11 +288,14 @@ int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float*
  *   dgx_bf16 (the bf16 configuration) dgx a second time as bf16, dgx_bf16[row ld_bf16 + d 4H + 4u + g]: the row-major
  *            operand copy the layer's data- and weight-gradient products read, so that no cast pass over dgx runs between
  *            the recurrence and those products.  ld_bf16 >= 8H, a multiple of 4; only the rows x 8H entries are written:
- *            padding columns / rows a product expects to be zero are the caller's. */
+ *            padding columns / rows a product expects to be zero are the caller's.
+ *            plane_bf16 = 0: that one rounded copy.  plane_bf16 > 0 (the fp32 configuration, r06): dgx_bf16 receives THREE planes
+ *            plane_bf16 elements apart -- the exact hi / mid / lo bf16 pieces of every dgx value (x = hi + mid + lo, see
+ *            sk_gemm_f32_splitk variant 0), split ONCE here by the lane that computed the value: the operand sk_gemm_pl3_tn reads. */
 int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
                 const float* cs, const float* c0, const int32_t* lens, const int32_t* offs, float* dgx, float* dh0,
-                float* dc0, float* dbias, void* dgx_bf16, int ld_bf16, void* ws, int T, int B, int H, int mode,
-                sk_stream_t stream);
+                float* dc0, float* dbias, void* dgx_bf16, int ld_bf16, int64_t plane_bf16, void* ws, int T, int B, int H,
+                int mode, sk_stream_t stream);
 /* Reorder the rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g H + u inside each block of 4H
  * rows) and the gate-interleaved order of gx / gates / dgx (row 4u + g).  back = 0: dst[4u+g] = src[gH+u] (weights,
  * biases -> interleaved); back = 1: dst[gH+u] (+)= src[4u+g] (weight gradients back to the parameter order,

@@ -1,0 +1,51 @@
+#!/bin/bash
+# r06, fourth GPU call: operands that arrive split (weight gradients on planes) -- parity, then A/B in the step; the RSH 12-unit
+# bound (timing-only); the streaming kernels after the PIT pair-kernel change.
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out
+S=$R/speech-separation_amd/sepkern
+cd $R
+timeout -k 10 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py -m gpu -x -q -k "arrive_split or twin or pit or reference or configs_match or train or xcd_local" > $O/r06d_tests.log 2>&1; rc=$?; echo "pytest rc $rc" | tee -a $O/r06d_tests.log; tail -5 $O/r06d_tests.log
+[ $rc = 0 ] || exit 1
+OUT=$O/r06_wgrad_planes.txt
+: > $OUT
+line() { python -c "
+import json,sys
+l=[x for x in sys.stdin.read().strip().splitlines() if x.startswith('{')]
+if not l: print('$1: no line'); sys.exit(0)
+d=json.loads(l[-1]); k=d['kernels']
+print('%-10s %.3f ms/step  loss %.6f  ' % ('$1', d['ms_per_step'], d['config']['mean_loss']) + '  '.join('%s %.2f' % (n, v['ms_per_step']) for n, v in k.items()))
+"; }
+for i in 1 2 3; do
+  SEPKERN_WGRAD_PLANES=0 timeout -k 10 200 python bench.py --no-cpu-baseline --no-secondary --no-aux --no-power-probe --steps 20 --warmup 3 2>/dev/null | line fp32ops | tee -a $OUT
+  timeout -k 10 200 python bench.py --no-cpu-baseline --no-secondary --no-aux --no-power-probe --steps 20 --warmup 3 2>/dev/null | line planes | tee -a $OUT
+done
+for name in fp32ops planes fp32ops planes; do
+  v=1; [ $name = fp32ops ] && v=0
+  SEPKERN_WGRAD_PLANES=$v timeout -k 10 200 python bench.py --no-cpu-baseline --no-secondary --no-aux --no-power-probe --ragged --steps 20 --warmup 3 2>/dev/null | python -c "
+import json,sys
+d=json.loads([x for x in sys.stdin.read().splitlines() if x.startswith('{')][-1])
+print('ragged %-9s %.3f ms/step  %.0f valid frames/s  ' % ('$name', d['ms_per_step'], d['value']) + '  '.join('%s %.2f' % (n, v['ms_per_step']) for n, v in d['kernels'].items()))
+" | tee -a $OUT
+done
+for name in fp32ops planes; do
+  v=1; [ $name = fp32ops ] && v=0
+  SEPKERN_WGRAD_PLANES=$v timeout -k 10 200 python bench.py --no-cpu-baseline --no-secondary --no-aux --no-power-probe --arch rsh --hidden 600 --layers 2 --num-spk 4 --steps 10 --warmup 2 2>/dev/null | line rsh_$name | tee -a $OUT
+done
+OUT3=$O/r06_bf16_xl8.txt
+: > $OUT3
+timeout -k 10 200 python speech-separation_amd/tools/lstm_bench.py --bf16 --rounds 5 --fwd "0,1,1,0,0,1,0,0,0,0;0,1,1,0,0,1,0,0,0,1;0,1,1,0,0,1,4,0,0,1;0,1,1,0,0,1,2,0,0,1;0,1,1,0,0,1,31,0,0,1" --bwd "0,1" 2>&1 | grep -v amdgpu.ids | tee -a $OUT3
+timeout -k 10 200 python speech-separation_amd/tools/lstm_bench.py --bf16 --ragged --rounds 5 --fwd "0,1,1,0,0,1,0,0,0,0;0,1,1,0,0,1,0,0,0,1" --bwd "0,1" 2>&1 | grep -v amdgpu.ids | tee -a $OUT3
+for i in 1 2; do
+  SEPKERN_LSTM_FWD=0,1,1,0,1,0,0,0,0 timeout -k 10 200 python bench.py --dtype bf16 --num-spk 3 --no-cpu-baseline --no-secondary --no-aux --no-power-probe --steps 20 --warmup 3 2>/dev/null | line bf16 | tee -a $OUT3
+  timeout -k 10 200 python bench.py --dtype bf16 --num-spk 3 --no-cpu-baseline --no-secondary --no-aux --no-power-probe --steps 20 --warmup 3 2>/dev/null | line bf16_xl8 | tee -a $OUT3
+done
+OUT2=$O/r06_rsh_idle_cus.txt
+: > $OUT2
+for i in 1 2; do
+  timeout -k 10 200 python bench.py --no-cpu-baseline --no-secondary --no-aux --no-power-probe --arch rsh --hidden 600 --layers 2 --num-spk 4 --steps 10 --warmup 2 2>/dev/null | line rsh | tee -a $OUT2
+  SEPKERN_ALLOW_DIAGNOSTIC_LIB=1 SEPKERN_LIB=$S/libsepkern_units12.so timeout -k 10 200 python bench.py --diagnostic --no-cpu-baseline --no-secondary --no-aux --no-power-probe --arch rsh --hidden 600 --layers 2 --num-spk 4 --steps 10 --warmup 2 2>/dev/null | line rsh_u12 | tee -a $OUT2
+done
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-secondary --steps 10 > $O/r06d_bench.json 2> $O/r06d_bench.err; echo "bench rc $?"; python -c "
+import json; d=json.load(open('$O/r06d_bench.json')); print(d['ms_per_step'], {k:(v['us_per_launch'], v['frac_of_hbm_peak']) for k,v in d['aux'].items() if k!='note'})"

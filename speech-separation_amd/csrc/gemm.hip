@@ -51,6 +51,11 @@ struct GemmArgs {
   int64_t sA, sB, sC, sbias;
   int sk_tiles, sk_full;  // stream-K kernel: tiles of the product, data-parallel rounds before the stream-K region
   int flip_q;             // split-product kernels: quarter period of the sign phases in K steps of BK (0: none), see SignPhase
+  // gemm_f32_kernel_pl3 (operands that arrive split): the three bf16 planes of each operand, K-major ([K][dim], lda / ldb
+  // elements between k rows), planeA / planeB elements from one plane to the next; A / B above are unused
+  const __bf16* Apl;
+  const __bf16* Bpl;
+  int64_t planeA, planeB;
 };
 constexpr size_t COUNTER_BYTES = 65536;  // head of a split-K workspace: 16384 counters
 
@@ -588,10 +593,11 @@ struct Split3 {
   bf16x8_t hi, mid, lo;
 };
 
-// Pieces by ROUND-TO-NEAREST (v_cvt_pk_bf16_f32): hi = bf16(x), r = x - hi (exact: a multiple of ulp(x), |r| <= 2^-9 |x|),
-// mid = bf16(r), lo = r - mid (exact, |lo| <= 2^-9 |r| <= 2^-18 |x|, at most 8 significant bits: IS a bf16).  (r04 cut by
+// Pieces by ROUND-TO-NEAREST (v_cvt_pk_bf16_f32): hi = bf16(x), r = x - hi (exact: a multiple of ulp(x); bf16 has 8 significand
+// bits, so |r| <= 2^-8 |x|), mid = bf16(r), lo = r - mid (exact, |lo| <= 2^-8 |r| <= 2^-16 |x|, at most 8 significant bits: IS a
+// bf16).  (r04 cut by
 // truncation: one instruction fewer per pair, but then |mid| < 2^-7 |x|, |lo| < 2^-15 |x| and all pieces share x's sign -- the
-// products left out below were up to 2^-21 of a b and a systematic shrink; rounded pieces make them <= 2^-26 and signless.)
+// products left out below were up to 2^-21 of a b and a systematic shrink; rounded pieces make them <= 2^-23 and signless.)
 // Operands beyond bf16's finite range (|x| > 3.39e38) round to inf.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Split3 split3(const float (&v)[8]) {
@@ -888,10 +894,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_streamk(GemmArgs g) {
 // fp32 product on the bf16 matrix pipe by an EXACT three-way split of both operands (variant 2 of sk_gemm_f32_splitk; what
 // variant 0 chooses for every product with aligned operands -- r05).
 // Every fp32 operand element x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits = 3 x 8; pieces by
-// rounding to nearest, see split3() above: |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|).  a*b is the sum of the nine piece products,
-// each exact in fp32 (8 x 8 bits), of relative sizes 1, 2^-9 (two), 2^-18 (three), 2^-27 (two), 2^-36.  The kernel forms the
-// SIX of size >= 2^-18 and the matrix cores add them into the same fp32 accumulators as always; the three it leaves out are
-// together <= 2^-26 of a*b -- a quarter of the half ulp an fp32 multiplier rounds away itself, and far below the rounding of
+// rounding to nearest, see split3() above: |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|).  a*b is the sum of the nine piece products,
+// each exact in fp32 (8 x 8 bits), of relative sizes 1, 2^-8 (two), 2^-16 (three), 2^-24 (two), 2^-32.  The kernel forms the
+// SIX of size >= 2^-16 and the matrix cores add them into the same fp32 accumulators as always; the three it leaves out are
+// together <= 2^-23 |a||b| in the worst case -- one ulp of the product: a SINGLE product may be off by about an ulp where an fp32
+// FMA is exact (typical pieces: a quarter of that), which is at the level of the rounding of
 // the fp32 accumulation that follows.  So this is an fp32 GEMM in another summation order, not a lower-precision one (tests:
 // error against fp64 not above the fp32-MFMA kernel's on operands spanning 2^+-20; single products within 1 ulp, exact when
 // both factors have <= 16 significant bits).  Six v_mfma_f32_32x32x16_bf16 (8 passes each, K = 16) replace eight
@@ -1341,6 +1348,186 @@ __global__ __launch_bounds__(512, 2) void gemm_f32_kernel_planes(GemmArgs g) {
     }
   }
   store_tile(g, acc, g.C, g.ldc, g.bias, false, m0 + wm * 64, n0 + wn * 64, lane);
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// Operands that ARRIVE split (r06; sk_gemm_pl3_tn): the T/N product C[M][N] = sum_k A[k][m] B[k][n] -- every weight gradient of
+// the training step: both factors are activation / gradient matrices whose ROWS are the contraction index -- on operands their
+// PRODUCERS already cut into the three bf16 pieces (three planes [K][dim] per operand: the backward recurrence writes dgx's with
+// the fp32 values, sk_split_rows / sk_hprev_rows the layer inputs' and the recurrent inputs').  gemm_f32_kernel_split3 stages fp32
+// tiles and every wave splits the fragments it reads -- each element twice per workgroup, 4.5 VALU instructions each time, ~22 %
+// of that kernel's time and, beside a recurrence, VALU slots and matrix-pipe time taken from its host
+// (profiles/r05_hosted_split_free_upper_bound.txt: -0.9 ms per training step with the pieces for free).  Here the plane tiles are
+// DMA'd into LDS as they lie (24 KB per K step instead of 16: 6 bytes per element instead of 4) and the waves read ready-made
+// bf16x8 fragments by the transposed LDS read (ds_read_b64_tr_b16, the planes kernel's K-major image and swizzle) and issue the
+// six MFMAs per fragment pair: NO VALU work in the K loop but the sign phases' 24 v_xor in negative stretches.  Same pieces, same
+// products, same K order, same sign phases as gemm_f32_kernel_split3: bit-identical results (tests).  128 x 128 tiles, 4 waves of
+// 64 x 64, two stages (48 KB of LDS), <= 128 VGPRs: it fits on a CU beside a persistent recurrence workgroup.  Split-K slices and
+// batches (the two directions of dW_hh) as in the other kernels.
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel_pl3(GemmArgs g) {
+  constexpr int PTILE = BK * BM * 2;  // 4 KB: one plane of one operand tile, [16 k][128 dims] bf16
+  constexpr int OPER = 3 * PTILE, STAGE = 2 * OPER;
+  constexpr int NST = 2;
+  constexpr int ROWB = 2 * BM;        // bytes of a k row in an LDS plane
+  __shared__ __attribute__((aligned(1024))) char lds[NST][STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  int tile = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt >> 3, rem = nt & 7, x = tile & 7, j = tile >> 3;
+    tile = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + j;
+  }
+  int m0, n0;
+  {
+    const int tilesM = gridDim.x / g.tilesN, per = GROUP_M * g.tilesN;
+    const int grp = tile / per, rem2 = tile - grp * per, first = grp * GROUP_M;
+    const int gsz = min(GROUP_M, tilesM - first);
+    m0 = (first + rem2 % gsz) * BM;
+    n0 = (rem2 / gsz) * BN;
+  }
+  const int z = blockIdx.z, ks = blockIdx.y;
+  const bool partial = g.splitk > 1;
+  float* C = partial ? g.slabs + ((int64_t)z * g.splitk + ks) * g.M * g.N : g.C + z * g.sC;
+  const int ldc = partial ? g.N : g.ldc;
+  const float* bias = (g.bias && !partial) ? g.bias + z * g.sbias : nullptr;
+  const int kbeg = ks * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+  const int nk = (kend - kbeg) / BK;
+
+  // ---- staging.  One DMA instruction = 1 KB = four k rows of one plane tile (16 lanes x 16 B per row).  Lane (kr = lane >> 4,
+  // j = lane & 15) fetches, for k row 4 kq + kr, the 16 bytes that belong at position j of the row's LDS image: the image keeps
+  // the 32-byte chunk c (16 dims) of k row r at chunk c ^ 2 (r & 3) (the transposed fragment reads of a half-wave then fall on 8
+  // different bank groups), and r & 3 = kr whatever kq is -- so a lane's offset inside a piece is the same for all 24 pieces of
+  // an operand and the piece itself (plane, k quad, K step) is a wave-uniform base address.  Dims past the operand's edge are
+  // clamped into its padded row (their products land in columns the epilogue masks).
+  const int kr = lane >> 4, jp = lane & 15;
+  const int dim = 16 * ((jp >> 1) ^ (2 * kr)) + 8 * (jp & 1);
+  const unsigned offA = (unsigned)((kr * g.lda + min(m0 + dim, ((g.M + 7) & ~7) - 8)) * 2);
+  const unsigned offB = (unsigned)((kr * g.ldb + min(n0 + dim, ((g.N + 7) & ~7) - 8)) * 2);
+  const __bf16* baseA = g.Apl + z * g.sA + (int64_t)kbeg * g.lda;
+  const __bf16* baseB = g.Bpl + z * g.sB + (int64_t)kbeg * g.ldb;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&lds[0][0];
+  // this wave's six pieces of a stage: p = wave + 4 i -> operand p / 12, plane (p % 12) / 4, k quad p % 4
+  auto stage = [&](int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int p = wave + 4 * i, op = p / 12, pl = (p % 12) >> 2, kq = p & 3;
+      const __bf16* src = (op ? baseB + pl * g.planeB + ((int64_t)kt * BK + 4 * kq) * g.ldb
+                              : baseA + pl * g.planeA + ((int64_t)kt * BK + 4 * kq) * g.lda);
+      const unsigned dst = lds_base + buf * STAGE + op * OPER + pl * PTILE + kq * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(op ? offB : offA), "s"(src), "s"(dst) : "memory");
+    }
+  };
+
+  // ---- fragments: the planes kernel's K-major read (k row 8 kh + q, piece pp of 16-dim block bq; + 4 rows for the upper half)
+  const int kh = lane >> 5;
+  auto km_frag = [&](int d0) {
+    const int bq = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+    return (8 * kh + q) * ROWB + ((((d0 >> 4) + bq) ^ (2 * q)) << 5) + 8 * pp;
+  };
+  int fa[2], fb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    fa[i] = km_frag(wm * 64 + 32 * i);
+    fb[i] = km_frag(wn * 64 + 32 * i);
+  }
+  auto rd = [&](const char* pl, int off) -> bf16x8_t {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pl + off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pl + off + 4 * ROWB));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, v);
+  };
+  auto frag = [&](const char* oper, int off, unsigned sm) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    Split3 f;
+    f.hi = rd(oper, off);
+    f.mid = rd(oper + PTILE, off);
+    f.lo = rd(oper + 2 * PTILE, off);
+    if (sm) {  // a negative stretch (wave-uniform): the B operand's pieces change sign
+      const u32x4_ m4 = {sm, sm, sm, sm};
+      f.hi = __builtin_bit_cast(bf16x8_t, __builtin_bit_cast(u32x4_, f.hi) ^ m4);
+      f.mid = __builtin_bit_cast(bf16x8_t, __builtin_bit_cast(u32x4_, f.mid) ^ m4);
+      f.lo = __builtin_bit_cast(bf16x8_t, __builtin_bit_cast(u32x4_, f.lo) ^ m4);
+    }
+    return f;
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto negate_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = -acc[i][j];
+  };
+
+  if (nk > 0) stage(0, 0);
+  SignPhase ph;
+  ph.init(g.flip_q, kbeg / BK);
+  unsigned held = 0u;
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // everybody's pieces of step kt have landed; all reads of the buffer refilled next are done
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    if (ph.mask != held) {
+      negate_acc();
+      held = ph.mask;
+    }
+    const char* ai = lds[cur];
+    const char* bi = lds[cur] + OPER;
+    const unsigned sm = held ? 0x80008000u : 0u;
+    const Split3 a0 = frag(ai, fa[0], 0u), b0 = frag(bi, fb[0], sm);
+    mma6(acc[0][0], a0, b0);
+    const Split3 a1 = frag(ai, fa[1], 0u);
+    mma6(acc[1][0], a1, b0);
+    const Split3 b1 = frag(bi, fb[1], sm);
+    mma6(acc[0][1], a0, b1);
+    mma6(acc[1][1], a1, b1);
+    ph.advance();
+    cur ^= 1;
+  }
+  if (held) negate_acc();
+  store_tile(g, acc, C, ldc, bias, partial, m0 + wm * 64, n0 + wn * 64, lane);
+  if (partial && g.counters) finish_splitk(g, z, m0 + wm * 64, n0 + wn * 64, tid);
+}
+
+// The three bf16 planes of an fp32 matrix (sk_split_rows): dst[p][r][c], p = 0 hi, 1 mid, 2 lo, the pieces split3() makes (round
+// to nearest even); rows R .. R_pad - 1 and columns C .. ld_dst - 1 are written as zeros (a K-major factor is read in whole K
+// steps; a clamped tile edge reads the padding).  HBM-bound: 4 bytes read, 6 written per element.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int R, int C, int ld_src, __bf16* __restrict__ dst,
+                                                         int ld_dst, int R_pad, int64_t plane) {
+  const int64_t n4 = (int64_t)R_pad * (ld_dst / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / (ld_dst / 4)), c = 4 * (int)(i % (ld_dst / 4));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < R) {
+      const float* sp = src + (int64_t)r * ld_src + c;
+      if (c + 3 < C && (((uintptr_t)sp) & 15) == 0) {
+        v = *reinterpret_cast<const float4*>(sp);
+      } else {
+        if (c < C) v.x = sp[0];
+        if (c + 1 < C) v.y = sp[1];
+        if (c + 2 < C) v.z = sp[2];
+        if (c + 3 < C) v.w = sp[3];
+      }
+    }
+    const Pl4 p = split4(v);
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    __bf16* d = dst + (int64_t)r * ld_dst + c;
+    *reinterpret_cast<u32x2_*>(d) = (u32x2_){p.h[0], p.h[1]};
+    *reinterpret_cast<u32x2_*>(d + plane) = (u32x2_){p.m[0], p.m[1]};
+    *reinterpret_cast<u32x2_*>(d + 2 * plane) = (u32x2_){p.l[0], p.l[1]};
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2402,6 +2589,68 @@ extern "C" int sk_gemm_bf16_mm(const void* A, const void* B, float* C, const flo
     const int64_t quads = sk_cdiv((int64_t)M * N, 4);
     const unsigned nb = (unsigned)(sk_cdiv(quads, 256) > 2048 ? 2048 : sk_cdiv(quads, 256));
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb, 1, (unsigned)batch), dim3(256), 0, st, r);
+    SK_CHECK_LAUNCH("splitk_reduce_kernel");
+  }
+  return SK_OK;
+}
+
+// ---------------------------------------------------------------- operands that arrive split
+extern "C" int sk_split_rows(const float* src, int R, int C, int ld_src, void* dst, int ld_dst, int R_pad, int64_t plane,
+                             sk_stream_t stream) {
+  SK_CHECK_ARG(src && dst && R > 0 && C > 0 && ld_src >= C && ld_dst >= C && ld_dst % 8 == 0 && ((uintptr_t)dst % 16) == 0 &&
+                   R_pad >= R && plane >= (int64_t)R_pad * ld_dst && plane % 8 == 0,
+               "sk_split_rows: bad arguments");
+  const int64_t n4 = (int64_t)R_pad * (ld_dst / 4);
+  const unsigned nb = (unsigned)(sk_cdiv(n4, 256) > 8192 ? 8192 : sk_cdiv(n4, 256));
+  hipLaunchKernelGGL(split_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, R, C, ld_src, (__bf16*)dst, ld_dst, R_pad, plane);
+  SK_CHECK_LAUNCH("sk_split_rows");
+  return SK_OK;
+}
+
+extern "C" int sk_gemm_pl3_tn(const void* Apl, const void* Bpl, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+                              int64_t planeA, int64_t planeB, int accumulate, int batch, int64_t sA, int64_t sB, int64_t sC,
+                              int splitk, void* ws, sk_stream_t stream) {
+  SK_CHECK_ARG(Apl && Bpl && C, "sk_gemm_pl3_tn: null pointer");
+  SK_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch > 0 && batch <= 65535, "sk_gemm_pl3_tn: bad sizes M=%d N=%d K=%d batch=%d", M, N, K, batch);
+  SK_CHECK_ARG(K % BK == 0, "sk_gemm_pl3_tn: K = %d must be a multiple of %d (the planes' zero tail rows)", K, BK);
+  SK_CHECK_ARG(ldc >= N && lda % 8 == 0 && ldb % 8 == 0 && (batch == 1 || (sA % 8 == 0 && sB % 8 == 0)) && planeA % 8 == 0 && planeB % 8 == 0,
+               "sk_gemm_pl3_tn: leading dimensions, plane and batch strides must be multiples of 8 elements");
+  SK_CHECK_ARG(lda >= (batch - 1) * sA + ((M + 7) & ~7) && ldb >= (batch - 1) * sB + ((N + 7) & ~7),
+               "sk_gemm_pl3_tn: leading dimension smaller than the operand's padded width");
+  SK_CHECK_ARG(((uintptr_t)Apl % 16) == 0 && ((uintptr_t)Bpl % 16) == 0, "sk_gemm_pl3_tn: planes must be 16-byte aligned");
+  SK_CHECK_ARG(splitk >= 1 && splitk <= 64 && (splitk == 1 || ws), "sk_gemm_pl3_tn: bad splitk %d / missing workspace", splitk);
+  GemmArgs g;
+  g.A = nullptr; g.B = nullptr; g.C = C; g.bias = nullptr;
+  g.Apl = (const __bf16*)Apl; g.Bpl = (const __bf16*)Bpl; g.planeA = planeA; g.planeB = planeB;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.accumulate = accumulate; g.act = 0; g.vecA = g.vecB = 1;
+  g.tilesN = (int)sk_cdiv(N, BN);
+  g.sA = sA; g.sB = sB; g.sC = sC; g.sbias = 0;
+  g.sk_tiles = 0; g.sk_full = 0; g.flip_q = 0;
+  g.kchunk = (int)(sk_cdiv(sk_cdiv(K, splitk), BK) * BK);
+  splitk = (int)sk_cdiv(K, g.kchunk);
+  g.splitk = splitk;
+  if (SK_SPLIT_FLIP) {  // the sign-phase rule of gemm_launch: one pattern over the whole K
+    const int nks = K / BK;
+    if (nks >= 48) {
+      const int periods = (nks + 32) / 64;
+      g.flip_q = (nks + 4 * periods - 1) / (4 * periods);
+    }
+  }
+  const int64_t tiles = sk_cdiv(M, BM) * g.tilesN;
+  SK_CHECK_ARG(tiles < (1ll << 31), "sk_gemm_pl3_tn: too many tiles");
+  g.slabs = ws ? (float*)((char*)ws + COUNTER_BYTES) : nullptr;
+  const bool inkernel = splitk > 1 && tiles * batch * sizeof(unsigned) <= COUNTER_BYTES;
+  g.counters = inkernel ? (unsigned*)ws : nullptr;
+  dim3 grid((unsigned)tiles, (unsigned)splitk, (unsigned)batch);
+  hipStream_t st = (hipStream_t)stream;
+  t_last_kernel = 14;
+  hipLaunchKernelGGL(gemm_f32_kernel_pl3, grid, dim3(256), 0, st, g);
+  SK_CHECK_LAUNCH("sk_gemm_pl3_tn");
+  if (splitk > 1 && !inkernel) {
+    const int64_t quads = sk_cdiv((int64_t)M * N, 4);
+    const unsigned nb = (unsigned)(sk_cdiv(quads, 256) > 2048 ? 2048 : sk_cdiv(quads, 256));
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb, 1, (unsigned)batch), dim3(256), 0, st, g);
     SK_CHECK_LAUNCH("splitk_reduce_kernel");
   }
   return SK_OK;

@@ -53,12 +53,12 @@ __device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((
 
 // S3 variant of the forward kernel (mode bit 28): the fp32 product h W_hh^T on the bf16 matrix pipe by an EXACT three-way
 // split of both operands.  An fp32 value x is cut into three bf16 pieces, x = hi + mid + lo exactly (24 significand bits =
-// 3 x 8; by rounding to nearest: hi = bf16(x), x - hi is exact and <= 2^-9 |x|; again for mid; what is left IS a bf16, <= 2^-18 |x|).
-// w h is the sum of nine piece products, each exact in fp32 (8 x 8 bits), of relative sizes 1 (hi hi), 2^-9 (hi mid, mid hi),
-// 2^-18 (hi lo, mid mid, lo hi), 2^-27 (mid lo, lo mid) and 2^-36 (lo lo).  The kernel forms the SIX of size >= 2^-18 and
+// 3 x 8; by rounding to nearest: hi = bf16(x), x - hi is exact and <= 2^-8 |x|; again for mid; what is left IS a bf16, <= 2^-16 |x|).
+// w h is the sum of nine piece products, each exact in fp32 (8 x 8 bits), of relative sizes 1 (hi hi), 2^-8 (hi mid, mid hi),
+// 2^-16 (hi lo, mid mid, lo hi), 2^-24 (mid lo, lo mid) and 2^-32 (lo lo).  The kernel forms the SIX of size >= 2^-16 and
 // adds them into fp32 accumulators with v_mfma_f32_16x16x32_bf16 (16 cycles each, K = 32): 96 matrix-pipe cycles per 32 k
-// instead of the 256 of eight v_mfma_f32_16x16x4_f32.  The three it leaves out are together <= 2^-26 of the product they
-// belong to, a QUARTER of the half ulp an fp32 multiplier rounds away itself, and far below the rounding of the fp32
+// instead of the 256 of eight v_mfma_f32_16x16x4_f32.  The three it leaves out are together <= 2^-23 |w||h| in the worst case (one
+// ulp of that product; typical pieces: a quarter of it) -- at the level of the rounding of the fp32
 // accumulation that follows: against an fp64 sum (K = 896, operands of the recurrence's scale) the six-product form has the error of the
 // nine-product form (rms 2.21e-7 vs 2.19e-7) and less than the fp32-MFMA kernel's own (2.50e-7), and differs from the nine-
 // product form by 7x less than that differs from the fp32-MFMA kernel (tests/test_gpu_kernels.py pins this on the device).
@@ -66,8 +66,8 @@ __device__ __forceinline__ int bf_img(int k, int b) { return (k >> 5) * 512 + ((
 // register pieces: 168 instead of 112 VGPRs), h by its producer before it publishes (three bf16 images: 6 instead of 4 bytes
 // per cell).  (r04 shipped all nine products: 144 cycles per 32 k.)
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-  // pieces by round-to-nearest: hi = bf16(x); r = x - hi is exact, |r| <= 2^-9 |x|; mid = bf16(r); lo = r - mid is exact, has
-  // at most 8 significant bits (IS a bf16) and |lo| <= 2^-18 |x|
+  // pieces by round-to-nearest: hi = bf16(x); r = x - hi is exact, |r| <= 2^-8 |x|; mid = bf16(r); lo = r - mid is exact, has
+  // at most 8 significant bits (IS a bf16) and |lo| <= 2^-16 |x|
   const __bf16 h = (__bf16)x;
   const float r = x - (float)h;
   const __bf16 m = (__bf16)r;
@@ -215,6 +215,8 @@ struct BwdArgs {
   int map, nby, poll_delay;
   __bf16* dgx_bf;  // optional bf16 twin of dgx (rows (t, b), ld_bf elements apart), written with the fp32 values; may be NULL
   int ld_bf;
+  long long pl_bf;  // 0: one bf16 copy (rounded: the bf16 configuration's operand); > 0 (fp32 kernel): THREE planes this many elements
+                    // apart -- the exact hi / mid / lo pieces of dgx, the operand sk_gemm_pl3_tn reads ("operands that arrive split")
   int fast;  // mode bit 29: read by the timing-only build -DSK_BWD_BOUND38 alone
 };
 
@@ -854,6 +856,206 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_kernel(FwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ forward, bf16: XCD-local streams of 8 rows
+// (r06, mode bit 30)  The bf16 recurrences are hand-off chains: 0.19 us of MFMA in a 3.1 us step.  What the chain
+// costs was measured stand-alone (tools/micro/xcd_local_handoff.hip, profiles/r05_xcd_local_handoff.txt): 2.45 us in the shipped
+// geometry (streams of 56 workgroups on an XCD pair, write-through stores, 28 KB pulled per workgroup and step), 1.34 us for a
+// stream of 28 workgroups on ONE XCD that publishes with PLAIN stores (within an XCD the L2 is the coherence point: an sc1 load
+// bypasses the L1 and is served by that L2, dirty line or not -- no write-through, no acknowledgement from memory) and pulls 14 KB.
+// r05 built such streams from 16-wave workgroups of 32 units x 16 rows and lost on the two things that were not the hand-off (two
+// cell-owning waves per SIMD; 28 KB still pulled).  This form changes ONE thing, the stream: 2 directions x ceil(B / 8) batch
+// groups of EIGHT rows (B <= 32: at most 8 streams, one per XCD), each 28 workgroups x 32 hidden units -- in bf16 the W_hh slice
+// of 32 units takes the registers 16 units take in fp32 (112 VGPRs).  A workgroup stays 8 waves: wave (tp, kh) multiplies the two
+// gate-row tiles 2 tp, 2 tp + 1 (8 units) with one K half; the MFMA's 16 batch columns carry the 8 rows TWICE (lanes n and n + 8
+// read the same fragment), so a lane simply keeps tile 2 tp's result for n < 8 and tile 2 tp + 1's for n >= 8: the four kh = 0
+// waves own all 256 cells with every lane busy -- one cell-owning wave per SIMD, as in the shipped kernel.  Per step a workgroup
+// publishes 512 B (its 32 units x 8 rows = chunk `ug` of the stream's image), polls 28 flags, pulls 14 KB.  The matrix pipe does
+// twice the work for the same cells (half-empty columns): 0.37 instead of 0.19 us per step, against more than a microsecond of
+// chain.  Same products, same K order, same sums as lstm_fwd_kernel<KS, true, 8>: bit-identical results (tests).
+// Membership: a workgroup belongs to the stream of the XCD it RUNS on (HW_REG_XCC_ID) and takes the next free unit group there (a
+// counter per XCD in the launch's control block) -- the dispatcher deals blocks round-robin over the XCDs but does not start at
+// XCD 0 for every dispatch (r05: a fixed block -> stream map failed inside the training step).  The grid is 8 x 32 blocks; the 4
+// surplus workgroups of an XCD, and those of an XCD without a stream, leave at once.  An XCD that received fewer than 28 could
+// not complete a step: the bounded spins then raise the status word like any failed launch.
+// Persistent launches only (mode 2 runs the ordinary kernel); one batch group per workgroup (no G loop: c and h live in registers).
+__device__ __forceinline__ int xl_img(int k, int r) { return (k >> 5) * 256 + ((((k >> 3) & 3) * 8 + r) << 3) + (k & 7); }  // bf16 elements
+
+template <int KS, bool PK>
+__global__ __launch_bounds__(512, 2) void lstm_fwd_xl8_kernel(FwdArgs a) {
+  constexpr int HP = 16 * KS;
+  constexpr int NUG = HP / 32;   // workgroups (unit groups of 32) per stream = 512-byte chunks of a stream's image
+  constexpr int NQ = NUG / 2;    // chunks per K half
+  constexpr int NPIECE = NUG / 2;  // 1 KB DMA pieces (two chunks each)
+  static_assert(NUG % 2 == 0 && NUG <= 32, "one XCD per stream");
+  __shared__ __attribute__((aligned(1024))) float hs[NUG * 128];   // B-operand image of h_{s-1}: NUG chunks x [4 k-octets][8 rows][8 bf16]
+  __shared__ __attribute__((aligned(16))) float red[4][2][64][4];  // the kh = 1 waves' partial tiles
+  __shared__ long long st_tpub;
+  __shared__ int s_abort, s_slot;
+  __shared__ int s_len[8];
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;  // NBG: batch groups of EIGHT rows
+  const int stream = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);  // HW_REG_XCC_ID[3:0]
+  if (tid == 0) {
+    s_slot = (stream < 2 * NBG) ? (int)__hip_atomic_fetch_add(a.ctrl + 32 + stream, 1u, SK_RLX, SK_AGENT) : NUG;
+    s_abort = 0;
+  }
+  __syncthreads();
+  const int ug = s_slot;
+  if (ug >= NUG) return;  // (uniform)
+  const int bg = stream % NBG, dir = stream / NBG;
+  const int tp = w & 3, kh = w >> 2;
+
+  // ---- W_hh slice -> registers: tiles 2 tp, 2 tp + 1; lane supplies A[i = lane & 15][k = 32 chunk + 8 (lane >> 4) + 0..7]
+  bf16x8 wb[2][NQ];
+  {
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int unit_i = ug * 32 + 4 * (2 * tp + tt) + (i >> 2), g_i = i & 3;
+      const bool rowok = unit_i < H;
+      const float* wrow = a.whh + ((size_t)dir * 4 * H + (size_t)g_i * H + unit_i) * H;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int k = 32 * (kh * NQ + q) + 8 * kq;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (rowok && k < H) v0 = *reinterpret_cast<const float4*>(wrow + k);
+        if (rowok && k + 4 < H) v1 = *reinterpret_cast<const float4*>(wrow + k + 4);
+        wb[tt][q] = pack8(v0, v1);
+      }
+    }
+  }
+
+  // ---- the cell of an owner lane: n < 8: tile 2 tp (units 8 tp + 0..3), row n; n >= 8: tile 2 tp + 1 (units 8 tp + 4..7), row n - 8
+  const int u_l = lane >> 4, n = lane & 15, sel = n >> 3, r = n & 7;
+  const bool owner = kh == 0;
+  const int unit = ug * 32 + 8 * tp + 4 * sel + u_l;
+  const int b = bg * 8 + r;
+  const bool cellok = owner && unit < H && b < B;
+  float c_reg = 0.f, h_reg = 0.f;
+  if (cellok) {
+    c_reg = a.c0[((size_t)dir * B + b) * H + unit];
+    h_reg = a.h0[((size_t)dir * B + b) * H + unit];
+  }
+  if (tid < 8) s_len[tid] = (bg * 8 + tid < B) ? a.lens[bg * 8 + tid] : 0;
+  __syncthreads();
+
+  constexpr size_t XBLK = (size_t)NUG * 128;  // floats per (parity, stream) exchange block
+  float* const xb0 = a.xbuf + (size_t)stream * XBLK;
+  float* const xb1 = xb0 + (size_t)8 * XBLK;
+  unsigned* const flags0 = a.flags + (size_t)stream * NUG * FSPREAD;  // one flag per 128-byte line
+  const int len_b = s_len[r];
+  const int Tg = PK ? s_len[0] : T;  // the group's longest utterance (lengths sorted descending)
+  const int s_hi = min(a.s_end, Tg);
+  bool aborted = false;
+  for (int s = a.s_begin; s < s_hi; ++s) {
+    const int t = dir ? Tg - 1 - s : s;
+    const int rb = PK ? a.offs[t] : t * B;
+    const bool live = cellok && t < len_b;
+    const size_t row = (size_t)rb + b;
+    // 1. this step's input-projection terms (independent of the recurrence: issue early)
+    float4 gxv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PK ? live : cellok) gxv = *reinterpret_cast<const float4*>(a.gx + (row * 2 + dir) * 4 * H + 4 * (size_t)unit);
+    // 2. h_{s-1}: the stream's image (8 rows x HP) -> LDS
+    if (s == 0) {
+      for (int i = tid; i < 8 * (HP / 8); i += 512) {
+        const int bb = i & 7, c8 = i >> 3;
+        const int brow = bg * 8 + bb, k = 8 * c8;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        const float* hp0 = a.h0 + ((size_t)dir * B + brow) * H + k;
+        if (brow < B && k < H) v0 = *reinterpret_cast<const float4*>(hp0);
+        if (brow < B && k + 4 < H) v1 = *reinterpret_cast<const float4*>(hp0 + 4);
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(hs) + xl_img(k, bb)) = pack8(v0, v1);
+      }
+    } else {
+      // one polling wave (28 flags, one per lane), held back behind the own flag store as in the shipped kernel; then the four
+      // waves that own no cells pull the 14 pieces (nothing of the hand-off queues behind the owners' bulk stores)
+      if (w == 0 && !wait_flags(flags0, NUG, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub + 10LL * a.poll_delay : 0LL, FSPREAD) &&
+          lane == 0)
+        s_abort = 1;
+      __syncthreads();
+      if (!s_abort && !owner) {
+        const float* src = ((s - 1) & 1) ? xb1 : xb0;
+        for (int p = w - 4; p < NPIECE; p += 4) dma_piece(src + p * 256, hs + p * 256, lane);
+        wait_vmcnt<0>();
+      }
+    }
+    __syncthreads();
+    if (s_abort) {
+      aborted = true;
+      break;
+    }
+    // 3. gates^T (128 gate rows x 8 rows, carried twice) = W_slice (128 x HP) * h^T; this wave: 32 gate rows, half of K.  Even / odd
+    //    chunks on two accumulators per tile, as lstm_fwd_kernel does (the same sums, bit for bit)
+    f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+    {
+      const float* hp = &hs[(kh * NQ) * 128 + ((lane >> 4) * 8 + r) * 4];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const bf16x8 hb = *reinterpret_cast<const bf16x8*>(hp + q * 128);
+        acc[0][q & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[0][q], hb, acc[0][q & 1], 0, 0, 0);
+        acc[1][q & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[1][q], hb, acc[1][q & 1], 0, 0, 0);
+      }
+    }
+    const f32x4 t0 = acc[0][0] + acc[0][1], t1 = acc[1][0] + acc[1][1];
+    if (!owner) {
+      *reinterpret_cast<f32x4*>(&red[tp][0][lane][0]) = t0;
+      *reinterpret_cast<f32x4*>(&red[tp][1][lane][0]) = t1;
+    }
+    __syncthreads();
+    float y_out = 0.f, c_out = 0.f;
+    f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+    bool valid = false;
+    if (owner) {
+      f32x4 pre = sel ? t1 : t0;
+      pre += *reinterpret_cast<const f32x4*>(&red[tp][sel][lane][0]);
+      // 4. cell update: this lane holds gates i, f, g, o of (unit, b)
+      const float gi_ = fast_sigmoid(pre[0] + gxv.x);
+      const float gf = fast_sigmoid(pre[1] + gxv.y);
+      const float gg = fast_tanh(pre[2] + gxv.z);
+      const float go = fast_sigmoid(pre[3] + gxv.w);
+      const float c_new = gf * c_reg + gi_ * gg;
+      const float h_new = go * fast_tanh(c_new);
+      valid = live;
+      if (valid) {
+        c_reg = c_new;
+        h_reg = h_new;
+      }
+      // 5. publish h_s first: the 8 units of this wave for row r are in lanes (u_l = 0..3, n = r) and (u_l, n = r + 8); lane n < 16
+      //    gathers the four of its half and stores 4 bf16 = 8 bytes of chunk `ug` -- PLAIN store: the consumers sit on this XCD
+      const float hv = cellok ? h_reg : 0.f;
+      const float h1 = __shfl(hv, n + 16, 64), h2 = __shfl(hv, n + 32, 64), h3 = __shfl(hv, n + 48, 64);
+      if (lane < 16) {
+        bf16x4 pk;
+        pk[0] = (__bf16)hv; pk[1] = (__bf16)h1; pk[2] = (__bf16)h2; pk[3] = (__bf16)h3;
+        float* xdst = (s & 1) ? xb1 : xb0;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(xdst) + ug * 512 + (tp * 8 + r) * 16 + sel * 8) = pk;
+      }
+      wait_vmcnt<0>();
+      g4[0] = gi_; g4[1] = gf; g4[2] = gg; g4[3] = go;
+      y_out = valid ? h_new : 0.f;
+      c_out = c_new;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(flags0 + (size_t)ug * FSPREAD, (unsigned)(s + 1), SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP);  // plain store
+      st_tpub = wall_clock64();
+    }
+    // 6. ... then the bulk stores of the step, off the critical path
+    if (PK ? valid : cellok) {
+      a.y[row * 2 * H + (size_t)dir * H + unit] = y_out;
+      if (a.gates && valid) {
+        *reinterpret_cast<f32x4*>(a.gates + (row * 2 + dir) * 4 * H + 4 * (size_t)unit) = g4;
+        a.cs[(row * 2 + dir) * H + unit] = c_out;
+      }
+    }
+  }
+  if (!aborted && cellok) {
+    if (a.hn) a.hn[((size_t)dir * B + b) * H + unit] = h_reg;
+    if (a.cn) a.cn[((size_t)dir * B + b) * H + unit] = c_reg;
+  }
+}
+
 // ------------------------------------------------------------------------------------ backward
 // dh_{prev}[b][u] = sum_{k'} dG[b][k'] W_hh[row(k')][u],  k' = 4*unit_k + gate (gate-interleaved).
 // Transposed MFMA: D[m = out unit][n = batch] = sum_k' A[m][k'] B[k'][n]; wave w takes the k' chunks
@@ -1038,17 +1240,20 @@ __device__ __forceinline__ float bwd_matmul(const BwdW<KS, BF>& wreg, const floa
 // (r06: a split-product form of this kernel for the top layer's launch -- W_hh^T as three register pieces, dG split by the wave that
 // multiplies it, six bf16 piece products -- was built, parity-pinned and measured: its 36 VALU instructions per 32 k' cost what the
 // fp32 MFMAs they replace cost; not kept.  profiles/r06_bwd_split_top_layer.txt, the code: profiles/r06_bwd_split_top_layer.patch)
-template <int KS, bool BF>
+// GM: the batch groups a workgroup may carry (1 or GMAX; a.G <= GM).  The G = 1 instantiation (every BASELINE shape but the
+// reference's batch of 100) keeps 14 KB less per-group state in LDS: 113 instead of 127 KB, which leaves the 48 KB a workgroup of
+// gemm_f32_kernel_pl3 needs beside it (r06: with 127 KB that kernel was not co-resident at all).
+template <int KS, bool BF, int GM = GMAX>
 __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) void lstm_bwd_kernel(BwdArgs a) {
   using C = BwdCfg<KS, BF>;
   constexpr int HP = 16 * KS, NQ = C::NQ;
   __shared__ __attribute__((aligned(16))) float ring_all[8][C::DEPTH * C::SB * 256];
   __shared__ float red[8][256];
-  __shared__ float st_carry[GMAX][256], st_dc[GMAX][256];  // per-group recurrent state of the owner lanes
+  __shared__ float st_carry[GM][256], st_dc[GM][256];  // per-group recurrent state of the owner lanes
   __shared__ __attribute__((aligned(16))) float st_db[256][4];  // owner lanes: running sum of their cells' dG (bias gradient)
-  __shared__ long long st_tpub[GMAX];  // wave 0: when this workgroup raised the group's flag (see wait_flags)
+  __shared__ long long st_tpub[GM];  // wave 0: when this workgroup raised the group's flag (see wait_flags)
   __shared__ int s_abort;
-  __shared__ int s_len[GMAX * 16];  // lengths of this workgroup's batch rows (loop-invariant: fetched once, not per step)
+  __shared__ int s_len[GM * 16];  // lengths of this workgroup's batch rows (loop-invariant: fetched once, not per step)
 
   int ug, by, dir;
   decode_block((int)blockIdx.x, KS, a.nby, a.map, ug, by, dir);
@@ -1228,9 +1433,31 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
       if (valid || (cellok && !a.offs)) {  // (packed rows: positions past a row's end do not exist)
         *reinterpret_cast<f32x4*>(a.dgx + (row * 2 + dir) * 4 * H + 4 * (size_t)unit) = dpre;
         if (a.dgx_bf) {  // the operand copy the data- and weight-gradient products of the bf16 configuration read (no cast pass)
-          bf16x4 pk;
-          pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
-          *reinterpret_cast<bf16x4*>(a.dgx_bf + row * a.ld_bf + (size_t)dir * 4 * H + 4 * (size_t)unit) = pk;
+          __bf16* const tw = a.dgx_bf + row * a.ld_bf + (size_t)dir * 4 * H + 4 * (size_t)unit;
+          if (!BF && a.pl_bf) {
+            // fp32: the three bf16 planes of the cell's four values -- the weight-gradient products then find their pieces made
+            // (18 VALU instructions per cell here instead of 4.5 per element in every wave that reads it)
+            const f32x2_t x0 = {dpre[0], dpre[1]}, x1 = {dpre[2], dpre[3]};
+            u32x2 Hh, Mm, Ll;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const f32x2_t x = j ? x1 : x0;
+              Hh[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(x, bf16x2_t));
+              const f32x2_t xh = {__uint_as_float(Hh[j] << 16), __uint_as_float(Hh[j] & 0xffff0000u)};
+              const f32x2_t r = x - xh;
+              Mm[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+              const f32x2_t rh = {__uint_as_float(Mm[j] << 16), __uint_as_float(Mm[j] & 0xffff0000u)};
+              const f32x2_t q = r - rh;
+              Ll[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(q, bf16x2_t));
+            }
+            *reinterpret_cast<u32x2*>(tw) = Hh;
+            *reinterpret_cast<u32x2*>(tw + a.pl_bf) = Mm;
+            *reinterpret_cast<u32x2*>(tw + 2 * a.pl_bf) = Ll;
+          } else {
+            bf16x4 pk;
+            pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
+            *reinterpret_cast<bf16x4*>(tw) = pk;
+          }
         }
       }
       SK_STAMP(6);
@@ -1337,8 +1564,18 @@ void launch_fwd_s3(const FwdArgs& a, int nblocks, hipStream_t st) {
 }
 template <int KS, bool BF>
 int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
+  if (a.G == 1)
+    hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF, 1>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
+  else
+    hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF, GMAX>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
   return 0;
+}
+
+void launch_fwd_xl8(const FwdArgs& a, hipStream_t st) {  // bf16, 608 < H <= 896 (KS = 56): 8 XCDs x 32 blocks
+  if (a.offs)
+    hipLaunchKernelGGL((lstm_fwd_xl8_kernel<56, true>), dim3(256), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL((lstm_fwd_xl8_kernel<56, false>), dim3(256), dim3(512), 0, st, a);
 }
 
 int dispatch_fwd_s3(int KS, const FwdArgs& a, int nblocks, hipStream_t st) {
@@ -1402,7 +1639,7 @@ int check_common(const char* fn, int T, int B, int H, const float* whh, int mode
   SK_CHECK_ARG(T > 0 && B > 0 && H > 0, "%s: bad sizes T=%d B=%d H=%d", fn, T, B, H);
   SK_CHECK_ARG(H % 4 == 0 && H <= 1024, "%s: hidden size %d must be a multiple of 4 and <= 1024", fn, H);
   SK_CHECK_ARG(((uintptr_t)whh % 16) == 0, "%s: whh must be 16-byte aligned", fn);
-  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 30) == 0,
+  SK_CHECK_ARG((mode & 0xff) >= 0 && (mode & 0xff) <= 2 && ((mode >> 8) & 0xff) <= GMAX && (mode >> 31) == 0,
                "%s: unknown mode %d", fn, mode);
   return SK_OK;
 }
@@ -1462,6 +1699,7 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   const bool tagged = ((mode >> 29) & 1) && !bf && !s3;  // bit 29 (fp32)
   if (tagged) opt |= 8;                // the data is the flag (lstm_fwd_kernel)
   int poll_delay = (mode >> 23) & 31;  // bits 23..27: FwdArgs::poll_delay, units of 0.1 us; 0 = choose, 31 = none
+  const bool xl8_bit = (mode >> 30) & 1;  // bit 30 (bf16): XCD-local streams of 8 rows (lstm_fwd_xl8_kernel)
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf || s3);  // (S3 exchanges bf16 images: the bf16 unit-group counts)
   hipStream_t st = (hipStream_t)stream;
@@ -1487,7 +1725,16 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));  // per-launch status word + flags (not the sticky word)
   if ((opt & 8) && mode != 2)  // tagged words: a new sequence must not find an old one's epochs in the buffers
     SK_CHECK_HIP(hipMemsetAsync(base + L.xbuf, 0, L.state - L.xbuf, st));
-  if (mode == 1 || (mode == 0 && fits)) {
+  // XCD-local streams of 8 rows: where the shape allows it -- the 56-chunk instantiation (608 < H <= 896: 28 workgroups of 32 units
+  // per stream), at most 8 streams (B <= 32), a device of 8 XCDs x 32 CUs, a persistent launch; anything else runs the ordinary form
+  const bool xl8 = xl8_bit && bf && L.KS == 56 && B <= 32 && gmin <= 1 && num_cus() >= 256 && (mode == 1 || (mode == 0 && fits));
+  if (xl8) {
+    a.s_begin = 0; a.s_end = T;
+    a.NBG = (B + 7) / 8;  // batch groups of EIGHT rows
+    a.G = 1; a.nby = a.NBG;
+    if (poll_delay == 8) a.poll_delay = 4;  // (a stream's flag stores land sooner: the small-grid hold-back)
+    launch_fwd_xl8(a, st);
+  } else if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T;
     s3 ? dispatch_fwd_s3(L.KS, a, nblocks, st) : dispatch_fwd(L.KS, bf, a, nblocks, st);
   } else {  // one launch per step: the state travels through the workspace
@@ -1502,11 +1749,11 @@ extern "C" int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, c
 
 extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, const float* whh, const float* gates,
                            const float* cs, const float* c0, const int32_t* lens, const int32_t* offs, float* dgx,
-                           float* dh0, float* dc0, float* dbias, void* dgx_bf16, int ld_bf16, void* ws, int T, int B, int H,
-                           int mode, sk_stream_t stream) {
+                           float* dh0, float* dc0, float* dbias, void* dgx_bf16, int ld_bf16, int64_t plane_bf16, void* ws, int T,
+                           int B, int H, int mode, sk_stream_t stream) {
   SK_CHECK_ARG(dy && whh && gates && cs && c0 && lens && dgx && ws, "sk_lstm_bwd: null pointer");
-  SK_CHECK_ARG(!dgx_bf16 || (ld_bf16 >= 8 * H && ld_bf16 % 4 == 0 && ((uintptr_t)dgx_bf16 % 8) == 0),
-               "sk_lstm_bwd: bf16 twin needs ld >= 8H, ld %% 4 == 0, 8-byte alignment");
+  SK_CHECK_ARG(!dgx_bf16 || (ld_bf16 >= 8 * H && ld_bf16 % 4 == 0 && ((uintptr_t)dgx_bf16 % 8) == 0 && plane_bf16 >= 0 && plane_bf16 % 4 == 0),
+               "sk_lstm_bwd: bf16 twin needs ld >= 8H, ld %% 4 == 0, 8-byte alignment, plane stride %% 4");
   SK_CHECK_ARG(((uintptr_t)gates % 16) == 0 && ((uintptr_t)dgx % 16) == 0, "sk_lstm_bwd: gates / dgx must be 16-byte aligned");
   int rc = check_common("sk_lstm_bwd", T, B, H, whh, mode);
   if (rc) return rc;
@@ -1525,7 +1772,8 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, 
   a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens; a.offs = offs;
   a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0; a.dhn = dhn; a.dcn = dcn;
   a.dbias = dbias;
-  a.dgx_bf = (__bf16*)dgx_bf16; a.ld_bf = ld_bf16; a.fast = fast;
+  a.dgx_bf = (__bf16*)dgx_bf16; a.ld_bf = ld_bf16; a.pl_bf = plane_bf16; a.fast = fast;
+  SK_CHECK_ARG(!plane_bf16 || !bf, "sk_lstm_bwd: planes of dgx are the fp32 configuration's (mode bit 16 = bf16 inputs is set)");
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
   a.T = T; a.B = B; a.H = H; a.NBG = L.NBG;

@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int MAXS = 4;
-constexpr int TCH = 8;   // frames per block in the pairwise pass (r06: 8 instead of 16 -- 1600 blocks for 32 x 400 frames, ~6 per CU)
+constexpr int TCH = 16;  // frames per block in the pairwise pass
 constexpr int RB = 4;    // (frame, utterance) rows per block in the backward pass
 
 struct SrcPtrs {
@@ -34,15 +34,9 @@ __global__ __launch_bounds__(256) void pit_pair_kernel(const float* __restrict__
   for (int s = 0; s < S; ++s)
 #pragma unroll
     for (int r = 0; r < S; ++r) acc[s][r] = 0.f;
-  // the chunk's frames x bins as one flat range, so that F = 257 does not leave a nearly empty second sweep
   const int Tb = offs ? min(T, lens[b]) : T;  // packed rows end with the utterance
-  const int t0 = ch * TCH, nel = max(0, min(Tb, t0 + TCH) - t0) * F;
-  // (frame, bin) of element i = threadIdx.x + 256 k, carried along instead of divided out: an integer division by the run-time F
-  // per element cost more instructions than the element's arithmetic (r06: 26.5 -> see profiles/r06*_bench.json aux.pit_fwd)
-  int dt = threadIdx.x / F, f = threadIdx.x - dt * F;
-  const int dstep = 256 / F, fstep = 256 - dstep * F;
-#pragma unroll 2
-  for (int i = threadIdx.x; i < nel; i += 256) {
+  const int t0 = ch * TCH, nfr = max(0, min(Tb, t0 + TCH) - t0);
+  auto element = [&](int dt, int f) {
     const int64_t row = (offs ? (int64_t)offs[t0 + dt] : (int64_t)(t0 + dt) * B) + b;
     const float mx = mix[row * F + f];
     float sv[S];
@@ -57,12 +51,22 @@ __global__ __launch_bounds__(256) void pit_pair_kernel(const float* __restrict__
         acc[s][r] += d * d;
       }
     }
-    dt += dstep;
-    f += fstep;
-    if (f >= F) {
-      f -= F;
-      ++dt;
-    }
+  };
+  // r06: whole 256-bin sweeps with the thread's bin fixed and the chunk's frames as the (unrolled) inner loop -- no index
+  // arithmetic per element and (2S + 1) x 4 independent loads in flight per thread; r05 walked the chunk as one flat range and
+  // divided every element's index by the run-time F (more instructions than the element's arithmetic, one load batch in flight:
+  // 26.5 us for 65.8 MB).  The F - 256 floor(F / 256) left-over bins (F = 257: one) x the chunk's frames are dealt to the first
+  // threads as a flat range, so that they do not cost a nearly empty sweep.
+  const int fullc = F & ~255;
+  for (int f0 = 0; f0 < fullc; f0 += 256) {
+    const int f = f0 + threadIdx.x;
+#pragma unroll 4
+    for (int dt = 0; dt < nfr; ++dt) element(dt, f);
+  }
+  const int tail = F - fullc;
+  for (int i = threadIdx.x; i < nfr * tail; i += 256) {
+    const int dt = i / tail;
+    element(dt, fullc + i - dt * tail);
   }
 #pragma unroll
   for (int s = 0; s < S; ++s)

@@ -21,7 +21,7 @@ BUILD_FLAG_NAMES = {0x1: "TIMING_ONLY (wrong results by construction)", 0x2: "AR
 def build_flag_names(mask):
     return [n for b, n in sorted(BUILD_FLAG_NAMES.items()) if mask & b] + (["unknown 0x%x" % (mask & ~0xf)] if mask & ~0xf else [])
 
-SK_VERSION = 130
+SK_VERSION = 131
 
 _p, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -43,12 +43,14 @@ PROTOTYPES = {
     "sk_gemm_bf16_nt": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "sk_gemm_bf16_mm": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _i, _p, _p]),
     "sk_cast_bf16_rows": (_i, [_p, _i, _i, _i, _p, _i, _i, _p]),
+    "sk_split_rows": (_i, [_p, _i, _i, _i, _p, _i, _i, _i64, _p]),
+    "sk_gemm_pl3_tn": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i64, _i64, _i, _i, _i64, _i64, _i64, _i, _p, _p]),
     "sk_pack_rows": (_i, [_p, _p, _p, _i, _i, _i, _p, _i, _p]),
     "sk_unpack_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _p, _p]),
     "sk_hprev_rows": (_i, [_p, _i, _p, _p, _i, _i, _i, _p, _i, _i, _p]),
     "sk_lstm_workspace_bytes": (_sz, [_i, _i, _i]),
     "sk_lstm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _p]),
+    "sk_lstm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i64, _p, _i, _i, _i, _i, _p]),
     "sk_lstm_status": (_i, [_p, _p]),
     "sk_gate_rows": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "sk_bn_workspace_bytes": (_sz, [_i, _i]),

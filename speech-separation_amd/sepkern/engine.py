@@ -128,9 +128,11 @@ class Engine:
         # product with flags.  bench.py's config.numerics says which one ran.  Backward: the XCD map only.
         def variant(env, default):
             v = [int(x) for x in os.environ.get(env, default).split(",")]
-            v += [0] * (8 - len(v))
-            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5], tagged=bool(v[6]), split3=bool(v[7]))
-        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0,0,0" if self.bf16 else
+            v += [0] * (9 - len(v))
+            return ops.lstm_variant_bits(bool(v[0]), v[1], bool(v[2]), bool(v[3]), bool(v[4]), v[5], tagged=bool(v[6]), split3=bool(v[7]),
+                                         xl8=bool(v[8]))
+        # (bf16, r06: ninth field = XCD-local streams of 8 rows where the shape allows them -- 608 < H <= 896, B <= 32; mode bit 30)
+        self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0,0,0,1" if self.bf16 else
                                 ("0,1,1,0,0,0,0,1" if hidden <= 896 else "0,1,1,0,0,8,1,0"))
         self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31,0,0")
         self.split3_fwd = bool(self.fwd_bits & 0x10000000) and not self.bf16 and hidden <= 896
@@ -155,6 +157,13 @@ class Engine:
         self.var_proj = v[2] if len(v) > 2 else None
         self.var_dgrad = v[3] if len(v) > 3 else None
         self.pad_in = int(os.environ.get("SEPKERN_PAD_IN", "16"))   # diagnostics: 4 = the r04 padding of the input width
+        # r06, "operands that arrive split" (fp32): the weight gradients -- T/N products of activation / gradient matrices, most of
+        # them hosted beside a backward recurrence -- read operands their producers already cut into the three bf16 pieces: the
+        # backward recurrence writes dgx's planes with the fp32 values, the layer inputs and recurrent inputs are split once in the
+        # forward pass (side stream), and sk_gemm_pl3_tn multiplies the planes with no VALU work in its K loop.  Bit for bit the
+        # products of the 128 x 128 split kernel.  SEPKERN_WGRAD_PLANES=0: that kernel on the fp32 operands (the r05 arrangement).
+        # (hidden sizes that are no multiple of 8: the second direction's columns of a plane would start off a 16-byte boundary)
+        self.wgrad_planes = os.environ.get("SEPKERN_WGRAD_PLANES", "1") != "0" and not self.bf16 and hidden % 8 == 0
         # diagnostics: sk_lstm_bwd mode bit 29 for the top layer's launch (1) or every layer's (2) -- read by timing-only builds
         # of the recurrence alone (csrc/lstm.hip SK_BWD_BOUND38); the product library ignores the bit
         self.bwd_diag = int(os.environ.get("SEPKERN_BWD_DIAG", "0"))
@@ -263,6 +272,11 @@ class Engine:
         co-resident with a recurrence (side stream): the register-staged GEMM kernel, which leaves the recurrence more of
         the matrix pipe than the LDS-DMA one does (measured: same step time with either, 2 ms longer recurrences with the
         latter)."""
+        if isinstance(dout2d, ops.Planes):              # operands that arrive split (fp32): both factors as planes
+            N = dout2d.C if N is None else N
+            K = inp2d.C if K is None else K
+            ops.gemm_pl3_tn(dout2d, inp2d, gw, N, K, dout2d.rows, accumulate=acc, batch=batch, sA=sA, sB=sB, sC=sC, splitk=0, ws_tag=ws_tag)
+            return
         Rp = dout2d.shape[0]
         N = dout2d.shape[1] if N is None else N
         K = inp2d.shape[1] if K is None else K
@@ -342,6 +356,8 @@ class Engine:
                 ahead_ev = torch.cuda.Event()
                 ahead_ev.record(side)
         inp, I = x2d, I0
+        planes = save and self.wgrad_planes
+        inp_pl = None                                       # the planes of the current layer's input (made beside the layer below)
         for l in range(L):
             whh = self.p("weight_hh_l%d" % l)
             if l in ahead:
@@ -358,6 +374,18 @@ class Engine:
             if Ip != I or inp.shape[0] < Rp or not inp.is_contiguous() or (l == 0 and Rp > R):
                 inp = ops.pad_rows(inp[:R], Ip, rows=Rp)   # one pass, no memset (F = 257 -> 260; tail rows zero)
             gx = pk.rows(8 * H)                              # (Rp, 2, 4H): projections -> saved gates -> dgx, in place
+            if planes and l == 0:
+                # the (padded) network input as planes, for layer 0's weight gradient: on the side stream beside its projection
+                if use_side:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    with torch.cuda.stream(side):
+                        inp_pl = ops.split_rows(inp, R)
+                    inp_pl.t.record_stream(main)
+                    inp.record_stream(side)
+                else:
+                    inp_pl = ops.split_rows(inp, R)
             self._proj(cache, inp, wih_gi, gx, bsum, R)
             y = pk.rows(2 * H)
             cs = torch.empty(Rp, 2 * H, device=dev) if save else None
@@ -365,24 +393,33 @@ class Engine:
             ws = ops.lstm_fwd(gx, whh, h0l, c0[2 * l:2 * l + 2], lens, y, gx if save else None, cs,
                               hn[2 * l:2 * l + 2] if want_state else None, cn[2 * l:2 * l + 2] if want_state else None,
                               T, B, H, self.lstm_mode | self.fwd_bits, bf16=self.bf16, offs=offs, rows=R)
-            hp = hp_ev = None
+            hp = hp_ev = y_pl = None
             if save:
                 # the recurrent inputs of the layer's rows, for its recurrent weight gradient: gathered HERE, on the side
                 # stream beside the next layer's projection, not in the backward pass where the side stream is the bound
+                # (fp32, operands that arrive split: cut into their planes there too, and so is y -- the next layer's input, or the
+                # Linear layer's: the other factor of their weight gradients)
+                def side_work():
+                    hp_ = self._hprev(y, h0l, pk)
+                    if planes:
+                        return ops.split_rows(hp_, R), ops.split_rows(y, R)
+                    return hp_, None
                 if use_side:
                     ev = torch.cuda.Event()
                     ev.record(main)
                     side.wait_event(ev)
                     with torch.cuda.stream(side):
-                        hp = self._hprev(y, h0l, pk)
+                        hp, y_pl = side_work()
                         hp_ev = torch.cuda.Event()
                         hp_ev.record(side)
-                    hp.record_stream(main)
+                    for t_ in (hp, y_pl):
+                        if t_ is not None:
+                            (t_.t if planes else t_).record_stream(main)
                     y.record_stream(side)
                 else:
-                    hp = self._hprev(y, h0l, pk)
-            saved.append((inp, gx, cs, y, wih_gi, hp, hp_ev))
-            inp, I = y, 2 * H
+                    hp, y_pl = side_work()
+            saved.append((inp, gx, cs, y, wih_gi, hp, hp_ev, inp_pl))
+            inp, I, inp_pl = y, 2 * H, y_pl
         if not save and not skdist.is_parallel():
             # inference: the caller copies the masks to the host next, a sync costs nothing.  Under data parallelism a
             # raise on ONE rank would leave the others waiting in their next collective: there the sticky word stays set
@@ -418,7 +455,7 @@ class Engine:
             self._proj(cache, xbn, self.p("lin.weight"), mask, self.p("lin.bias"), R, act=1)
         ctx = None
         if save:
-            ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, fold=fold, mask=mask, pk=pk, h0=h0,
+            ctx = dict(saved=saved, mean=mean, var=var, bn_count=bn_count, xbn=xbn, fold=fold, mask=mask, pk=pk, h0=h0, ytop_pl=inp_pl,
                        c0=c0, training=training, version=self.param_version(),
                        # bf16: the backward pass multiplies the SAME row-major copies of the weights and of every layer
                        # input (none of them is written in between), so they are made once per step
@@ -488,7 +525,12 @@ class Engine:
                 # dW = dz^T bn(y) = (dz^T y) diag(s) + colsum(dz) t^T  (sk_bn_unfold_grad): the product runs against y itself
                 G = torch.empty(O, 2 * H, device=dev)
                 dzsum = torch.empty(O, device=dev)
-                self._wgrad(cache, dz, y_top, G, False, "gemm" + tag, beside=overlap)
+                if ctx.get("ytop_pl") is not None:
+                    dz_pl = ops.split_rows(dz, R)            # (R x O: a tenth of a layer's dgx)
+                    self._wgrad(cache, dz_pl, ctx["ytop_pl"], G, False, "gemm" + tag, beside=overlap)
+                    keep.append(dz_pl)
+                else:
+                    self._wgrad(cache, dz, y_top, G, False, "gemm" + tag, beside=overlap)
                 ops.colsum(dz, R, O, O, dzsum, ws_tag="bn" + tag)
                 ops.bn_unfold_grad(G, dzsum, ctx["fold"][0], ctx["fold"][1], self.g("lin.weight"), accumulate=acc)
                 if acc:
@@ -509,7 +551,7 @@ class Engine:
         dc0 = torch.empty(2 * L, B, H, device=dev) if want_dstate else None
         dx = None
         for l in range(L - 1, -1, -1):
-            inp, gates, cs, y, wih_gi, hp, hp_ev = ctx["saved"][l]      # inp: (Rp, I padded to a multiple of 4)
+            inp, gates, cs, y, wih_gi, hp, hp_ev, inp_pl = ctx["saved"][l]      # inp: (Rp, I padded to a multiple of 4)
             I = I0 if l == 0 else 2 * H
             Ip = inp.shape[1]
             whh = self.p("weight_hh_l%d" % l)
@@ -525,6 +567,8 @@ class Engine:
             # bf16: the recurrence writes dgx a second time as bf16 -- the operand copy its three products read (data
             # gradient, dW_ih, dW_hh) -- instead of a cast pass over 4 x the bytes between recurrence and products
             twin = None
+            if inp_pl is not None:                       # fp32: dgx also as its three bf16 planes, for the two weight gradients
+                twin = ops.Planes.empty(R, 8 * H, dev)
             if self.nt:
                 rows, ld = ops.pad_to(Rp, 64) + 64, ops.pad_to(8 * H, 64)
                 twin = (torch.empty if ld == 8 * H else torch.zeros)(rows, ld, dtype=torch.bfloat16, device=dev)
@@ -534,7 +578,7 @@ class Engine:
                               dc0[sl] if want_dstate else None, T, B, H, mode,
                               dhn=dhn[sl] if dhn is not None else None, dcn=dcn[sl] if dcn is not None else None, bf16=self.bf16,
                               dbias=dbias, dgx_bf16=twin, offs=offs, rows=R)
-            if twin is not None:
+            if twin is not None and self.nt:
                 ev = torch.cuda.Event()
                 ev.record(main)
                 cache[(dgx.data_ptr(), tuple(dgx.shape))] = (twin, ev, main, dgx)
@@ -554,10 +598,13 @@ class Engine:
                 tag = "side" if stream is not main else "main"
                 beside = stream is not main
                 # dW_hh[d] = sum_rows dG[:, d]^T hprev[:, d-half]: both directions as one batched launch
-                self._wgrad(cache, dgx, hp, gw_hh, False, "gemm_" + tag, beside, batch=2, sA=4 * H, sB=H, sC=4 * H * H,
+                pl = inp_pl is not None
+                self._wgrad(cache, twin if pl else dgx, hp, gw_hh, False, "gemm_" + tag, beside, batch=2, sA=4 * H, sB=H, sC=4 * H * H,
                             N=4 * H, K=H)
                 # dW_ih (both directions stacked as (8H, I)) = dgx^T x_in
-                self._wgrad(cache, dgx, inp, gw_ih, False, "gemm_" + tag, beside)
+                self._wgrad(cache, twin if pl else dgx, inp_pl if pl else inp, gw_ih, False, "gemm_" + tag, beside)
+                if pl:
+                    keep += [twin, inp_pl]
                 ops.gate_rows(gw_hh, H, back=True, out=self.g("weight_hh_l%d" % l), accumulate=acc)
                 ops.gate_rows(gw_ih, H, back=True, out=self.g("weight_ih_l%d" % l).view(8 * H, I), accumulate=acc, cols=I)
                 db = torch.empty(8 * H, device=dev)

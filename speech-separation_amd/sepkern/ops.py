@@ -169,6 +169,50 @@ def cast_bf16(x2d, ld=None, out=None, rows=None):
     return out
 
 
+class Planes:
+    """The three bf16 planes (hi, mid, lo pieces: x = hi + mid + lo exactly) of an fp32 (R, C) matrix: t is a (3, rows, ld)
+    bfloat16 tensor, ld = C rounded up to 8, rows >= R rounded up to 64 with zero tail rows ("operands that arrive split",
+    include/sepkern.h).  Made by split_rows() or by lstm_bwd(dgx_bf16=Planes.empty(...))."""
+
+    def __init__(self, t, R, C):
+        self.t, self.R, self.C = t, R, C
+        self.rows, self.ld = t.shape[1], t.shape[2]
+        self.plane = t.stride(0)
+
+    @staticmethod
+    def empty(R, C, device, zero_tail=True):
+        rows, ld = pad_to(R, 64), pad_to(C, 8)
+        t = torch.empty(3, rows + 1, ld, dtype=torch.bfloat16, device=device)[:, :rows]     # (+1 row: a clamped edge tile may read past the last row's end)
+        if zero_tail and (rows > R or ld > C):
+            t[:, R:].zero_()
+            if ld > C:
+                t[:, :, C:].zero_()
+        return Planes(t, R, C)
+
+
+def split_rows(x2d, R=None):
+    """Planes of the first R rows of an fp32 (>= R, C) matrix (sk_split_rows: one pass, 4 bytes read and 6 written per element)."""
+    _chk(x2d)
+    R = x2d.shape[0] if R is None else R
+    Cc = x2d.shape[1]
+    pl = Planes.empty(R, Cc, x2d.device, zero_tail=False)
+    with _timed("split_rows_kernel", 0.0):
+        _lib.call("sk_split_rows", _ptr(x2d), R, Cc, x2d.stride(0), _ptr(pl.t), pl.ld, pl.rows, pl.plane, _stream())
+    return pl
+
+
+def gemm_pl3_tn(A, B, Cout, M, N, K, accumulate=False, batch=1, sA=0, sB=0, sC=0, splitk=1, ws_tag="gemm"):
+    """Cout[M, N] (+)= A^T B with A, B Planes whose rows are the contraction index (K <= their row counts, K % 16 == 0): the weight
+    gradients on operands that arrive split (sk_gemm_pl3_tn).  batch / strides (in columns) / splitk (0 = choose) as gemm()."""
+    _chk(Cout)
+    if splitk == 0:
+        splitk = pick_splitk(M, N, K, batch)
+    ws = workspace(_lib.load().sk_gemm_workspace_bytes(M, N, batch, splitk), ws_tag) if splitk > 1 else None
+    with _timed("gemm_f32_split_kernel", 2.0 * M * N * K * batch):
+        _lib.call("sk_gemm_pl3_tn", _ptr(A.t), _ptr(B.t), _ptr(Cout), M, N, K, A.ld, B.ld, Cout.stride(-2), A.plane, B.plane,
+                  int(accumulate), batch, sA, sB, sC, int(splitk), _ptr(ws), _stream())
+
+
 def gemm_bf16_nt(A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, accumulate=False, act=0, batch=1, sA=0, sB=0, sC=0,
                  sbias=0, splitk=1, ws_tag="gemm", streamk=False):
     """Cout[M,N] = act(A[M,K] B[N,K]^T + bias (+ Cout)) with A, B bfloat16 tensors (K-contiguous, K % 64 == 0).
@@ -585,18 +629,21 @@ def lstm_ws(T, B, H):
     return workspace(n, "lstm")
 
 
-def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0, tagged=False, split3=False):
+def lstm_variant_bits(half=False, blockmap=0, poll1=False, repflags=False, spread=False, poll_delay=0, tagged=False, split3=False,
+                      xl8=False):
     """Geometry / protocol variants of the persistent recurrence (speed only; include/sepkern.h, mode bits 17..29);
     poll_delay: the forward kernel's polling wave holds its first poll of a step back (units of 0.1 us, 0 = the library's
     choice, 31 = none); tagged (forward, fp32): the exchanged h carries the step's epoch in its two low mantissa bits and
     nothing else is signalled (mode bit 29); split3 (forward, fp32): the product h W_hh^T by the exact three-way bf16 split
-    of both operands on the bf16 matrix pipe (mode bit 28; flags hand-off, the tagged one does not combine with it)."""
+    of both operands on the bf16 matrix pipe (mode bit 28; flags hand-off, the tagged one does not combine with it); xl8 (forward,
+    bf16, 608 < H <= 896, B <= 32, persistent launches; other shapes run the ordinary form): XCD-local streams of 8 rows x 28
+    workgroups of 32 units with a plain-store hand-off (mode bit 30) -- the same arithmetic bit for bit."""
     if half:      # (the first field of SEPKERN_LSTM_FWD / _BWD keeps its place so that recorded switch strings stay readable)
         raise _lib.SepkernError("the 8-unit / 256-thread forward recurrence (field `half`, mode bit 17) was retired in r05: "
                                 "measured slower at every shape (DESIGN_HISTORY.md)")
     return (((int(blockmap) & 3) << 18) | (0x100000 if poll1 else 0) |
             (0x200000 if repflags else 0) | (0x400000 if spread else 0) | ((int(poll_delay) & 31) << 23) |
-            (0x20000000 if tagged else 0) | (0x10000000 if split3 else 0))
+            (0x20000000 if tagged else 0) | (0x10000000 if split3 else 0) | (0x40000000 if xl8 else 0))
 
 
 def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=False, blockmap=0, offs=None, rows=None):
@@ -615,7 +662,13 @@ def lstm_fwd(gx, whh, h0, c0, lens, y, gates, cs, hn, cn, T, B, H, mode=0, bf16=
 def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=None, dcn=None, bf16=False,
              dbias=None, dgx_bf16=None, offs=None, rows=None):
     """dbias ((B+15)//16, 2, 4H): optional by-product (include/sepkern.h), its column sum is the bias gradient.
-    dgx_bf16: a (rows, ld >= 8H) bfloat16 tensor that receives dgx as bf16 as well.  offs: as lstm_fwd."""
+    dgx_bf16: a (rows, ld >= 8H) bfloat16 tensor that receives dgx as bf16 as well -- or (fp32 configuration) a Planes object:
+    dgx's three exact bf16 pieces, the operand gemm_pl3_tn reads.  offs: as lstm_fwd."""
+    plane = 0
+    if isinstance(dgx_bf16, Planes):
+        if bf16:
+            raise _lib.SepkernError("lstm_bwd: planes of dgx belong to the fp32 configuration")
+        plane, dgx_bf16 = dgx_bf16.plane, dgx_bf16.t[0]
     ws = lstm_ws(T, B, H)
     mode = int(mode) | (0x10000 if bf16 else 0)
     _chk(dbias)
@@ -626,7 +679,7 @@ def lstm_bwd(dy, whh, gates, cs, c0, lens, dgx, dh0, dc0, T, B, H, mode=0, dhn=N
     with _timed("lstm_bwd_kernel", 2.0 * (T * B if rows is None else rows) * 2 * 4 * H * H):
         _lib.call("sk_lstm_bwd", _ptr(dy), _ptr(dhn), _ptr(dcn), _ptr(whh), _ptr(gates), _ptr(cs), _ptr(c0),
                   _ptr(lens), _ptr(offs), _ptr(dgx), _ptr(dh0), _ptr(dc0), _ptr(dbias), _ptr(dgx_bf16),
-                  0 if dgx_bf16 is None else dgx_bf16.stride(0), _ptr(ws), T, B, H, mode, _stream())
+                  0 if dgx_bf16 is None else dgx_bf16.stride(0), int(plane), _ptr(ws), T, B, H, mode, _stream())
     return ws
 
 

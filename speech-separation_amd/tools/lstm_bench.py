@@ -49,12 +49,13 @@ def main():
         for s in spec.split(";"):
             if s:
                 v = [int(x) for x in s.split(",")]
-                out.append(tuple(v + [0] * (9 - len(v))))
+                out.append(tuple(v + [0] * (10 - len(v))))
         return out
     fwd_vars, bwd_vars = parse(a.fwd), parse(a.bwd)
 
     def bits(var):
-        return ops.lstm_variant_bits(bool(var[0]), var[1], bool(var[2]), bool(var[3]), bool(var[5]), var[6], tagged=bool(var[7]), split3=bool(var[8])) | (var[4] << 8)
+        return ops.lstm_variant_bits(bool(var[0]), var[1], bool(var[2]), bool(var[3]), bool(var[5]), var[6], tagged=bool(var[7]), split3=bool(var[8]),
+                                     xl8=bool(var[9])) | (var[4] << 8)
 
     def run_fwd(var):
         g = gx.clone()
@@ -103,10 +104,10 @@ def main():
     print("BLSTM recurrence, T=%d B=%d H=%d %s%s: us per step (median / min over %d rounds), max |diff| vs first variant"
           % (T, B, H, "bf16" if bf else "fp32", " ragged" if a.ragged else "", a.rounds))
     for v in fwd_vars:
-        print("  fwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d tagged=%d split3=%d : %7.3f / %7.3f   diff %.3g"
+        print("  fwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d tagged=%d split3=%d xl8=%d : %7.3f / %7.3f   diff %.3g"
               % (v + (1e3 * statistics.median(tf[v]) / T, 1e3 * min(tf[v]) / T, df[v])))
     for v in bwd_vars:
-        print("  bwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d tagged=%d split3=%d : %7.3f / %7.3f   diff %.3g"
+        print("  bwd half=%d map=%d poll1=%d rep=%d gmin=%d spread=%d delay=%d tagged=%d split3=%d xl8=%d : %7.3f / %7.3f   diff %.3g"
               % (v + (1e3 * statistics.median(tb[v]) / T, 1e3 * min(tb[v]) / T, db[v])))
 
 

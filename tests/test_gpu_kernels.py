@@ -957,6 +957,42 @@ def test_lstm_geometry_and_protocol_variants_are_bitwise_identical(ops, layout, 
 
 
 @pytest.mark.parametrize("layout", ["padded", "packed"])
+@pytest.mark.parametrize("T,B,H,lens,delay", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1], 0), (40, 27, 896, [40] * 9 + [21] * 14 + [3] * 4, 4),
+                                              (9, 20, 704, [9] * 7 + [4] * 13, 31), (33, 8, 896, [33] * 3 + [20] * 5, 0), (7, 32, 600, [7] * 32, 0),
+                                              (6, 40, 896, [6] * 40, 0)])
+def test_lstm_forward_bf16_xcd_local_streams_of_eight_rows(ops, layout, T, B, H, lens, delay):
+    """Mode bit 30 (bf16 forward, 608 < H <= 896, B <= 32, r06): every (direction, 8-row batch group) stream is 28 workgroups of
+    32 units on ONE XCD, h_t published with plain stores and a plain flag (the XCD's L2 is the coherence point; sc1 polls and
+    pulls), 14 KB pulled per step.  Who computes what and how it is signalled changes, the arithmetic does not: every output equals
+    the ordinary bf16 form's bit for bit, run after run, with ragged lengths, B not a multiple of 8, hidden sizes that leave part
+    of the last unit group empty; the status word stays clear.  H = 600 and B = 40 take the ordinary form (the bit is ignored)."""
+    g = torch.Generator().manual_seed(H + T)
+    rw = _Rows(layout, T, B, lens)
+    gx = rw.put(torch.randn(T, B, 2, 4 * H, generator=g) * 0.5)
+    whh = (torch.randn(2, 4 * H, H, generator=g) / 30).cuda()
+    h0, c0 = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+
+    def fwd(bits):
+        gg = gx.clone()
+        y, cs = rw.new(2 * H, 0.0), rw.new(2 * H, 0.0)
+        hn, cn = torch.empty(2, B, H).cuda(), torch.empty(2, B, H).cuda()
+        ws = ops.lstm_fwd(gg, whh, h0, c0, rw.lens, y, gg, cs, hn, cn, T, B, H, 1 | bits, bf16=True, offs=rw.offs)
+        ops.lstm_status(ws)
+        return y, gg, cs, hn, cn
+
+    def rows_of(a):
+        if a.dim() == 2 and a.shape[0] == rw.R and not rw.packed and a.shape[1] in (8 * H, 2 * H):
+            return a.view(T, B, -1)[rw.valid]
+        return a[:rw.pk.R] if (a.dim() == 2 and a.shape[0] == rw.R) else a
+
+    ref = fwd(ops.lstm_variant_bits(False, 1, True, False, True, 0))
+    for rep in range(2):
+        out = fwd(ops.lstm_variant_bits(False, 1, True, False, True, delay, xl8=True))
+        for a_, b_ in zip(out, ref):
+            assert torch.equal(rows_of(a_), rows_of(b_))
+
+
+@pytest.mark.parametrize("layout", ["padded", "packed"])
 @pytest.mark.parametrize("T,B,H,lens,delay", [(12, 32, 896, [12] * 20 + [7] * 8 + [2] * 3 + [1], 0), (30, 16, 896, [30] * 9 + [17] * 7, 31),
                                               (9, 100, 600, [9] * 60 + [4] * 40, 4), (7, 20, 300, [7] * 7 + [4] * 13, 8), (11, 3, 64, [11, 5, 1], 0)])
 def test_lstm_forward_tagged_hand_off(ops, layout, T, B, H, lens, delay):
@@ -1027,6 +1063,61 @@ def test_lstm_backward_bf16_twin_of_dgx(ops, T, B, H, lens, bf16):
         assert torch.equal(twin[:R, :8 * H], dgx.to(torch.bfloat16))
         assert float(dgx.abs().max()) > 0
         assert bool((twin[R:] == 7).all()) and bool((twin[:, 8 * H:] == 7).all())
+        if not bf16:
+            # fp32 (r06, operands that arrive split): dgx also as its THREE exact bf16 planes -- hi + mid + lo = dgx bit for bit,
+            # pieces of the sizes the split promises, zero tail rows left alone, dgx itself unchanged
+            pl = ops.Planes.empty(R, 8 * H, "cuda")
+            gg = gates.clone()
+            dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+            ops.lstm_status(ops.lstm_bwd(dy, whh, gg, cs, c0, rw.lens, gg, dh0, dc0, T, B, H, 1, dgx_bf16=pl, offs=rw.offs))
+            assert torch.equal(gg, outs[0][0]) and torch.equal(dh0, outs[0][1])
+            hi, mid, lo = (pl.t[i, :R].double() for i in range(3))
+            assert torch.equal((hi + mid + lo)[:, :8 * H], dgx.double())
+            assert bool((mid.abs() <= hi.abs() * 2.0 ** -8 + 1e-45).all()) and bool((lo.abs() <= hi.abs() * 2.0 ** -16 + 1e-45).all())
+            assert bool((pl.t[:, R:] == 0).all())
+
+
+@pytest.mark.parametrize("M,N,K,batch,splitk", [(512, 272, 1280, 1, 1), (514, 384, 2048, 1, 3), (256, 128, 1024, 2, 2), (300, 260, 64, 1, 1),
+                                                (1024, 512, 12800, 1, 5), (3584, 896, 1600, 2, 0)])
+def test_gemm_on_operands_that_arrive_split_is_bit_for_bit_the_split_kernel(ops, M, N, K, batch, splitk):
+    """sk_split_rows + sk_gemm_pl3_tn (r06): the T/N product on operands cut ONCE into their three bf16 planes equals the 128 x 128
+    split kernel (variant 2) on the fp32 operands bit for bit -- same pieces, same six products, same K order, same sign phases,
+    same slab sums -- with ragged tile edges (M = 514: clamped edge reads), batches taken out of wider matrices (the two
+    directions of dW_hh), K slices, accumulation; the planes reassemble the operand exactly and carry zero tails."""
+    g = torch.Generator().manual_seed(M + 7 * N + K)
+    R = K - 37 if K > 64 else K                                # valid rows: the planes' tail rows up to K are zero
+    A = torch.zeros(K, batch * M)
+    B = torch.zeros(K, batch * N)
+    A[:R] = torch.randn(R, batch * M, generator=g) * torch.exp2(torch.randint(-12, 13, (R, batch * M), generator=g).float())
+    B[:R] = torch.randn(R, batch * N, generator=g)
+    Ad, Bd = dev(A), dev(B)
+    Apl, Bpl = ops.split_rows(Ad, R), ops.split_rows(Bd, R)
+    for pl, X in ((Apl, A), (Bpl, B)):
+        assert pl.rows >= R and pl.rows % 64 == 0 and pl.ld % 8 == 0
+        parts = pl.t.cpu().double()
+        assert torch.equal(parts.sum(0)[:R, :X.shape[1]], X[:R].double())
+        assert bool((parts[:, R:] == 0).all()) and bool((parts[:, :, X.shape[1]:] == 0).all())
+    Kp = Apl.rows if K > 64 else K
+    C0 = torch.randn(batch, M, N, generator=g)
+    outs = []
+    for planes in (True, False):
+        for _ in range(2):
+            C = dev(C0.clone())
+            if planes:
+                ops.gemm_pl3_tn(Apl, Bpl, C, M, N, Kp, accumulate=True, batch=batch, sA=M, sB=N, sC=M * N, splitk=splitk, ws_tag="t_pl3")
+            else:
+                Az, Bz = torch.zeros(Kp, batch * M).cuda(), torch.zeros(Kp, batch * N).cuda()
+                Az[:K], Bz[:K] = Ad, Bd
+                ops.gemm(Az, Bz, C, M, N, Kp, batch * M, batch * N, N, transA=True, accumulate=True, batch=batch, sA=M, sB=N, sC=M * N,
+                         splitk=splitk, variant=2, ws_tag="t_pl3")
+            torch.cuda.synchronize()
+            outs.append(C.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[2], outs[3])          # run-to-run
+    ref = torch.stack([A[:, z * M:(z + 1) * M].double().t() @ B[:, z * N:(z + 1) * N].double() for z in range(batch)]) + C0.double()
+    mag = torch.stack([A[:, z * M:(z + 1) * M].double().abs().t() @ B[:, z * N:(z + 1) * N].double().abs() for z in range(batch)])
+    assert float(((outs[0].double() - ref).abs() / (mag + 1e-30)).max()) < 2.0 ** -23 * 4 * np.sqrt(K)
+    if M % 4 == 0:                                            # (M = 514: the fp32 split kernel's LDS-DMA conditions do not hold, variant 2 falls back)
+        assert torch.equal(outs[0], outs[2])
 
 
 @pytest.mark.parametrize("H,B", [(896, 32), (600, 48), (304, 16)])
