@@ -276,8 +276,11 @@ size_t sk_lstm_workspace_bytes(int T, int B, int H);
 int sk_lstm_fwd(const float* gx, const float* whh, const float* h0, const float* c0, const int32_t* lens,
                 const int32_t* offs, float* y, float* gates, float* cs, float* hn, float* cn, void* ws,
                 int T, int B, int H, int mode, sk_stream_t stream);
-/* Backward of the recurrence.  mode as sk_lstm_fwd (bits 0..7, 8..15, 16, 18..19, 22, 23..27; bit 29: read by timing-only
- * diagnostic builds alone).  dy (T,B,2H) is the gradient of the layer output, dhn / dcn (2,B,H; either may be NULL = 0)
+/* Backward of the recurrence.  mode as sk_lstm_fwd (bits 0..7, 8..15, 16, 18..19, 22, 23..27, 30; bit 29: read by timing-only
+ * diagnostic builds alone); bit 17 (speed only, r06): EXCLUSIVE -- the instantiation whose LDS footprint (127 KB) leaves no room
+ * for a workgroup of sk_gemm_pl3_tn beside it, so that products enqueued on other streams take the CUs the grid leaves free instead
+ * of sharing the recurrence's (without the bit and with one batch group per workgroup: 113 KB, such a workgroup fits).
+ * dy (T,B,2H) is the gradient of the layer output, dhn / dcn (2,B,H; either may be NULL = 0)
  * the gradient wrt the final state (the RSH arch carries the hidden state from pass to pass, reference archs/RSH.py:172);
  * produces dgx (T,B,2,4H) = gradient of the gate pre-activations (gate-interleaved like gx; padded layout: zero at padded
  * positions), from which the caller forms dW_ih, dW_hh (with sk_hprev_rows), db and dx with the GEMMs, and dh0/dc0

@@ -218,6 +218,7 @@ struct BwdArgs {
   long long pl_bf;  // 0: one bf16 copy (rounded: the bf16 configuration's operand); > 0 (fp32 kernel): THREE planes this many elements
                     // apart -- the exact hi / mid / lo pieces of dgx, the operand sk_gemm_pl3_tn reads ("operands that arrive split")
   int fast;  // mode bit 29: read by the timing-only build -DSK_BWD_BOUND38 alone
+  int exclusive;  // mode bit 17: the instantiation with the larger LDS footprint (no GEMM workgroup fits beside it), see launch_bwd
 };
 
 // Flag replication (opt bit 1): every producer raises its flag in NREP copies with ONE store instruction (NREP lanes,
@@ -1515,6 +1516,251 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
   }
 }
 
+// ------------------------------------------------------------------------------------ backward, bf16: XCD-local streams of 8 rows
+// The backward twin of lstm_fwd_xl8_kernel (r06, mode bit 30): a stream = (direction, 8-row batch group) = 28 workgroups x 32 OUT
+// units on one XCD; per step a workgroup publishes the dG of its 256 cells (32 units x 4 gates x 8 rows bf16 = 2 KB: four 512-byte
+// chunks of the stream's image [k' / 32][4 octets][8 rows][8]) with PLAIN stores and a plain flag, polls 28 flags and pulls the
+// stream's 56 KB (instead of 112 KB): every wave its eighth of k' = 4H, seven 1 KB LDS-DMAs issued together and consumed behind
+// counted vmcnt waits.  A wave multiplies both 16-unit tiles of the workgroup with each fragment (the MFMA's 16 columns carry the 8
+// rows twice, as in the forward kernel), the 8 x 2 partial tiles meet in LDS, and the four owner waves (one per SIMD) hold all 256
+// cells: lane (u_l, n) owns out unit 16 (n >> 3) + 4 w + u_l, row n & 7.  W_hh^T for 32 out units: 112 VGPRs.  Same products, same
+// K order, same sums as lstm_bwd_kernel<KS, true>: bit-identical dgx / dh0 / dc0 / dbias.  One batch group per workgroup (carry and
+// dc in registers); persistent launches only.
+template <int KS>
+__global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) void lstm_bwd_xl8_kernel(BwdArgs a) {
+  constexpr int HP = 16 * KS;
+  constexpr int NUG = HP / 32;      // workgroups per stream
+  constexpr int NCHK = HP * 4 / 32; // 512-byte chunks of a stream's dG image
+  constexpr int NQ = NCHK / 8;      // chunks per wave
+  constexpr int NDMA = NQ / 2;      // 1 KB LDS-DMAs per wave and step
+  static_assert(NCHK % 16 == 0 && NUG <= 32, "eight waves x pairs of chunks; one XCD per stream");
+  __shared__ __attribute__((aligned(1024))) float ring_all[8][NQ * 128];
+  __shared__ float red[8][2][256];
+  __shared__ __attribute__((aligned(16))) float st_db[256][4];
+  __shared__ long long st_tpub;
+  __shared__ int s_abort, s_slot;
+  __shared__ int s_len[8];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int T = a.T, B = a.B, H = a.H, NBG = a.NBG;  // NBG: batch groups of EIGHT rows
+  const int stream = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);  // HW_REG_XCC_ID[3:0]
+  if (tid == 0) {
+    s_slot = (stream < 2 * NBG) ? (int)__hip_atomic_fetch_add(a.ctrl + 32 + stream, 1u, SK_RLX, SK_AGENT) : NUG;
+    s_abort = 0;
+  }
+  __syncthreads();
+  const int ug = s_slot;
+  if (ug >= NUG) return;  // (uniform)
+  const int bg = stream % NBG, dir = stream / NBG;
+  float* const ring = &ring_all[w][0];
+
+  // ---- W_hh^T slice -> registers: tiles tt = 0, 1 (out units ug*32 + 16 tt + i); chunk c of this wave holds
+  //      k' = 32 (w NQ + c) + 8 (l >> 4) + j, i.e. unit_k = 8 (w NQ + c) + 2 (l >> 4) + (j >> 2), gate j & 3
+  bf16x8 wreg[2][NQ];
+  {
+    const int i = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int uout = ug * 32 + 16 * tt + i;
+      // Unconditional loads from clamped addresses + a mask (per-element "load or zero" branches serialise the 224 loads of the
+      // slice, each behind its own s_waitcnt).  The element offset of (chunk c, slot j) is min(off0_j + c 8 H, lim_j): eight
+      // running 32-bit offsets -- computed afresh per load the scheduler hoists all 224 address computations to the top (256
+      // VGPRs and spills in a kernel whose loop needs ~190, and no GEMM wave fits beside it)
+      const float* wbase = a.whh + (size_t)dir * 4 * H * H + min(uout, H - 1);
+      unsigned off[8], lim[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        off[j] = (unsigned)(((j & 3) * H + 8 * (w * NQ) + 2 * kq + (j >> 2)) * H);
+        lim[j] = (unsigned)(((j & 3) * H + (H - 1)) * H);
+      }
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int unit_k = 8 * (w * NQ + c) + 2 * kq + (j >> 2);
+          const float x = wbase[min(off[j], lim[j])];
+          v[j] = __uint_as_float(__float_as_uint(x) & ((uout < H && unit_k < H) ? 0xffffffffu : 0u));
+          off[j] += 8u * (unsigned)H;
+        }
+        wreg[tt][c] = pack8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+        asm volatile("" ::"v"(wreg[tt][c]) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+
+  const int u_l = lane >> 4, n = lane & 15, sel = n >> 3, r = n & 7;
+  const bool owner = w < 4;
+  const int unit = ug * 32 + 16 * sel + 4 * (w & 3) + u_l;
+  const int b = bg * 8 + r;
+  const bool cellok = owner && unit < H && b < B;
+  const int oi = (w & 3) * 64 + lane;
+  // carry = gradient wrt h that passes straight through a frozen (padded) step; starts as the gradient arriving at the final state
+  float carry = 0.f, dc_rec = 0.f;
+  if (cellok) {
+    const size_t o = ((size_t)dir * B + b) * H + unit;
+    if (a.dhn) carry = a.dhn[o];
+    if (a.dcn) dc_rec = a.dcn[o];
+  }
+  if (tid < 8) s_len[tid] = (bg * 8 + tid < B) ? a.lens[bg * 8 + tid] : 0;
+  if (owner) *reinterpret_cast<f32x4*>(&st_db[oi][0]) = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  constexpr unsigned XBYTES = (unsigned)NCHK * 512u;  // bytes per (parity, stream) exchange block
+  unsigned* const myflags = a.flags + (size_t)stream * NUG * FSPREAD;
+  const unsigned ring_lds = __builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)ring);
+  const unsigned xpos = (unsigned)xl_img(4 * unit, r) * 2u;  // byte position of this cell's four gate gradients in the image
+  const int len_b = s_len[r];
+  const int Tg = a.offs ? s_len[0] : T;
+  const int s_hi = min(a.s_end, Tg);
+  auto row_base = [&](int tt) { return (tt < 0 || tt >= T) ? 0 : (a.offs ? a.offs[tt] : tt * B); };
+
+  // dh from the dG image of parity `par`: returns, for the owner lanes, sum over all k' of dG * W for their (unit, row)
+  auto matmul = [&](int par) -> float {
+    const unsigned xo = ((unsigned)par * 8u + (unsigned)stream) * XBYTES + (unsigned)w * (NQ * 512u);
+    f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+    __builtin_amdgcn_sched_barrier(0);  // the counted waits below assume the DMAs are this wave's youngest vector-memory operations
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) dma_piece_s(a.xbuf, xo + i * 1024u, ring_lds + i * 1024u, lane);
+    const float* src = ring + ((lane >> 4) * 8 + r) * 4;
+#define SK_XL8_PIECE(I)                                                                                         \
+    if constexpr (I < NDMA) {                                                                                     \
+      wait_vmcnt<NDMA - 1 - I>();                                                                                 \
+      const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(src + (2 * I) * 128);                                    \
+      const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(src + (2 * I + 1) * 128);                                \
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[0][2 * I], f0, acc[0][0], 0, 0, 0);               \
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[1][2 * I], f0, acc[1][0], 0, 0, 0);               \
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[0][2 * I + 1], f1, acc[0][1], 0, 0, 0);           \
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[1][2 * I + 1], f1, acc[1][1], 0, 0, 0);           \
+    }
+    SK_XL8_PIECE(0) SK_XL8_PIECE(1) SK_XL8_PIECE(2) SK_XL8_PIECE(3) SK_XL8_PIECE(4) SK_XL8_PIECE(5) SK_XL8_PIECE(6) SK_XL8_PIECE(7)
+#undef SK_XL8_PIECE
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[w][tt][red_slot(4 * (lane >> 4) + q, lane & 15)] = acc[tt][0][q] + acc[tt][1][q];
+    __syncthreads();
+    const int m = 4 * (w & 3) + (lane >> 4);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v += red[k][sel][red_slot(m, lane & 15)];
+    __syncthreads();
+    return v;
+  };
+
+  bool aborted = false;
+  for (int s = a.s_begin; s < s_hi; ++s) {
+    const int t = dir ? s : Tg - 1 - s;  // reverse of the forward processing order
+    const int rb = row_base(t);
+    const int rb_next = row_base(dir ? t + 1 : t - 1);
+    const bool valid = cellok && t < len_b;
+    const size_t row = (size_t)rb + b;
+    // 1. saved activations of this cell (independent of the recurrence: issue early)
+    float gi_ = 0.f, gf = 0.f, gg = 0.f, go = 0.f, ct = 0.f, cprev = 0.f, dyv = 0.f;
+    if (valid) {
+      const float4 gv = *reinterpret_cast<const float4*>(a.gates + (row * 2 + dir) * 4 * H + 4 * (size_t)unit);
+      gi_ = gv.x; gf = gv.y; gg = gv.z; go = gv.w;
+      ct = a.cs[(row * 2 + dir) * H + unit];
+      const bool has_prev = dir ? (t + 1 < len_b) : (t > 0);
+      const size_t rowp = (size_t)rb_next + b;
+      cprev = has_prev ? a.cs[(rowp * 2 + dir) * H + unit] : a.c0[((size_t)dir * B + b) * H + unit];
+      dyv = a.dy[row * 2 * H + (size_t)dir * H + unit];
+    }
+    // 2. recurrent gradient from the step processed before this one
+    float dh_rec = 0.f;
+    if (s > 0) {
+      if (s > a.s_begin && w == 0) {
+        if (!wait_flags(myflags, NUG, (unsigned)s, a.ctrl, lane, a.poll_delay ? st_tpub + 10LL * a.poll_delay : 0LL, FSPREAD) && lane == 0)
+          s_abort = 1;
+      }
+      __syncthreads();
+      if (s_abort) {
+        aborted = true;
+        break;
+      }
+      dh_rec = matmul((s - 1) & 1);
+    }
+    // 3. cell backward (owner waves)
+    f32x4 dpre = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+      dh_rec += carry;
+      if (valid) {
+        const float dh = dyv + dh_rec;
+        const float tc = fast_tanh(ct);
+        const float dout = dh * tc;
+        const float dc = dc_rec + dh * go * (1.0f - tc * tc);
+        dpre[0] = dc * gg * gi_ * (1.0f - gi_);
+        dpre[1] = dc * cprev * gf * (1.0f - gf);
+        dpre[2] = dc * gi_ * (1.0f - gg * gg);
+        dpre[3] = dout * go * (1.0f - go);
+        dc_rec = dc * gf;
+        carry = 0.f;
+        if (a.dbias) *reinterpret_cast<f32x4*>(&st_db[oi][0]) += dpre;
+      } else {
+        carry = dh_rec;  // frozen step: h_t = h_{t-1}
+      }
+      // 4. publish dG_s first: 8 bytes per cell into chunk unit >> 3 of the stream's image -- PLAIN store (the consumers sit on this XCD)
+      bf16x4 pk;
+      pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
+      char* xdst = reinterpret_cast<char*>(a.xbuf) + ((unsigned)(s & 1) * 8u + (unsigned)stream) * XBYTES;
+      if (unit < HP) *reinterpret_cast<bf16x4*>(xdst + xpos) = pk;
+      wait_vmcnt<0>();
+    }
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(myflags + (size_t)ug * FSPREAD, (unsigned)(s + 1), SK_RLX, __HIP_MEMORY_SCOPE_WORKGROUP);  // plain store
+      st_tpub = wall_clock64();
+    }
+    // 5. ... then the bulk stores of the step (dgx, zero at padded positions)
+    if (valid || (cellok && !a.offs)) {
+      *reinterpret_cast<f32x4*>(a.dgx + (row * 2 + dir) * 4 * H + 4 * (size_t)unit) = dpre;
+      if (a.dgx_bf) {
+        bf16x4 pk;
+        pk[0] = (__bf16)dpre[0]; pk[1] = (__bf16)dpre[1]; pk[2] = (__bf16)dpre[2]; pk[3] = (__bf16)dpre[3];
+        *reinterpret_cast<bf16x4*>(a.dgx_bf + row * a.ld_bf + (size_t)dir * 4 * H + 4 * (size_t)unit) = pk;
+      }
+    }
+  }
+  if (aborted) return;
+  if (a.dbias && owner) {
+    // bias gradient: this workgroup's dG summed over its 8 rows; the row of (batch-group-of-16 block, direction) receives the sums
+    // of its TWO 8-row groups by atomic adds -- two addends: the result does not depend on their order, and equals the 16-row
+    // kernel's (whose shuffle tree adds the two halves last)
+    f32x4 dbsum = *reinterpret_cast<const f32x4*>(&st_db[oi][0]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v = dbsum[q];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      dbsum[q] = v;
+    }
+    if (r == 0 && unit < H) {
+      float* dbp = a.dbias + ((size_t)(bg >> 1) * 2 + dir) * 4 * H + unit;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomicAdd(dbp + (size_t)q * H, dbsum[q]);
+    }
+  }
+  if (a.final_mm) {
+    // gradient wrt the initial state: one more product with the last published dG (the stream's step Tg - 1)
+    if (Tg > a.s_begin && w == 0) {
+      if (!wait_flags(myflags, NUG, (unsigned)Tg, a.ctrl, lane, 0LL, FSPREAD) && lane == 0) s_abort = 1;
+    }
+    __syncthreads();
+    if (s_abort) return;
+    float dh_rec = matmul((Tg - 1) & 1);
+    if (cellok) {
+      dh_rec += carry;
+      if (a.dh0) a.dh0[((size_t)dir * B + b) * H + unit] = dh_rec;
+      if (a.dc0) a.dc0[((size_t)dir * B + b) * H + unit] = dc_rec;
+    }
+  }
+}
+
+
 // Rows of a (nblk * 4H, C) matrix between torch's gate-major order (row g*H + u inside each block of 4H rows: the
 // order of weight_ih / weight_hh / bias rows, gates i,f,g,o) and the recurrence's gate-interleaved order (row 4u + g).
 //   back == 0: dst[4u + g] = src[g H + u]            (weights and biases -> the order gx / gates / dgx are kept in)
@@ -1564,7 +1810,14 @@ void launch_fwd_s3(const FwdArgs& a, int nblocks, hipStream_t st) {
 }
 template <int KS, bool BF>
 int launch_bwd(const BwdArgs& a, dim3 grid, hipStream_t st) {
-  if (a.G == 1)
+  // G = 1: the instantiation that keeps 113 KB of LDS -- a workgroup of gemm_f32_kernel_pl3 (48 KB) fits beside it and the weight
+  // gradients run CO-RESIDENT with the recurrence.  a.exclusive (mode bit 17) selects the 127 KB one instead: only a 32 KB split3
+  // workgroup would fit, the pl3 kernel does not -- the recurrence keeps its CUs to itself and the weight gradients take the CUs the
+  // grid leaves free.  The engine asks for that on RAGGED batches: once the short batch group's streams have left the grid, half
+  // the chip is idle for the rest of the launch and the weight gradients run there for free, while co-resident they only slow the
+  // long group's chain (measured, profiles/r06_wgrad_planes.txt: ragged 28.98 -> 28.48 ms exclusive, 29.40 co-resident; uniform
+  // 28.27 -> 27.95 co-resident, 28.11 exclusive).
+  if (a.G == 1 && !a.exclusive)
     hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF, 1>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
   else
     hipLaunchKernelGGL((lstm_bwd_kernel<KS, BF, GMAX>), dim3(grid.x * grid.y * grid.z), dim3(NTHREADS), 0, st, a);
@@ -1764,6 +2017,8 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, 
   const int map = ((mode >> 18) & 3) | (((mode >> 22) & 1) << 2);
   int poll_delay = (mode >> 23) & 31;  // as sk_lstm_fwd; 0 = none here until measured otherwise
   const int fast = (mode >> 29) & 1;   // (diagnostic builds only, BwdArgs::fast)
+  const bool xl8_bit = (mode >> 30) & 1;  // bit 30 (bf16): XCD-local streams of 8 rows (lstm_bwd_xl8_kernel)
+  const int exclusive = (mode >> 17) & 1;  // bit 17: keep the CUs to the recurrence (launch_bwd)
   mode &= 0xff;
   const WsLayout L = ws_layout(B, H, bf);
   hipStream_t st = (hipStream_t)stream;
@@ -1772,7 +2027,7 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, 
   a.dy = dy; a.whh = whh; a.gates = gates; a.cs = cs; a.c0 = c0; a.lens = lens; a.offs = offs;
   a.dgx = dgx; a.dh0 = dh0; a.dc0 = dc0; a.dhn = dhn; a.dcn = dcn;
   a.dbias = dbias;
-  a.dgx_bf = (__bf16*)dgx_bf16; a.ld_bf = ld_bf16; a.pl_bf = plane_bf16; a.fast = fast;
+  a.dgx_bf = (__bf16*)dgx_bf16; a.ld_bf = ld_bf16; a.pl_bf = plane_bf16; a.fast = fast; a.exclusive = exclusive;
   SK_CHECK_ARG(!plane_bf16 || !bf, "sk_lstm_bwd: planes of dgx are the fp32 configuration's (mode bit 16 = bf16 inputs is set)");
   a.xbuf = (float*)(base + L.xbuf); a.state = (float*)(base + L.state);
   a.flags = (unsigned*)(base + L.flags); a.ctrl = (unsigned*)(base + L.ctrl);
@@ -1789,7 +2044,13 @@ extern "C" int sk_lstm_bwd(const float* dy, const float* dhn, const float* dcn, 
   SK_CHECK_HIP(hipMemsetAsync(base + L.ctrl, 0, L.xbuf - L.ctrl, st));
   if (dbias)  // (the kernels ADD their sums: a sequence advanced in step launches accumulates)
     SK_CHECK_HIP(hipMemsetAsync(dbias, 0, (size_t)L.NBG * 8 * H * sizeof(float), st));  // rows >= grid y stay 0
-  if (mode == 1 || (mode == 0 && fits)) {
+  const bool xl8 = xl8_bit && bf && L.KS == 56 && B <= 32 && gmin <= 1 && num_cus() >= 256 && (mode == 1 || (mode == 0 && fits));
+  if (xl8) {  // (as sk_lstm_fwd's: 28 workgroups of 32 out units per (direction, 8-row group) stream, one XCD each)
+    a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;
+    a.NBG = (B + 7) / 8;
+    a.G = 1; a.nby = a.NBG;
+    hipLaunchKernelGGL((lstm_bwd_xl8_kernel<56>), dim3(256), dim3(NTHREADS), 0, st, a);
+  } else if (mode == 1 || (mode == 0 && fits)) {
     a.s_begin = 0; a.s_end = T; a.final_mm = want_d0;
     dispatch_bwd(L.KS, bf, a, grid, st);
   } else {

@@ -134,7 +134,7 @@ class Engine:
         # (bf16, r06: ninth field = XCD-local streams of 8 rows where the shape allows them -- 608 < H <= 896, B <= 32; mode bit 30)
         self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0,0,0,1" if self.bf16 else
                                 ("0,1,1,0,0,0,0,1" if hidden <= 896 else "0,1,1,0,0,8,1,0"))
-        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31,0,0")
+        self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31,0,0,1" if self.bf16 else "0,1,0,0,0,31,0,0")
         self.split3_fwd = bool(self.fwd_bits & 0x10000000) and not self.bf16 and hidden <= 896
         self.tagged_fwd = bool(self.fwd_bits & 0x20000000) and not self.bf16 and not self.split3_fwd
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one: the
@@ -164,6 +164,12 @@ class Engine:
         # products of the 128 x 128 split kernel.  SEPKERN_WGRAD_PLANES=0: that kernel on the fp32 operands (the r05 arrangement).
         # (hidden sizes that are no multiple of 8: the second direction's columns of a plane would start off a 16-byte boundary)
         self.wgrad_planes = os.environ.get("SEPKERN_WGRAD_PLANES", "1") != "0" and not self.bf16 and hidden % 8 == 0
+        # ... and whether the backward recurrences keep their CUs to themselves while those products run (sk_lstm_bwd mode bit 17):
+        # "auto" = on ragged batches -- there half the chip falls idle once the short batch group's streams have left the grid, the
+        # weight gradients run on those CUs for free, and co-resident they would only slow the long group's chain (ragged 28.98 ->
+        # 28.48 ms exclusive, 29.40 co-resident); on uniform batches nothing falls idle and co-residency wins (28.27 -> 27.95, 28.11
+        # exclusive; profiles/r06_wgrad_planes.txt).  "0" / "1": never / always.
+        self.bwd_exclusive = os.environ.get("SEPKERN_BWD_EXCLUSIVE", "auto")
         # diagnostics: sk_lstm_bwd mode bit 29 for the top layer's launch (1) or every layer's (2) -- read by timing-only builds
         # of the recurrence alone (csrc/lstm.hip SK_BWD_BOUND38); the product library ignores the bit
         self.bwd_diag = int(os.environ.get("SEPKERN_BWD_DIAG", "0"))
@@ -356,7 +362,9 @@ class Engine:
                 ahead_ev = torch.cuda.Event()
                 ahead_ev.record(side)
         inp, I = x2d, I0
-        planes = save and self.wgrad_planes
+        # (planes only under the split arithmetic: with fp32-MFMA variants asked for -- 8 / 1, the reference's literal arithmetic --
+        # the weight gradients stay fp32-MFMA products of the fp32 operands)
+        planes = save and self.wgrad_planes and self.var_side in (0, 2) and self.var_main in (0, 2, 9)
         inp_pl = None                                       # the planes of the current layer's input (made beside the layer below)
         for l in range(L):
             whh = self.p("weight_hh_l%d" % l)
@@ -559,6 +567,8 @@ class Engine:
             mode = self.lstm_mode | self.bwd_bits
             if self.bwd_diag == 2 or (self.bwd_diag == 1 and l == L - 1):
                 mode |= 0x20000000
+            if inp_pl is not None and (self.bwd_exclusive == "1" or (self.bwd_exclusive == "auto" and not pk.uniform and B > 16)):
+                mode |= 0x20000                          # exclusive: see __init__
             sl = slice(2 * l, 2 * l + 2)
             nbg = (B + 15) // 16
             dbias = torch.empty(nbg, 8 * H, device=dev)      # by-product of the recurrence: bias-gradient partials

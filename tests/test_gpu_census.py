@@ -23,6 +23,7 @@ GEMM_KERNELS = {
     6: "gemm_f32_kernel_streamk (fp32 MFMA, 256x256 persistent)", 9: "bf::gemm_bf16_kernel (fp32 operands rounded on the way in)",
     10: "gemm_f32_kernel_planes (split products, split once while staging, 256x128)",
     11: "bf2::gemm_bf16_nt_kernel<128>", 12: "bf2::gemm_bf16_nt_kernel<256>", 13: "bf2::gemm_bf16_streamk_kernel",
+    14: "gemm_f32_kernel_pl3 (split products on operands that arrive split, 128x128)",
 }
 # entry point -> the kernel(s) it launches when the choice does not depend on the arguments
 FIXED = {
@@ -32,7 +33,7 @@ FIXED = {
     "sk_bn_bwd_sums": "colred_kernel + colfin_kernel", "sk_bn_bwd_apply": "bn_bwd_apply_kernel", "sk_colsum": "colred_kernel + colfin_kernel",
     "sk_sigmoid_bwd": "sigmoid_bwd_kernel", "sk_pad_rows": "pad_rows_kernel", "sk_gate_rows": "gate_rows_kernel",
     "sk_hprev_rows": "hprev_rows_kernel", "sk_pack_rows": "pack_rows_kernel", "sk_unpack_rows": "pack_rows_kernel (unpack form)",
-    "sk_cast_bf16_rows": "bf2::cast_kernel", "sk_grad_norm": "sumsq_kernel + norm_fin_kernel", "sk_clip_adam": "clip_adam_kernel",
+    "sk_cast_bf16_rows": "bf2::cast_kernel", "sk_split_rows": "split_rows_kernel", "sk_grad_norm": "sumsq_kernel + norm_fin_kernel", "sk_clip_adam": "clip_adam_kernel",
     "sk_rsh_loss_fwd": "rsh_sse_kernel + rsh_select_kernel", "sk_rsh_loss_bwd": "rsh_bwd_kernel", "sk_att_update": "att_update_kernel",
     "sk_att_update_bwd": "att_update_bwd_kernel",
 }
@@ -51,17 +52,22 @@ def _lstm_kernel(name, args):
     if name == "sk_lstm_fwd":
         T, B, H, mode, offs = args[12], args[13], args[14], args[15], args[5]
     else:
-        T, B, H, mode, offs = args[16], args[17], args[18], args[19], args[8]
+        T, B, H, mode, offs = args[17], args[18], args[19], args[20], args[8]
     bf = bool(mode & 0x10000)
     s3 = name == "sk_lstm_fwd" and bool(mode & 0x10000000) and not bf and _pick_ks(H, True) != 64
     ks = _pick_ks(H, bf or s3)
     nbg = (B + 15) // 16
     g = next(g_ for g_ in range(1, 9) if ks * ((nbg + g_ - 1) // g_) * 2 <= 256)
     wgs = ks * ((nbg + g - 1) // g) * 2
+    if bool(mode & 0x40000000) and bf and ks == 56 and B <= 32:            # XCD-local streams of 8 rows (mode bit 30)
+        n8 = 2 * ((B + 7) // 8)
+        k = "lstm_fwd_xl8_kernel<56, %s>" % ("true" if offs else "false") if name == "sk_lstm_fwd" else "lstm_bwd_xl8_kernel<56>"
+        return k, "T=%d B=%d H=%d: %d streams of 28 workgroups x 32 units x 8 rows, one XCD each (%d CUs held)" % (T, B, H, n8, 28 * n8)
     if name == "sk_lstm_fwd":
         k = "lstm_fwd_kernel<%d, %s, 8, %s, %s>" % (ks, "true" if bf else "false", "true" if s3 else "false", "true" if offs else "false")
     else:
-        k = "lstm_bwd_kernel<%d, %s>" % (ks, "true" if bf else "false")
+        excl = bool(mode & 0x20000)
+        k = "lstm_bwd_kernel<%d, %s, %d>%s" % (ks, "true" if bf else "false", 1 if (g == 1 and not excl) else 8, " (exclusive)" if excl else "")
     return k, "T=%d B=%d H=%d: %d persistent workgroups (one per CU), %d batch group(s) each" % (T, B, H, wgs, g)
 
 
@@ -77,10 +83,12 @@ class Spy:
             self.orig(name, *args)
             side = torch.cuda.current_stream() != torch.cuda.default_stream()
             val = lambda a: getattr(a, "value", a)      # noqa: E731
-            if name in ("sk_gemm_f32_splitk", "sk_gemm_bf16_splitk", "sk_gemm_bf16_mm", "sk_gemm_bf16_nt"):
+            if name in ("sk_gemm_f32_splitk", "sk_gemm_bf16_splitk", "sk_gemm_bf16_mm", "sk_gemm_bf16_nt", "sk_gemm_pl3_tn"):
                 kid = lib.load().sk_gemm_last_kernel()
-                M, N, K = args[4], args[5], args[6]
-                if name == "sk_gemm_bf16_nt":
+                M, N, K = (args[3], args[4], args[5]) if name == "sk_gemm_pl3_tn" else (args[4], args[5], args[6])
+                if name == "sk_gemm_pl3_tn":
+                    form, batch, splitk = "T/N", args[12], args[16]
+                elif name == "sk_gemm_bf16_nt":
                     form, batch, splitk = "N/T", args[12], args[17]
                 else:
                     form = ("T" if args[10] else "N") + "/" + (("N" if args[11] else "T") if name == "sk_gemm_bf16_mm" else ("T" if args[11] else "N"))
@@ -103,7 +111,7 @@ class Spy:
         return False
 
 
-def _step(arch, H, L, S, B, T, dtype, env=None):
+def _step(arch, H, L, S, B, T, dtype, env=None, ragged=False):
     """One training step of the given configuration on a uniform batch; returns the spy's rows."""
     import uPIT
     from sepkern.optim import ClipAdam
@@ -122,7 +130,7 @@ def _step(arch, H, L, S, B, T, dtype, env=None):
         model.train()
         opt = ClipAdam(model, lr=1e-3, max_norm=0.25)
         g = torch.Generator(device="cuda").manual_seed(1)
-        pk = Packing.from_lens([T] * B, "cuda")
+        pk = Packing.from_lens([T - (i * (T // 2)) // max(1, B - 1) for i in range(B)] if ragged else [T] * B, "cuda")
         mix = torch.rand(pk.Rp, F, device="cuda", generator=g)
         srcs = [torch.rand(pk.Rp, F, device="cuda", generator=g) * 0.6 for _ in range(S)]
 
@@ -153,6 +161,8 @@ def _step(arch, H, L, S, B, T, dtype, env=None):
 
 CONFIGS = (
     ("BASELINE configs[1] (the headline): uPIT 3x896, 2-spk, 32 x 400, fp32", dict(arch="upit", H=896, L=3, S=2, B=32, T=400, dtype="fp32")),
+    ("the same model on a RAGGED batch (the WSJ0-2mix-shaped set: 32 utterances of 200 .. 400 frames)",
+     dict(arch="upit", H=896, L=3, S=2, B=32, T=400, dtype="fp32", ragged=True)),
     ("the same step in the reference's literal arithmetic (bench.py secondary.fp32_mfma: GEMM variants 8 / 1, plain forward product)",
      dict(arch="upit", H=896, L=3, S=2, B=32, T=400, dtype="fp32", env={"SEPKERN_GEMM_VARIANTS": "8,1", "SEPKERN_LSTM_FWD": "0,1,1,0,0,0,0,0"})),
     ("BASELINE configs[3]: uPIT 3x896, 3-spk, 32 x 400, bf16", dict(arch="upit", H=896, L=3, S=3, B=32, T=400, dtype="bf16")),
@@ -192,7 +202,7 @@ def test_design_md_carries_the_generated_census():
     assert have == md.strip(), "DESIGN.md's kernel census is stale: regenerate it (gpurun_out/census.md holds the current one)"
     # every fp32 GEMM kernel the library still carries serves a launch of some configuration above
     used = {r.split("|")[3].strip() for r in md.splitlines() if r.startswith("| ")}
-    for kid in (1, 2, 3, 4, 6, 10, 11, 12, 13):
+    for kid in (1, 2, 3, 4, 6, 10, 11, 12, 13, 14):
         assert GEMM_KERNELS[kid] in used, "no configuration launches " + GEMM_KERNELS[kid]
 
 

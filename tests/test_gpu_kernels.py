@@ -990,6 +990,26 @@ def test_lstm_forward_bf16_xcd_local_streams_of_eight_rows(ops, layout, T, B, H,
         out = fwd(ops.lstm_variant_bits(False, 1, True, False, True, delay, xl8=True))
         for a_, b_ in zip(out, ref):
             assert torch.equal(rows_of(a_), rows_of(b_))
+    # ... and the backward twin (lstm_bwd_xl8_kernel): dgx, its bf16 copy, dh0, dc0 and the bias-gradient partials bit for bit
+    dy = rw.put(torch.randn(T, B, 2 * H, generator=g))
+    dhn, dcn = torch.randn(2, B, H, generator=g).cuda(), torch.randn(2, B, H, generator=g).cuda()
+    y, gates, cs, hn, cn = ref
+
+    def bwd(bits):
+        gg = gates.clone()
+        dh0, dc0 = torch.zeros(2, B, H).cuda(), torch.zeros(2, B, H).cuda()
+        dbias = torch.full(((B + 15) // 16, 2, 4 * H), float("nan")).cuda()
+        twin = torch.zeros(rw.R, 8 * H, dtype=torch.bfloat16).cuda()
+        ws = ops.lstm_bwd(dy, whh, gg, cs, c0, rw.lens, gg, dh0, dc0, T, B, H, 1 | bits, dhn=dhn, dcn=dcn, bf16=True, dbias=dbias,
+                          dgx_bf16=twin, offs=rw.offs)
+        ops.lstm_status(ws)
+        return gg, twin, dh0, dc0, dbias
+    bref = bwd(ops.lstm_variant_bits(False, 1, False, False, False, 31))
+    for rep in range(2):
+        out = bwd(ops.lstm_variant_bits(False, 1, False, False, False, 31, xl8=True))
+        for a_, b_ in zip(out, bref):
+            assert torch.equal(rows_of(a_), rows_of(b_))
+    assert float(bref[2].abs().max()) > 0 and torch.isfinite(bref[4]).all()
 
 
 @pytest.mark.parametrize("layout", ["padded", "packed"])
