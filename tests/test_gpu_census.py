@@ -168,6 +168,8 @@ CONFIGS = (
     ("BASELINE configs[3]: uPIT 3x896, 3-spk, 32 x 400, bf16", dict(arch="upit", H=896, L=3, S=3, B=32, T=400, dtype="bf16")),
     ("BASELINE configs[0]'s model at the reference's batch size: uPIT 2x600, 2-spk, 100 x 400, fp32", dict(arch="upit", H=600, L=2, S=2, B=100, T=400, dtype="fp32")),
     ("BASELINE configs[4] (one GPU): RSH 2x600, 4-spk, 32 x 400, fp32", dict(arch="rsh", H=600, L=2, S=4, B=32, T=400, dtype="fp32")),
+    ("BASELINE configs[0] (the plumbing case): uPIT 2x300, 2-spk, 8 x 100, fp32 -- a hidden size that is no multiple of 8: fp32 operands, the 128 x 128 split kernel",
+     dict(arch="upit", H=300, L=2, S=2, B=8, T=100, dtype="fp32")),
 )
 
 
