@@ -15,15 +15,14 @@ import os
 import sys
 
 def is_split(name):
-    """fp32 products on the bf16 pipe: gemm_f32_kernel_split3<..>, gemm_f32_kernel_planes<..> and the S6 form
-    gemm_f32_kernel_streamk<.., .., true>."""
-    import re
-    return "gemm_f32_kernel_split3" in name or "gemm_f32_kernel_planes" in name or re.search(r"gemm_f32_kernel_streamk<\w+, \w+, true>", name) is not None
+    """fp32 products on the bf16 pipe: gemm_f32_kernel_split3<..>, gemm_f32_kernel_planes<..>, gemm_f32_kernel_pl3 (r06; the S6
+    stream-K form was retired)."""
+    return "gemm_f32_kernel_split3" in name or "gemm_f32_kernel_planes" in name or "gemm_f32_kernel_pl3" in name
 
 
 KEYS = ("gemm_f32_split_kernel", "gemm_f32_kernel", "gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "hprev_rows_kernel", "lstm_fwd_kernel",
-        "lstm_bwd_kernel", "clip_adam", "pit_pair", "pit_bwd", "bn_apply", "bn_bwd", "splitk_reduce", "colred", "sumsq")
-BF16_ONLY = ("gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel")
+        "lstm_bwd_kernel", "lstm_fwd_xl8_kernel", "lstm_bwd_xl8_kernel", "split_rows_kernel", "clip_adam", "pit_pair", "pit_bwd", "bn_apply", "bn_bwd", "splitk_reduce", "colred", "sumsq")
+BF16_ONLY = ("gemm_bf16_kernel", "gemm_bf16_nt_kernel", "cast_kernel", "lstm_fwd_xl8_kernel", "lstm_bwd_xl8_kernel")
 
 
 def kernel_source_id(root):

@@ -1590,6 +1590,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
       }
     }
   }
+  __builtin_amdgcn_sched_barrier(0);  // (nothing of what follows is to be computed above the weight load and kept alive across it)
 
   const int u_l = lane >> 4, n = lane & 15, sel = n >> 3, r = n & 7;
   const bool owner = w < 4;
