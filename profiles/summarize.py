@@ -21,7 +21,8 @@ def find(d, pat):
 def main():
     tag, trace = sys.argv[1], sys.argv[2]
     print("# rocprofv3 summary %s" % tag)
-    print("# command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary")
+    extra = " --dtype bf16 --num-spk 3" if tag.endswith("_bf16") else " --no-secondary --no-power-probe"
+    print("# command: rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux" + extra)
     rows = list(csv.DictReader(open(find(trace, "kernel_stats.csv"))))
     print("%-78s %6s %12s %12s %7s" % ("kernel", "calls", "total_ms", "avg_us", "pct"))
     for r in rows[:24]:
