@@ -135,8 +135,6 @@ class Engine:
         self.fwd_bits = variant("SEPKERN_LSTM_FWD", "0,1,1,0,1,0,0,0,1" if self.bf16 else
                                 ("0,1,1,0,0,0,0,1" if hidden <= 896 else "0,1,1,0,0,8,1,0"))
         self.bwd_bits = variant("SEPKERN_LSTM_BWD", "0,1,0,0,0,31,0,0,1" if self.bf16 else "0,1,0,0,0,31,0,0")
-        # (bf16 diagnostics: K slices of the weight-gradient launches that run beside a recurrence; 0 = the library's choice)
-        self.side_splitk_bf16 = int(os.environ.get("SEPKERN_BF16_SIDE_SPLITK", "0"))
         self.split3_fwd = bool(self.fwd_bits & 0x10000000) and not self.bf16 and hidden <= 896
         self.tagged_fwd = bool(self.fwd_bits & 0x20000000) and not self.bf16 and not self.split3_fwd
         # Weight-gradient GEMMs of layer l run on a side stream while layer l-1's recurrence runs on the main one: the
@@ -296,8 +294,7 @@ class Engine:
         a = dout2d if dout2d.dtype == torch.bfloat16 else self._copy(cache, dout2d)
         b = inp2d if inp2d.dtype == torch.bfloat16 else self._copy(cache, inp2d)
         ops.gemm_bf16_mm(a, b, gw, N, K, ops.pad_to(Rp, 64), a.shape[1], b.shape[1], K, a_kmajor=True, b_kmajor=True,
-                         accumulate=acc, batch=batch, sA=sA, sB=sB, sC=sC, splitk=self.side_splitk_bf16 if beside else 0, ws_tag=ws_tag,
-                         streamk=not beside and batch == 1)
+                         accumulate=acc, batch=batch, sA=sA, sB=sB, sC=sC, splitk=0, ws_tag=ws_tag, streamk=not beside and batch == 1)
 
     def _hprev(self, y, h0l, pk):
         """The recurrent inputs of a layer's packed rows (sk_hprev_rows), as the operand its recurrent weight gradient reads."""
