@@ -1527,7 +1527,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
 // K order, same sums as lstm_bwd_kernel<KS, true>: bit-identical dgx / dh0 / dc0 / dbias.  One batch group per workgroup (carry and
 // dc in registers); persistent launches only.
 template <int KS>
-__global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) void lstm_bwd_xl8_kernel(BwdArgs a) {
+__global__ __launch_bounds__(NTHREADS, 2) void lstm_bwd_xl8_kernel(BwdArgs a) {
   constexpr int HP = 16 * KS;
   constexpr int NUG = HP / 32;      // workgroups per stream
   constexpr int NCHK = HP * 4 / 32; // 512-byte chunks of a stream's dG image
@@ -1565,8 +1565,10 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(192))) 
       const int uout = ug * 32 + 16 * tt + i;
       // Unconditional loads from clamped addresses + a mask (per-element "load or zero" branches serialise the 224 loads of the
       // slice, each behind its own s_waitcnt).  The element offset of (chunk c, slot j) is min(off0_j + c 8 H, lim_j): eight
-      // running 32-bit offsets -- computed afresh per load the scheduler hoists all 224 address computations to the top (256
-      // VGPRs and spills in a kernel whose loop needs ~190, and no GEMM wave fits beside it)
+      // running 32-bit offsets -- computed afresh per load the scheduler hoists all 224 address computations to the top.  As
+      // built the kernel still takes all 256 VGPRs, with 40 dwords spilled in THIS prologue only (the loop needs ~190 and does
+      // not spill): two waves per SIMD fill the register file, no GEMM wave fits beside this kernel -- the side-stream weight
+      // gradients run on the 32 CUs its grid leaves free (profiles/r06_bf16_xcd_local_streams_of_8_rows.txt)
       const float* wbase = a.whh + (size_t)dir * 4 * H * H + min(uout, H - 1);
       unsigned off[8], lim[8];
 #pragma unroll
